@@ -1,0 +1,367 @@
+"""CPU ORACLE for the MMDiT flow-matching hot path.  TEST INFRASTRUCTURE ONLY.
+
+This file restates, in plain torch-CPU ops, the algorithm of the reference
+(gmongaras/Stable-Diffusion-3-From-Scratch @ /root/reference) for the one hot
+path this repo accelerates.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it; the product path (the package + libmmdit_hip.so)
+never does and fails loudly when the HIP library is missing.
+
+Parity pin: every function here is checked against outputs of the reference
+itself, imported in the build container by tools/make_goldens.py (three
+sys.modules stubs) and committed as fixtures under tests/golden/.
+The xformers SwiGLU boundary (un-vendored third party, xformers==0.0.29.post3,
+reference README.md:69) is restated from its documented eager semantics and is
+"parity unpinned" at that boundary only; the FLUX VAE (diffusers==0.30.3) is not
+restated here at all.
+
+Reference citations (file:line are into /root/reference/src):
+  forward            models/diff_model.py:264-346
+  block              blocks/Transformer_Block_Dual.py:56-77
+  attention          blocks/Attention.py:118-135, 174-194, 258-284, 410-425
+  rope               blocks/rotary_embedding.py:36-76, 269-321
+  mlp                blocks/MLP.py:25-40 (+ xformers SwiGLU eager semantics)
+  norm               blocks/Norm.py:16-22
+  time embedding     blocks/PositionalEncoding.py:15-30
+  patch embed        blocks/ImagePositionalEncoding.py:114-116, 175-187
+  unpatchify         blocks/patchify.py:41-72
+  noise / loss / opt model_trainer.py:378-503, models/diff_model.py:229-241
+  sampler            models/diff_model.py:367-429
+
+Rounding modes (OracleConfig):
+  attn_core = "oracle_bf16": the reference CPU branch, Attention.py:277-284
+              (QK^T rounded to bf16, scaled in bf16, softmax in bf16, PV in bf16)
+            = "fp32":        exact softmax attention
+            = "flash_bf16":  the HIP fast path's rounding points (bf16 Q/K/V,
+              fp32 scores, P=exp(s-m) rounded to bf16, fp32 row sum, O/l -> bf16)
+  gemm      = "fp32":  reference arithmetic (fp32 weights and activations)
+            = "bf16":  operands (weights and GEMM inputs) rounded to bf16 at the
+              same points as the HIP fast path, fp32 accumulation; intermediate
+              GEMM outputs that the fast path stores as bf16 are rounded too.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+FP32_EPS = torch.finfo(torch.float32).eps  # nn.RMSNorm(eps=None) on fp32 input
+
+
+@dataclass
+class OracleConfig:
+    dim: int = 256
+    num_heads: int = 4
+    num_blocks: int = 2
+    hidden_scale: float = 4.0
+    patch_size: int = 2
+    inCh: int = 16
+    class_dim: int = 768
+    MLP_type: str = "swiglu"
+    text_hidden: int = 2304
+    attn_core: str = "oracle_bf16"
+    gemm: str = "fp32"
+
+    @property
+    def head_dim(self):
+        return self.dim // self.num_heads
+
+    @property
+    def hidden(self):
+        return int(self.dim * self.hidden_scale)
+
+
+# ----------------------------------------------------------------------------
+# rounding helpers
+# ----------------------------------------------------------------------------
+def _rb(x: torch.Tensor) -> torch.Tensor:
+    """Round to bf16 and back, straight-through for autograd."""
+    return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
+
+
+def _lin(cfg: OracleConfig, x, w, b=None):
+    """nn.Linear; in gemm=bf16 mode both operands are rounded to bf16 first."""
+    if cfg.gemm == "bf16":
+        x = _rb(x)
+        w = _rb(w)
+    return F.linear(x, w, b)
+
+
+def _act(cfg: OracleConfig, x):
+    """Activation tensor that the HIP fast path stores as bf16."""
+    return _rb(x) if cfg.gemm == "bf16" else x
+
+
+# ----------------------------------------------------------------------------
+# leaf functions
+# ----------------------------------------------------------------------------
+def positional_encoding(time: torch.Tensor, dim: int) -> torch.Tensor:
+    """PositionalEncoding.forward (blocks/PositionalEncoding.py:15-30).
+    denom_i = 10000^(2i/dim) for i = 0..dim-1 (not dim/2); output is
+    cat(sin(e[:, 0::2]), cos(e[:, 1::2]))."""
+    denom = (torch.tensor(10000.0) ** ((2 * torch.arange(dim)) / dim)).to(torch.float32)
+    e = time[:, None] / denom[None, :]
+    return torch.cat((e[:, ::2].sin(), e[:, 1::2].cos()), dim=1)
+
+
+def rms_norm(x: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """nn.RMSNorm(dim) with eps=None on fp32 input -> eps = finfo(fp32).eps."""
+    return F.rms_norm(x, (x.shape[-1],), w, FP32_EPS)
+
+
+def norm_modulate(x, y, w_scale, w_shift, cfg: OracleConfig):
+    """Norm.forward (blocks/Norm.py:16-22): LN(no affine, eps 1e-5)*(1+W_s y)+W_h y."""
+    xn = F.layer_norm(x, (x.shape[-1],))
+    return xn * (1 + _lin(cfg, y, w_scale)[:, None, :]) + _lin(cfg, y, w_shift)[:, None, :]
+
+
+def rope_inv_freq(head_dim: int) -> torch.Tensor:
+    """RotaryEmbedding(dim=head_dim//2) 'lang' frequencies
+    (blocks/rotary_embedding.py:120; Attention.py:98)."""
+    d = head_dim // 2
+    return 1.0 / (10000 ** (torch.arange(0, d, 2)[: d // 2].float() / d))
+
+
+def axial_freqs(height: int, width: int, inv_freq: torch.Tensor) -> torch.Tensor:
+    """get_axial_freqs(height, width) (blocks/rotary_embedding.py:269-288):
+    (h, w, head_dim) angles; first half <- row index, second half <- column
+    index, each frequency repeated twice (interleaved pairs)."""
+    fh = torch.arange(height).float()[:, None] * inv_freq[None, :]
+    fw = torch.arange(width).float()[:, None] * inv_freq[None, :]
+    fh = fh.repeat_interleave(2, dim=-1)[:, None, :].expand(height, width, -1)
+    fw = fw.repeat_interleave(2, dim=-1)[None, :, :].expand(height, width, -1)
+    return torch.cat([fh, fw], dim=-1)
+
+
+def rotate_half(x):
+    """(x0,x1,x2,x3,..) -> (-x1,x0,-x3,x2,..) (blocks/rotary_embedding.py:36-40)."""
+    x = x.reshape(*x.shape[:-1], -1, 2)
+    x1, x2 = x.unbind(dim=-1)
+    return torch.stack((-x2, x1), dim=-1).reshape(*x.shape[:-2], -1)
+
+
+def apply_rope(freqs, t):
+    """apply_rotary_emb (blocks/rotary_embedding.py:43-76), full-width rotation."""
+    return t * freqs.cos() + rotate_half(t) * freqs.sin()
+
+
+def attention_core(q, k, v, scale: float, mode: str):
+    """softmax(q k^T * scale) v on (B,H,S,hd) tensors.
+    oracle_bf16 reproduces the op sequence of Attention.py:277-284."""
+    if mode == "oracle_bf16":
+        attn = (q.to(torch.bfloat16) @ k.to(torch.bfloat16).mT) * scale
+        attn = attn.softmax(dim=-1)
+        return (attn @ v.to(torch.bfloat16)).to(q.dtype)
+    if mode == "fp32":
+        attn = ((q @ k.mT) * scale).softmax(dim=-1)
+        return attn @ v
+    if mode == "flash_bf16":
+        qb, kb, vb = _rb(q), _rb(k), _rb(v)
+        s = (qb @ kb.mT) * scale
+        m = s.amax(dim=-1, keepdim=True)
+        p = torch.exp(s - m)
+        l = p.sum(dim=-1, keepdim=True)
+        o = (_rb(p) @ vb) / l
+        return _rb(o)
+    raise ValueError(mode)
+
+
+def patch_embed(x_t, w_patch, cfg: OracleConfig):
+    """PatchEmbed.forward with pos_embed=None: Conv2d(k=p, stride=p, no bias),
+    flatten(2).transpose(1,2)  (blocks/ImagePositionalEncoding.py:114-116, 181-183)."""
+    if cfg.gemm == "bf16":
+        x_t, w_patch = _rb(x_t), _rb(w_patch)
+    y = F.conv2d(x_t, w_patch, None, stride=cfg.patch_size)
+    return y.flatten(2).transpose(1, 2)
+
+
+def unpatchify(patches, patch_size: int, hw):
+    """blocks/patchify.py:41-72; patch vector order is (C, ph, pw)."""
+    n, _, pd = patches.shape
+    h, w = hw
+    nh, nw = (h + patch_size - 1) // patch_size, (w + patch_size - 1) // patch_size
+    ch = pd // (patch_size * patch_size)
+    x = patches.view(n, nh, nw, ch, patch_size, patch_size).permute(0, 3, 1, 4, 2, 5).contiguous()
+    return x.view(n, ch, nh * patch_size, nw * patch_size)[:, :, :h, :w]
+
+
+def mlp(x, sd, prefix: str, cfg: OracleConfig):
+    """MLP.forward (blocks/MLP.py:25-40).  swiglu = xformers SwiGLU eager
+    semantics: w3(silu(x W1^T + b1) * (x W2^T + b2)) + b3, [W1;W2] = w12."""
+    if cfg.MLP_type == "swiglu":
+        gu = _act(cfg, _lin(cfg, x, sd[prefix + "MLP.w12.weight"], sd[prefix + "MLP.w12.bias"]))
+        g, u = gu.chunk(2, dim=-1)
+        h = _act(cfg, F.silu(g) * u)
+        return _lin(cfg, h, sd[prefix + "MLP.w3.weight"], sd[prefix + "MLP.w3.bias"])
+    if cfg.MLP_type == "gelu":
+        u = _act(cfg, _lin(cfg, x, sd[prefix + "lin_up.weight"], sd[prefix + "lin_up.bias"]))
+        h = _act(cfg, F.gelu(u))
+        return _lin(cfg, h, sd[prefix + "lin_down.weight"], sd[prefix + "lin_down.bias"])
+    raise ValueError(cfg.MLP_type)
+
+
+def attention(x, c, sd, prefix: str, cfg: OracleConfig, hw, last: bool, taps: Optional[dict] = None):
+    """Attention.forward, dual / softmax / RoPE2d branch (blocks/Attention.py)."""
+    B, N, d = x.shape
+    M = c.shape[1]
+    H, hd = cfg.num_heads, cfg.head_dim
+
+    def heads(t, L):
+        return t.reshape(B, L, H, hd).permute(0, 2, 1, 3)
+
+    q_x = rms_norm(heads(_act(cfg, _lin(cfg, x, sd[prefix + "query_proj_x.weight"])), N), sd[prefix + "q_norm_x.weight"])
+    k_x = rms_norm(heads(_act(cfg, _lin(cfg, x, sd[prefix + "key_proj_x.weight"])), N), sd[prefix + "k_norm_x.weight"])
+    v_x = heads(_act(cfg, _lin(cfg, x, sd[prefix + "value_proj_x.weight"])), N)
+    q_c = rms_norm(heads(_act(cfg, _lin(cfg, c, sd[prefix + "query_proj_c.weight"])), M), sd[prefix + "q_norm_c.weight"])
+    k_c = rms_norm(heads(_act(cfg, _lin(cfg, c, sd[prefix + "key_proj_c.weight"])), M), sd[prefix + "k_norm_c.weight"])
+    v_c = heads(_act(cfg, _lin(cfg, c, sd[prefix + "value_proj_c.weight"])), M)
+
+    # RoPE2d on image tokens only; patch size hard-coded to 2 (Attention.py:178-179)
+    h2, w2 = hw[0] // 2, hw[1] // 2
+    freqs = axial_freqs(h2, w2, sd[prefix + "rotary_emb.freqs"])
+    q_x = apply_rope(freqs, q_x.reshape(B, H, h2, w2, hd)).reshape(B, H, -1, hd)
+    k_x = apply_rope(freqs, k_x.reshape(B, H, h2, w2, hd)).reshape(B, H, -1, hd)
+
+    q = torch.cat([q_x, q_c], dim=2)
+    k = torch.cat([k_x, k_c], dim=2)
+    v = torch.cat([v_x, v_c], dim=2)
+    if taps is not None:
+        taps["q"], taps["k"], taps["v"] = q.detach(), k.detach(), v.detach()
+    o = attention_core(q, k, v, hd ** -0.5, cfg.attn_core)
+    if taps is not None:
+        taps["attn_core"] = o.detach()
+    o_x = o[:, :, :N].permute(0, 2, 1, 3).reshape(B, N, -1)
+    o_c = o[:, :, N:].permute(0, 2, 1, 3).reshape(B, M, -1)
+    a_x = _lin(cfg, o_x, sd[prefix + "out_proj_x.weight"])
+    a_c = o_c if last else _lin(cfg, o_c, sd[prefix + "out_proj_c.weight"])
+    return a_x, a_c
+
+
+def block(X, c, y, sd, i: int, cfg: OracleConfig, hw, taps: Optional[dict] = None):
+    """Transformer_Block_Dual.forward (blocks/Transformer_Block_Dual.py:56-77)."""
+    p = f"blocks.{i}."
+    last = i == cfg.num_blocks - 1
+    y = F.silu(_lin(cfg, y, sd[p + "y_proj.0.weight"], sd[p + "y_proj.0.bias"]))
+
+    def nrm(Z, name):
+        return _act(cfg, norm_modulate(Z, y, sd[p + name + ".c_scale.weight"], sd[p + name + ".c_shift.weight"], cfg))
+
+    def gate(name):
+        return _lin(cfg, y, sd[p + name + ".weight"])[:, None, :]
+
+    n1x, n1c = nrm(X, "norm1_x"), nrm(c, "norm1_c")
+    a_x, a_c = attention(n1x, n1c, sd, p + "attn.", cfg, hw, last, taps)
+    if taps is not None:
+        taps.update(y_proj=y.detach(), norm1_x=n1x.detach(), norm1_c=n1c.detach(), attn_x=a_x.detach(), attn_c=a_c.detach())
+    X = a_x * gate("scale1_x") + X
+    if not last:
+        c = a_c * gate("scale1_c") + c
+    m_x = mlp(nrm(X, "norm2_x"), sd, p + "MLP_x.", cfg)
+    if taps is not None:
+        taps["mlp_x"] = m_x.detach()
+    X = m_x * gate("scale2_x") + X
+    if not last:
+        c = mlp(nrm(c, "norm2_c"), sd, p + "MLP_c.", cfg) * gate("scale2_c") + c
+    return X, c
+
+
+def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, x_t, t, c, c_pooled,
+            nullCls_pooled=None, nullCls_gemma=None, nullCls_bert=None,
+            taps: Optional[dict] = None):
+    """diff_model.forward (models/diff_model.py:264-346).  Like the reference it
+    zeroes the caller's c / c_pooled rows IN PLACE for null-masked samples."""
+    with torch.no_grad():
+        if nullCls_pooled is not None:
+            c_pooled[nullCls_pooled] *= 0
+        if nullCls_gemma is not None:
+            c[nullCls_gemma, :77] *= 0
+        if nullCls_bert is not None:
+            c[nullCls_bert, 77:] *= 0
+    d = cfg.dim
+    pe = positional_encoding(t.float() * sd["time_scale"], d)
+    t_emb = _lin(cfg, pe, sd["t_emb2.weight"])
+    y = t_emb + _lin(cfg, c_pooled.to(torch.float32), sd["cond_MLP.weight"])
+    hw = x_t.shape[-2:]
+    cf = c.to(torch.float32)
+    ctx = torch.cat([
+        _lin(cfg, sd["learnable_scalar"] * rms_norm(cf[:, :77], sd["pre_c_norm.weight"]), sd["c_proj.weight"]),
+        _lin(cfg, sd["learnable_scalar2"] * rms_norm(cf[:, 77:], sd["pre_c_norm2.weight"]), sd["c_proj2.weight"]),
+    ], dim=1)
+    X = patch_embed(x_t.to(torch.float32), sd["pos_enc.proj.weight"], cfg)
+    X = _lin(cfg, X, sd["patch_emb.weight"], sd["patch_emb.bias"])
+    if taps is not None:
+        taps.update(y=y.detach(), c0=ctx.detach(), x0=X.detach(), blocks=[])
+    for i in range(cfg.num_blocks):
+        bt = {} if (taps is not None and i == 0) else None
+        X, ctx = block(X, ctx, y, sd, i, cfg, hw, bt)
+        if taps is not None:
+            taps["blocks"].append((X.detach(), ctx.detach()))
+            if bt is not None:
+                taps["block0"] = bt
+    Z = _act(cfg, norm_modulate(X, y, sd["out_norm.c_scale.weight"], sd["out_norm.c_shift.weight"], cfg))
+    Z = _lin(cfg, Z, sd["out_proj.weight"], sd["out_proj.bias"])
+    return unpatchify(Z, cfg.patch_size, hw)
+
+
+# ----------------------------------------------------------------------------
+# training step (model_trainer.py:378-503) and sampler (diff_model.py:367-429)
+# ----------------------------------------------------------------------------
+def noise_batch(x0, t, eps):
+    """diff_model.noise_batch with the noise passed in (diff_model.py:229-241)."""
+    tt = t[:, None, None, None]
+    return (1 - tt) * x0 + tt * eps
+
+
+def rectified_flow_loss(v_pred, x0, eps):
+    """model_trainer.py:429-446: MSE(v_pred, eps - x0), per-sample flatten, global mean."""
+    return F.mse_loss(v_pred, (eps - x0), reduction="none").flatten(1, -1).mean()
+
+
+def warmup_lr(step: int, warmup_steps: int) -> float:
+    """HF get_constant_schedule_with_warmup lambda (model_trainer.py:25-41)."""
+    return 1.0 if step >= warmup_steps else float(step) / float(max(1.0, warmup_steps))
+
+
+class OracleTrainer:
+    """fwd + bwd + clip(1.0) + AdamW(lr, (0.9,0.999), 1e-8, wd 0.01) + constant-with-warmup
+    schedule, restating model_trainer.py:260-263, 463-503 on the oracle forward."""
+
+    def __init__(self, sd, cfg: OracleConfig, lr=1e-4, warmup_steps=0):
+        self.cfg = cfg
+        self.sd = {k: v.clone().requires_grad_(k.split(".")[-1] != "freqs") for k, v in sd.items()}
+        self.params = [v for v in self.sd.values() if v.requires_grad]
+        self.optim = torch.optim.AdamW(self.params, lr=lr, eps=1e-8, weight_decay=0.01, betas=(0.9, 0.999))
+        self.base_lr, self.warmup_steps, self.step_idx = lr, warmup_steps, 0
+        for g in self.optim.param_groups:
+            g["lr"] = lr * warmup_lr(0, warmup_steps)
+
+    def step(self, x0, eps, t, c, c_pooled, nulls=(None, None, None)):
+        x_t = noise_batch(x0, t, eps)
+        v = forward(self.sd, self.cfg, x_t, t, c, c_pooled, *nulls)
+        loss = rectified_flow_loss(v, x0, eps)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.params, 1.0)
+        self.optim.step()
+        self.step_idx += 1
+        for g in self.optim.param_groups:
+            g["lr"] = self.base_lr * warmup_lr(self.step_idx, self.warmup_steps)
+        self.optim.zero_grad()
+        return loss.detach()
+
+
+@torch.no_grad()
+def euler_cfg_sample(sd, cfg: OracleConfig, noise, text_hidden, text_pooled, num_steps: int, cfg_scale: float):
+    """sample_imgs, sampler='euler' (diff_model.py:384-429), up to (not including) VAE decode."""
+    B = noise.shape[0]
+    out = noise.clone()
+    null = torch.tensor([0] * B + [1] * B).bool()
+    th = text_hidden.repeat(2 * B, 1, 1)
+    tp = text_pooled.repeat(2 * B, 1)
+    for t in torch.linspace(1, 1.0 / num_steps, num_steps):
+        tt = t.repeat(2 * B)
+        v = forward(sd, cfg, out.repeat(2, 1, 1, 1), tt, th, tp, null, null, null)
+        v = (1 + cfg_scale) * v[:B] - cfg_scale * v[B:]
+        out = out - v * (1 / num_steps)
+    return out
