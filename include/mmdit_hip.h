@@ -1,0 +1,186 @@
+/*
+ * mmdit_hip.h -- C ABI of libmmdit_hip.so: the MI355X (gfx950) kernels behind the
+ * MMDiT flow-matching training path of gmongaras/Stable-Diffusion-3-From-Scratch.
+ *
+ * The reference has no native code: its GPU arithmetic is reached through
+ * torch / flash-attn / xformers call sites in src/blocks and src/models
+ * (SURVEY.md 2b).  Each entry point below replaces one of those call sites and
+ * cites it (file:line into the reference's src/).  Conventions:
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
+ *     owned by the caller (workspaces and saved-for-backward buffers included);
+ *   - the library allocates nothing, keeps no mutable global state, never
+ *     synchronises the device and launches only on the stream it is given;
+ *   - re-entrant: safe to call from the autograd worker thread;
+ *   - return value: 0 on success, MMDIT_ERR_* (<0) for invalid arguments, or a
+ *     positive hipError_t from the launch.
+ * dtype codes: MMDIT_F32 / MMDIT_BF16.  "T" below = activation dtype of the
+ * caller's precision mode (bf16 = fast mode, f32 = parity mode).
+ */
+#ifndef MMDIT_HIP_H
+#define MMDIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMDIT_F32 0
+#define MMDIT_BF16 1
+
+#define MMDIT_ERR_ARG (-1)      /* null pointer / bad size / misaligned */
+#define MMDIT_ERR_DTYPE (-2)    /* dtype combination not built */
+#define MMDIT_ERR_SHAPE (-3)    /* unsupported shape (e.g. head_dim != 64) */
+
+#define MMDIT_ACT_NONE 0
+#define MMDIT_ACT_SILU 1
+
+#define MMDIT_PREC_BF16 0       /* single-pass bf16 MFMA operands, fp32 accumulate */
+#define MMDIT_PREC_SPLIT 1      /* split-bf16 (hi+lo) 3-pass MFMA: fp32-grade products */
+
+typedef void* mmdit_stream_t;   /* hipStream_t */
+
+/* library/ABI version and build target ("gfx950") */
+int mmdit_abi_version(void);
+const char* mmdit_build_arch(void);
+
+/* ---------------------------------------------------------------------------
+ * GEMM:  C[M,N] = epilogue( A[M,K] * B[N,K]^T )         fp32 accumulation on MFMA
+ * Replaces every nn.Linear on the path (Attention.py:130-135, 424-425;
+ * MLP.py:19,32 / xformers SwiGLU w12,w3; Norm.py:13-14; Transformer_Block_Dual.py
+ * :25-28,49-53; diff_model.py:306-332,339) and their autograd dgrad/wgrad.
+ *   a_kmajor=0: A stored (M,K) row-major, lda >= K.   a_kmajor=1: A stored (K,M), lda >= M.
+ *   b_kmajor=0: B stored (N,K) row-major (nn.Linear weight), ldb >= K.  b_kmajor=1: B stored (K,N).
+ *   forward = (0,0); dgrad dX = dY * W uses (0,1) with B=W; wgrad dW = dY^T X uses (1,1).
+ * Epilogue, in order:  v = acc (+ bias[n]);  aux = v (optional, raw pre-activation copy);
+ *   v = act(v);  v = residual[m,n] + gate[(m / rows_per_batch), n] * v   (gate optional -> residual + v);
+ *   C = (accumulate ? C + v : v).
+ * Requirements: K%8==0 for row-major operands, M%8==0 / N%8==0 for k-major operands,
+ * 16-byte aligned bases and leading dimensions.
+ * ------------------------------------------------------------------------- */
+typedef struct {
+  const void* A; int a_dtype; int a_kmajor; int64_t lda;
+  const void* B; int b_dtype; int b_kmajor; int64_t ldb;
+  void* C; int c_dtype; int64_t ldc;
+  int M, N, K;
+  const float* bias;
+  int act;
+  const float* gate; int64_t ld_gate; int rows_per_batch;
+  const float* residual; int64_t ld_res;
+  void* aux; int aux_dtype; int64_t ld_aux;
+  int accumulate;
+  int precision;
+} mmdit_gemm_args;
+int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
+
+/* dtype conversion of n elements (bf16 shadow copies of the fp32 master weights; the
+ * reference gets these from torch.autocast, model_trainer.py:416). n%8==0 not required. */
+int mmdit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, mmdit_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * adaLN: out = LayerNorm(x; eps=1e-5, no affine) * (1 + scale[b,:]) + shift[b,:]
+ * Norm.forward, blocks/Norm.py:16-22.  x fp32 (rows, d) residual stream;
+ * scale/shift fp32 with leading dimension ld_mod (slices of the per-block
+ * modulation matrix); b = row / rows_per_batch.  Saves mean/rstd per row.
+ * bwd: dx = dres + LN-backward(dout * (1+scale));  dscale[b,:] += sum_rows dout*xhat;
+ *      dshift[b,:] += sum_rows dout   (atomic fp32 accumulation, caller zero-inits).
+ * d%4==0, d<=4096.
+ * ------------------------------------------------------------------------- */
+int mmdit_ln_modulate_fwd(const float* x, const float* scale, const float* shift, int64_t ld_mod,
+                          int rows, int d, int rows_per_batch,
+                          void* out, int out_dtype, float* mean, float* rstd, mmdit_stream_t stream);
+int mmdit_ln_modulate_bwd(const void* dout, int dout_dtype, const float* x, const float* mean, const float* rstd,
+                          const float* scale, int64_t ld_mod, const float* dres,
+                          int rows, int d, int rows_per_batch,
+                          float* dx, float* dscale, float* dshift, int64_t ld_dmod, mmdit_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Text pre-norm: out = scalar * RMSNorm_w(x), eps = FLT_EPSILON (nn.RMSNorm(eps=None) on fp32)
+ * diff_model.py:164-172, 323-326.  Rows are (b, j) with j in [0,154): rows with j < split use
+ * (w1, s1), the others (w2, s2).  out is written as two contiguous halves:
+ * out1[(b*split + j), :] and out2[(b*(tokens-split) + j - split), :].
+ * bwd accumulates dw1,dw2 (d) and ds1,ds2 (1) atomically (x has no gradient in the reference).
+ * ------------------------------------------------------------------------- */
+int mmdit_text_rmsnorm_fwd(const void* x, int x_dtype, const float* w1, const float* w2, const float* s1, const float* s2,
+                           int batch, int tokens, int split, int d, void* out1, void* out2, int out_dtype, mmdit_stream_t stream);
+int mmdit_text_rmsnorm_bwd(const void* dout1, const void* dout2, int dout_dtype, const void* x, int x_dtype,
+                           const float* w1, const float* w2, const float* s1, const float* s2,
+                           int batch, int tokens, int split, int d,
+                           float* dw1, float* dw2, float* ds1, float* ds2, mmdit_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Per-head QK RMSNorm + axial 2-D RoPE + head split into the joint [image;text] buffers.
+ * Attention.py:130-135 (q/k_norm_*), 178-194 + rotary_embedding.py:36-76,269-288 (RoPE2d),
+ * 259-261 (cat).  qkv: (batch*tokens, 3*dim) rows of one stream = [q | k | v], head_dim = 64.
+ * Writes bf16 Q,K,V of shape (batch, heads, S_total, 64) at token offset tok0.
+ * rope_cos/rope_sin: fp32 (tokens, 64) tables or NULL (text stream: no rotation).
+ * bwd: dqkv from dQ,dK,dV (dtype dq_dtype), dwq/dwk (64) accumulated atomically.
+ * ------------------------------------------------------------------------- */
+int mmdit_qk_norm_rope_fwd(const void* qkv, int qkv_dtype, const float* wq, const float* wk,
+                           const float* rope_cos, const float* rope_sin,
+                           int batch, int tokens, int heads, int s_total, int tok0,
+                           void* Q, void* K, void* V, mmdit_stream_t stream);
+int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void* dV, int dq_dtype,
+                           const void* qkv, int qkv_dtype, const float* wq, const float* wk,
+                           const float* rope_cos, const float* rope_sin,
+                           int batch, int tokens, int heads, int s_total, int tok0,
+                           void* dqkv, int dqkv_dtype, float* dwq, float* dwk, mmdit_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Joint softmax attention core, non-causal, head_dim 64, bf16 operands, fp32 accumulate.
+ * Replaces flash_attn_func (Attention.py:293) and its CPU twin (Attention.py:277-284).
+ * Q,K,V: bf16 (batch, heads, S, 64).  Output is written head-merged and split by stream:
+ * Ox (batch, n_img, heads*64), Oc (batch, S-n_img, heads*64), bf16.  lse: fp32 (batch,heads,S).
+ * mode 0: flash (fp32 scores, online softmax).  mode 1: reproduces the rounding points of the
+ * reference's CPU branch (scores->bf16, *scale->bf16, softmax->bf16, PV->bf16; two passes).
+ * bwd: dOx/dOc bf16 (dOc may be NULL = zeros, last block), delta fp32 workspace (batch,heads,S),
+ * dQ,dK,dV written (not accumulated) in dq_dtype.
+ * ------------------------------------------------------------------------- */
+int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img,
+                   float scale, int mode, void* Ox, void* Oc, float* lse, mmdit_stream_t stream);
+int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc,
+                   const void* dOx, const void* dOc, const float* lse, float* delta,
+                   int batch, int heads, int S, int n_img, float scale,
+                   void* dQ, void* dK, void* dV, int dq_dtype, mmdit_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * MLP activations.  swiglu: h = silu(g) * u with [g | u] = gu (rows, 2*hidden)  (xformers SwiGLU
+ * eager semantics behind MLP.py:19,32).  gelu: h = gelu_erf(u) (MLP.py:21-23,36-40).
+ * bwd also accumulates the column sums of the produced gradient into dbias (bias grad of the
+ * preceding Linear), atomically; dbias may be NULL.
+ * ------------------------------------------------------------------------- */
+int mmdit_swiglu_fwd(const void* gu, void* h, int dtype, int rows, int hidden, mmdit_stream_t stream);
+int mmdit_swiglu_bwd(const void* dh, const void* gu, void* dgu, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t stream);
+int mmdit_gelu_fwd(const void* u, void* h, int dtype, int rows, int hidden, mmdit_stream_t stream);
+int mmdit_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t stream);
+/* d(pre) = dy * silu'(pre): y_proj's SiLU (Transformer_Block_Dual.py:25-28). dbias accumulates column sums. */
+int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, mmdit_stream_t stream);
+
+/* Backward of  Y = X + gate[b,:] * acc  (Transformer_Block_Dual.py:64-66,70-76):
+ * dacc = dy * gate[b,:] (dtype dacc_dtype); dgate[b,:] += sum_rows dy*acc; dbias[:] += sum_rows dacc (optional). */
+int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate,
+                            int rows, int d, int rows_per_batch, void* dacc, int dacc_dtype,
+                            float* dgate, int64_t ld_dgate, float* dbias, mmdit_stream_t stream);
+
+/* Column sums: out[c] += sum_r x[r,c]  (bias gradients). */
+int mmdit_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* out, mmdit_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Patchify / unpatchify layout kernels (ImagePositionalEncoding.py:114-116,181-183 conv-as-GEMM gather;
+ * patchify.py:41-72).  Image is NCHW (batch, ch, H, W), H and W even; tokens are row-major over
+ * (H/2, W/2) and the patch vector order is (ch, ph, pw).
+ * ------------------------------------------------------------------------- */
+int mmdit_patchify(const void* img, int img_dtype, int batch, int ch, int H, int W, void* tokens, int tok_dtype, mmdit_stream_t stream);
+int mmdit_unpatchify(const void* tokens, int tok_dtype, int batch, int ch, int H, int W, void* img, int img_dtype, mmdit_stream_t stream);
+
+/* Sinusoidal timestep embedding, PositionalEncoding.py:15-30 with diff_model.py:306's time_scale:
+ * tau = t*time_scale; e_i = tau / 10000^(2i/dim), i=0..dim-1; out = [sin(e_0),sin(e_2),..,cos(e_1),cos(e_3),..].
+ * denom: the fp32 table 10000^(2i/dim), i=0..dim-1 (the reference precomputes it too, PositionalEncoding.py:15-16).
+ * bwd: dtime_scale += sum dout * d(out)/d(time_scale). */
+int mmdit_time_embed_fwd(const float* t, const float* time_scale, const float* denom, int batch, int dim, void* out, int out_dtype, mmdit_stream_t stream);
+int mmdit_time_embed_bwd(const void* dout, int dout_dtype, const float* t, const float* time_scale, const float* denom, int batch, int dim, float* dtime_scale, mmdit_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMDIT_HIP_H */

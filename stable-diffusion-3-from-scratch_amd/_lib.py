@@ -1,0 +1,94 @@
+"""ctypes binding of libmmdit_hip.so (C ABI: include/mmdit_hip.h).
+
+There is no fallback: if the library is missing or a call fails, a RuntimeError is
+raised.  The product path never routes through PyTorch math or the CPU oracle.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmdit_hip.so")
+HEADER_PATH = os.path.join(_HERE, "..", "include", "mmdit_hip.h")
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_SILU = 0, 1
+PREC_BF16, PREC_SPLIT = 0, 1
+
+_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [
+        ("A", _vp), ("a_dtype", _i), ("a_kmajor", _i), ("lda", _i64),
+        ("B", _vp), ("b_dtype", _i), ("b_kmajor", _i), ("ldb", _i64),
+        ("C", _vp), ("c_dtype", _i), ("ldc", _i64),
+        ("M", _i), ("N", _i), ("K", _i),
+        ("bias", _vp),
+        ("act", _i),
+        ("gate", _vp), ("ld_gate", _i64), ("rows_per_batch", _i),
+        ("residual", _vp), ("ld_res", _i64),
+        ("aux", _vp), ("aux_dtype", _i), ("ld_aux", _i64),
+        ("accumulate", _i),
+        ("precision", _i),
+    ]
+
+
+# argument types of every entry point, in header order
+_SIGNATURES = {
+    "mmdit_abi_version": ([], _i),
+    "mmdit_build_arch": ([], ctypes.c_char_p),
+    "mmdit_gemm": ([ctypes.POINTER(GemmArgs), _vp], _i),
+    "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
+    "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
+    "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),
+    "mmdit_text_rmsnorm_fwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
+    "mmdit_text_rmsnorm_bwd": ([_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "mmdit_qk_norm_rope_fwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "mmdit_qk_norm_rope_bwd": ([_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
+    "mmdit_attn_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp], _i),
+    "mmdit_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
+    "mmdit_swiglu_fwd": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "mmdit_swiglu_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "mmdit_gelu_fwd": ([_vp, _vp, _i, _i, _i, _vp], _i),
+    "mmdit_gelu_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "mmdit_silu_bwd": ([_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "mmdit_gate_residual_bwd": ([_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _vp], _i),
+    "mmdit_colsum": ([_vp, _i, _i, _i, _i64, _vp, _vp], _i),
+    "mmdit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
+    "mmdit_unpatchify": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
+    "mmdit_time_embed_fwd": ([_vp, _vp, _vp, _i, _i, _vp, _i, _vp], _i),
+    "mmdit_time_embed_bwd": ([_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp], _i),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    """Entry points declared by include/mmdit_hip.h (parsed from the header text)."""
+    with open(HEADER_PATH) as f:
+        txt = f.read()
+    return sorted(set(re.findall(r"\b(mmdit_[a-z0-9_]+)\s*\(", txt)) - {"mmdit_stream_t"})
+
+
+def lib():
+    """Load the HIP library (once).  Raises RuntimeError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
+                "(hipcc --offload-arch=gfx950).  There is no PyTorch/CPU fallback for the MMDiT hot path.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError -> symbol missing: fail loudly
+            fn.argtypes = argtypes
+            fn.restype = restype
+        _lib = L
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        kind = {-1: "invalid argument", -2: "dtype combination not built", -3: "unsupported shape"}.get(status, f"hipError {status}")
+        raise RuntimeError(f"{what} failed: {kind}")

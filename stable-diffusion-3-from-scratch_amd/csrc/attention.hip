@@ -1,0 +1,460 @@
+// Joint [image;text] softmax attention for gfx950, head_dim 64, bf16 MFMA operands, fp32 accumulate.
+//
+// All matmuls are issued "transposed" so that the softmax row statistic of a query lives in ONE lane:
+//   S^T = K Q^T  (v_mfma_f32_32x32x16_bf16: lane owns query l&31, 16 keys per accumulator)
+//   O^T = V^T P^T: the accumulator registers of S^T are already the B operand of this MFMA (the
+//   key order inside a 16-key slab is a fixed permutation which the V^T operand reproduces by
+//   addressing), V^T fragments come from a row-major [key][d] LDS tile via ds_read_b64_tr_b16.
+// Forward: one wave = 32 queries, KV tiles of 64 keys double-buffered through LDS.
+// Backward: two kernels (dQ: query-stationary; dK/dV: key-stationary) so nothing is atomically reduced.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int KT = 64;          // keys (or queries) per LDS tile
+constexpr int P144 = 144;       // row pitch for ds_read_b128 fragments (conflict-free)
+constexpr int P192 = 192;       // row pitch for ds_read_b64_tr_b16 fragments (conflict-free)
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// B-operand fragment from 8 consecutive accumulator registers (fp32 -> bf16), regs [h8*8, h8*8+8)
+__device__ __forceinline__ bf16x8 pack_frag(const f32x16& p, int h8) {
+  u32x4 w;
+#pragma unroll
+  for (int i = 0; i < 4; i++) w[i] = pack_bf2(p[h8 * 8 + 2 * i], p[h8 * 8 + 2 * i + 1]);
+  return __builtin_bit_cast(bf16x8, w);
+}
+
+// A-operand fragment of X^T where X is a row-major [row][64] LDS tile (pitch bytes): lane owns column
+// cb*32 + (lane&31); its 8 k-slots are rows  rb + 16*h8 + 4*(lane>>5) + {0..3}  and  + 8 + {0..3}
+// (the row order produced by pack_frag on an accumulator whose rows are these tile rows).
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int pitch, int rb, int h8, int cb, int lane) {
+  const int row = rb + 16 * h8 + 4 * (lane >> 5) + ((lane & 15) >> 2);
+  const int col = cb * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4;
+  const char* p = tile + row * pitch + col * 2;
+  s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 8 * pitch);
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// A-operand fragment of a row-major [row][64] LDS tile: lane owns row rb + (lane&31), k = ks*16 + (lane>>5)*8 ..+7
+__device__ __forceinline__ bf16x8 row_frag(const char* tile, int pitch, int rb, int ks, int lane) {
+  return *LDS_PTR(const bf16x8, tile + (rb + (lane & 31)) * pitch + (ks * 16 + (lane >> 5) * 8) * 2);
+}
+
+// copy a [64 rows][64] bf16 tile global -> LDS, rows >= nvalid zero-filled.  NT threads.
+template <int NT>
+__device__ __forceinline__ void tile_g2r(u32x4 (&st)[512 / NT], const bf16_t* g, int row0, int nrows_total, int tid) {
+#pragma unroll
+  for (int i = 0; i < 512 / NT; i++) {
+    const int c = tid + i * NT, row = c >> 3, kc = c & 7;
+    st[i] = (row0 + row < nrows_total) ? *(const u32x4*)(g + (int64_t)(row0 + row) * HD + kc * 8) : (u32x4){0, 0, 0, 0};
+  }
+}
+template <int NT>
+__device__ __forceinline__ void tile_r2s(const u32x4 (&st)[512 / NT], char* tile, int pitch, int tid) {
+#pragma unroll
+  for (int i = 0; i < 512 / NT; i++) {
+    const int c = tid + i * NT, row = c >> 3, kc = c & 7;
+    *LDS_PTR(u32x4, tile + row * pitch + kc * 16) = st[i];
+  }
+}
+
+// pointer to the 64-wide head slice of token s (joint index) in the stream-split (B, L, H*64) tensors
+__device__ __forceinline__ const bf16_t* tok_ptr(const bf16_t* x_img, const bf16_t* x_txt, int64_t b, int s, int n_img, int n_txt, int D, int h) {
+  if (s < n_img) return x_img + ((b * n_img + s) * (int64_t)D + h * HD);
+  return x_txt ? x_txt + ((b * n_txt + (s - n_img)) * (int64_t)D + h * HD) : nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int NW, bool ORACLE>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                            int H, int S, int n_img, float scale,
+                                                            bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse) {
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * P144 + 2 * KT * P192];
+  auto kt = [&](int i) { return smem + i * KT * P144; };
+  auto vt = [&](int i) { return smem + 2 * KT * P144 + i * KT * P192; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, h = bh % H;
+  const int64_t b = bh / H;
+  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
+  const bf16_t* Kb = K + (int64_t)bh * S * HD;
+  const bf16_t* Vb = V + (int64_t)bh * S * HD;
+  const int q = blockIdx.x * 32 * NW + wave * 32 + (lane & 31);
+  const int qc = min(q, S - 1);
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[db][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const int nkv = (S + KT - 1) / KT;
+  u32x4 sk[512 / NT], sv[512 / NT];
+
+  // scores of tile j from LDS buffer kb_ -> s[2] (masked keys = -inf).  fast: log2 domain; oracle: natural, bf16-rounded
+  auto scores = [&](int j, const char* ktile, f32x16 (&s)[2]) {
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, P144, kb * 32, ks, lane), qf[ks], s[kb], 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = j * KT + kb * 32 + acc_row(r, lane);
+        float v;
+        if (ORACLE) v = bf2f(f2bf(bf2f(f2bf(s[kb][r])) * scale));   // Attention.py:277: bf16 matmul, then bf16 * scale
+        else v = s[kb][r] * (scale * LOG2E);
+        s[kb][r] = key < S ? v : -INFINITY;
+      }
+    }
+  };
+  auto tile_max = [&](const f32x16 (&s)[2]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    return fmaxf(mx, __shfl_xor(mx, 32, 64));
+  };
+  auto pv = [&](const f32x16 (&p)[2], const char* vtile) {
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int h8 = 0; h8 < 2; h8++) {
+        const bf16x8 pf = pack_frag(p[kb], h8);
+#pragma unroll
+        for (int db = 0; db < 2; db++) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(vtile, P192, kb * 32, h8, db, lane), pf, o[db], 0, 0, 0);
+      }
+  };
+
+  for (int pass = 0; pass < (ORACLE ? 2 : 1); pass++) {
+    tile_g2r<NT>(sk, Kb, 0, S, tid);
+    tile_g2r<NT>(sv, Vb, 0, S, tid);
+    __syncthreads();  // previous pass done with the buffers
+    tile_r2s<NT>(sk, kt(0), P144, tid);
+    tile_r2s<NT>(sv, vt(0), P192, tid);
+    __syncthreads();
+    for (int j = 0; j < nkv; j++) {
+      const int cur = j & 1;
+      if (j + 1 < nkv) {
+        tile_g2r<NT>(sk, Kb, (j + 1) * KT, S, tid);
+        tile_g2r<NT>(sv, Vb, (j + 1) * KT, S, tid);
+      }
+      f32x16 s[2];
+      scores(j, kt(cur), s);
+      if (!ORACLE) {
+        const float mn = fmaxf(m, tile_max(s));
+        const float alpha = exp2f(m - mn);
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) { const float p = exp2f(s[kb][r] - mn); s[kb][r] = p; rs += p; }
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * alpha + rs; m = mn;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[db][r] *= alpha;
+        pv(s, vt(cur));
+      } else if (pass == 0) {
+        const float mn = fmaxf(m, tile_max(s));
+        float rs = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) rs += __expf(s[kb][r] - mn);
+        rs += __shfl_xor(rs, 32, 64);
+        l = l * __expf(m - mn) + rs; m = mn;
+      } else {
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) s[kb][r] = __expf(s[kb][r] - m) / l;   // softmax output, rounded to bf16 by pack_frag
+        pv(s, vt(cur));
+      }
+      if (j + 1 < nkv) {
+        tile_r2s<NT>(sk, kt(cur ^ 1), P144, tid);
+        tile_r2s<NT>(sv, vt(cur ^ 1), P192, tid);
+        __syncthreads();
+      }
+    }
+  }
+
+  if (q < S) {
+    const float inv = ORACLE ? 1.f : 1.f / l;
+    const int n_txt = S - n_img, D = H * HD;
+    bf16_t* dst = q < n_img ? Ox + ((b * n_img + q) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (q - n_img)) * (int64_t)D + h * HD);
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float v4[4] = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
+        st4(dst + db * 32 + 8 * g + 4 * (lane >> 5), v4);
+      }
+    if (lane < 32) lse[(int64_t)bh * S + q] = ORACLE ? m + __logf(l) : m * LN2 + __logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward prep: delta[b,h,s] = sum_d dO * O
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ Ox, const bf16_t* __restrict__ Oc, const bf16_t* __restrict__ dOx,
+                                                            const bf16_t* __restrict__ dOc, int64_t total, int H, int S, int n_img, float* __restrict__ delta) {
+  const int n_txt = S - n_img, D = H * HD;
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int chunk = (int)(gid & 7);
+    int64_t r = gid >> 3;
+    const int h = (int)(r % H); r /= H;
+    const int s = (int)(r % S);
+    const int64_t b = r / S;
+    const bf16_t* po = tok_ptr(Ox, Oc, b, s, n_img, n_txt, D, h);
+    const bf16_t* pd = tok_ptr(dOx, dOc, b, s, n_img, n_txt, D, h);
+    float acc = 0.f;
+    if (pd) {
+      float a[8], g[8];
+      ld8(po + chunk * 8, a); ld8(pd + chunk * 8, g);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc += a[e] * g[e];
+    }
+    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
+    if (chunk == 0) delta[(b * H + h) * (int64_t)S + s] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
+// ------------------------------------------------------------------------------------------------
+template <int NW, typename TG>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
+                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               int H, int S, int n_img, float scale, TG* __restrict__ dQ) {
+  constexpr int NT = NW * 64;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * P144];
+  char* ktile = smem;
+  char* vtile = smem + KT * P144;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, h = bh % H;
+  const int64_t b = bh / H;
+  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
+  const bf16_t* Kb = K + (int64_t)bh * S * HD;
+  const bf16_t* Vb = V + (int64_t)bh * S * HD;
+  const int q = blockIdx.x * 32 * NW + wave * 32 + (lane & 31);
+  const int qc = min(q, S - 1);
+  const bf16_t* dop = tok_ptr(dOx, dOc, b, qc, n_img, S - n_img, H * HD, h);
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
+    u32x4 z = {0, 0, 0, 0};
+    dof[ks] = dop ? *(const bf16x8*)(dop + ks * 16 + (lane >> 5) * 8) : __builtin_bit_cast(bf16x8, z);
+  }
+  const float lq = lse[(int64_t)bh * S + qc] * LOG2E, dq_delta = delta[(int64_t)bh * S + qc];
+  f32x16 acc[2];
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[db][r] = 0.f;
+
+  const int nkv = (S + KT - 1) / KT;
+  u32x4 sk[512 / NT], sv[512 / NT];
+  for (int j = 0; j < nkv; j++) {
+    tile_g2r<NT>(sk, Kb, j * KT, S, tid);
+    tile_g2r<NT>(sv, Vb, j * KT, S, tid);
+    __syncthreads();
+    tile_r2s<NT>(sk, ktile, P144, tid);
+    tile_r2s<NT>(sv, vtile, P144, tid);
+    __syncthreads();
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, P144, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vtile, P144, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int key = j * KT + kb * 32 + acc_row(r, lane);
+        const float p = key < S ? exp2f(s[r] * (scale * LOG2E) - lq) : 0.f;
+        s[r] = p * (dp[r] - dq_delta);
+      }
+#pragma unroll
+      for (int h8 = 0; h8 < 2; h8++) {
+        const bf16x8 dsf = pack_frag(s, h8);
+#pragma unroll
+        for (int db = 0; db < 2; db++) acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ktile, P144, kb * 32, h8, db, lane), dsf, acc[db], 0, 0, 0);
+      }
+    }
+  }
+  if (q < S) {
+    TG* dst = dQ + ((int64_t)bh * S + q) * HD;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float v4[4] = {acc[db][g * 4] * scale, acc[db][g * 4 + 1] * scale, acc[db][g * 4 + 2] * scale, acc[db][g * 4 + 3] * scale};
+        st4(dst + db * 32 + 8 * g + 4 * (lane >> 5), v4);
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward dK/dV: key-stationary (each wave owns 32 keys), loops over query tiles of 64.
+//   S[q][key] = Q K^T, dP[q][key] = dO V^T  (lane owns key l&31, rows = queries)
+//   dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[hd][key] += Q^T[hd][q] dS[q][key]
+// ------------------------------------------------------------------------------------------------
+template <typename TG>
+__global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                           const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV) {
+  constexpr int NT = 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * P144 + 2 * KT * 4];
+  char* qtile = smem;
+  char* dotile = smem + KT * P144;
+  float* lse_s = (float*)(smem + 2 * KT * P144);
+  float* del_s = lse_s + KT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y, h = bh % H;
+  const int64_t b = bh / H;
+  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
+  const bf16_t* Kb = K + (int64_t)bh * S * HD;
+  const bf16_t* Vb = V + (int64_t)bh * S * HD;
+  const int key = blockIdx.x * KT + wave * 32 + (lane & 31);
+  const int keyc = min(key, S - 1);
+  const int n_txt = S - n_img, D = H * HD;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    kf[ks] = *(const bf16x8*)(Kb + (int64_t)keyc * HD + ks * 16 + (lane >> 5) * 8);
+    vf[ks] = *(const bf16x8*)(Vb + (int64_t)keyc * HD + ks * 16 + (lane >> 5) * 8);
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+
+  const int nq = (S + KT - 1) / KT;
+  for (int jq = 0; jq < nq; jq++) {
+    u32x4 sq[4], sd[4];
+    tile_g2r<NT>(sq, Qb, jq * KT, S, tid);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = tid + i * NT, row = c >> 3, kc = c & 7, s = jq * KT + row;
+      const bf16_t* p = s < S ? tok_ptr(dOx, dOc, b, s, n_img, n_txt, D, h) : nullptr;
+      sd[i] = p ? *(const u32x4*)(p + kc * 8) : (u32x4){0, 0, 0, 0};
+    }
+    float lv = 0.f, dl = 0.f;
+    if (tid < KT && jq * KT + tid < S) { lv = lse[(int64_t)bh * S + jq * KT + tid] * LOG2E; dl = delta[(int64_t)bh * S + jq * KT + tid]; }
+    __syncthreads();
+    tile_r2s<NT>(sq, qtile, P144, tid);
+    tile_r2s<NT>(sd, dotile, P144, tid);
+    if (tid < KT) { lse_s[tid] = lv; del_s[tid] = dl; }
+    __syncthreads();
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, P144, qb * 32, ks, lane), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, P144, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+      }
+      f32x16 ds;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int r0 = qb * 32 + 8 * g + 4 * (lane >> 5);
+        const f32x4 l4 = *LDS_PTR(const f32x4, lse_s + r0);
+        const f32x4 d4 = *LDS_PTR(const f32x4, del_s + r0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int r = g * 4 + e;
+          const bool ok = (key < S) && (jq * KT + r0 + e < S);
+          const float p = ok ? exp2f(s[r] * (scale * LOG2E) - l4[e]) : 0.f;
+          s[r] = p;
+          ds[r] = p * (dp[r] - d4[e]);
+        }
+      }
+#pragma unroll
+      for (int h8 = 0; h8 < 2; h8++) {
+        const bf16x8 pf = pack_frag(s, h8), dsf = pack_frag(ds, h8);
+#pragma unroll
+        for (int db = 0; db < 2; db++) {
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dotile, P144, qb * 32, h8, db, lane), pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, P144, qb * 32, h8, db, lane), dsf, dk[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (key < S) {
+    TG* pk = dK + ((int64_t)bh * S + key) * HD;
+    TG* pv = dV + ((int64_t)bh * S + key) * HD;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float k4[4] = {dk[db][g * 4] * scale, dk[db][g * 4 + 1] * scale, dk[db][g * 4 + 2] * scale, dk[db][g * 4 + 3] * scale};
+        float v4[4] = {dv[db][g * 4], dv[db][g * 4 + 1], dv[db][g * 4 + 2], dv[db][g * 4 + 3]};
+        st4(pk + db * 32 + 8 * g + 4 * (lane >> 5), k4);
+        st4(pv + db * 32 + 8 * g + 4 * (lane >> 5), v4);
+      }
+  }
+}
+
+}  // namespace
+
+extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale, int mode,
+                              void* Ox, void* Oc, float* lse, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(Q && K && V && Ox && lse && batch > 0 && heads > 0 && S > 0 && n_img > 0 && n_img <= S);
+  MMDIT_CHECK_ARG(Oc || n_img == S);
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int NW = 2;
+  dim3 grid((S + 32 * NW - 1) / (32 * NW), batch * heads);
+  if (mode == 0) hipLaunchKernelGGL((attn_fwd_kernel<NW, false>), grid, dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
+  else if (mode == 1) hipLaunchKernelGGL((attn_fwd_kernel<NW, true>), grid, dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
+  else return MMDIT_ERR_ARG;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc, const void* dOx, const void* dOc,
+                              const float* lse, float* delta, int batch, int heads, int S, int n_img, float scale,
+                              void* dQ, void* dK, void* dV, int dq_dtype, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(Q && K && V && Ox && dOx && lse && delta && dQ && dK && dV && batch > 0 && heads > 0 && S > 0 && n_img > 0 && n_img <= S);
+  MMDIT_CHECK_ARG(Oc || n_img == S);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)batch * S * heads * 8;
+  int64_t g = (total + 255) / 256;
+  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, (const bf16_t*)Ox, (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc,
+                     total, heads, S, n_img, delta);
+  constexpr int NW = 2;
+  dim3 gq((S + 32 * NW - 1) / (32 * NW), batch * heads), gk((S + KT - 1) / KT, batch * heads);
+  if (dq_dtype == MMDIT_BF16) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, bf16_t>), gq, dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, heads, S, n_img, scale, (bf16_t*)dQ);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<bf16_t>), gk, dim3(128), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, heads, S, n_img, scale, (bf16_t*)dK, (bf16_t*)dV);
+  } else if (dq_dtype == MMDIT_F32) {
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, float>), gq, dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, heads, S, n_img, scale, (float*)dQ);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<float>), gk, dim3(128), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, heads, S, n_img, scale, (float*)dK, (float*)dV);
+  } else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}

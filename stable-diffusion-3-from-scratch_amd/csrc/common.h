@@ -1,0 +1,87 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes, MFMA 32x32x16 bf16).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mmdit_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef uint16_t bf16_t;  // raw storage type for bf16 in global memory
+
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+// round-to-nearest-even fp32 -> bf16 (NaN preserved as quiet NaN)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// generic scalar load/store by dtype tag
+template <typename T> struct io;
+template <> struct io<float> {
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct io<bf16_t> {
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+};
+
+// load / store 8 consecutive elements as fp32 (16 B bf16 vector or 2 x 16 B fp32 vectors)
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+  float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+  uint4 a = *(const uint4*)p;
+  uint32_t w[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+  *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+  *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+  *(uint4*)p = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
+}
+__device__ __forceinline__ void ld4(const float* p, float (&v)[4]) { float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
+__device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
+  uint2 a = *(const uint2*)p;
+  v[0] = __builtin_bit_cast(float, a.x << 16); v[1] = __builtin_bit_cast(float, a.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, a.y << 16); v[3] = __builtin_bit_cast(float, a.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) { *(uint2*)p = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// transpose read: lane gets 4 bf16 = column (lane&15) of the 4x16 block whose rows are addressed by the 16-lane group
+__device__ __forceinline__ s16x4 lds_tr16(const void* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p)); }
+
+static inline int mmdit_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? 0 : (int)e;
+}
+#define MMDIT_CHECK_ARG(c) do { if (!(c)) return MMDIT_ERR_ARG; } while (0)

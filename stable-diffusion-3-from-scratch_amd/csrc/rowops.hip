@@ -1,0 +1,766 @@
+// HBM-bound row / elementwise kernels of the MMDiT path for gfx950.
+// All loads/stores are 8-16 B per lane; reductions over a row live in one 64-lane wave;
+// per-batch / per-column gradient sums are accumulated in registers over a row chunk and
+// flushed with fp32 atomics (caller zero-initialises the destination).
+#include "common.h"
+#include <float.h>
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;           // nn.LayerNorm default (Norm.py:10)
+constexpr float RMS_EPS = FLT_EPSILON;    // nn.RMSNorm(eps=None) on fp32 input
+
+// -------------------------------------------------------------------------------------------
+// adaLN forward: one wave per row, the row is kept in registers (NIT float4 per lane).
+// -------------------------------------------------------------------------------------------
+template <int NIT, typename TO>
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int64_t ld_mod, int rows, int d, int rpb, TO* __restrict__ out,
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nch = d >> 2;
+  const float* xr = x + (int64_t)row * d;
+  float v[NIT][4];
+  float s = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) { ld4(xr + ch * 4, v[it]); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
+    else { v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f; }
+  }
+  const float mean = wave_sum(s) / d;
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { float c = v[it][e] - mean; q += c * c; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / d + LN_EPS);
+  if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
+  const int b = row / rpb;
+  const float* sc = scale + (int64_t)b * ld_mod;
+  const float* sh = shift + (int64_t)b * ld_mod;
+  TO* orow = out + (int64_t)row * d;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) {
+      float a[4], h[4], o[4];
+      ld4(sc + ch * 4, a); ld4(sh + ch * 4, h);
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = (v[it][e] - mean) * rstd * (1.f + a[e]) + h[e];
+      st4(orow + ch * 4, o);
+    }
+  }
+}
+
+// adaLN backward: block = (batch b, chunk of RCH rows); wave w takes rows w, w+4, ...
+constexpr int LN_BWD_RCH = 64;
+template <int NIT, typename TG>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
+                                                         const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
+                                                         const float* __restrict__ dres, int d, int rpb, int nchunk,
+                                                         float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  const int nch = d >> 2;
+  const float* sc = scale + (int64_t)b * ld_mod;
+  float a1[NIT][4], ds[NIT][4], dh[NIT][4];
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) { ld4(sc + ch * 4, a1[it]); } else { a1[it][0] = a1[it][1] = a1[it][2] = a1[it][3] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 4; e++) { a1[it][e] += 1.f; ds[it][e] = 0.f; dh[it][e] = 0.f; }
+  }
+  const int rend = min(rpb, (chunk + 1) * LN_BWD_RCH);
+  for (int rl = chunk * LN_BWD_RCH + wave; rl < rend; rl += 4) {
+    const int64_t row = (int64_t)b * rpb + rl;
+    const float mean = mean_i[row], rstd = rstd_i[row];
+    float g[NIT][4], xh[NIT][4];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      int ch = lane + 64 * it;
+      if (ch < nch) {
+        float dy[4], xv[4];
+        ld4(dout + row * d + ch * 4, dy);
+        ld4(x + row * d + ch * 4, xv);
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          xh[it][e] = (xv[e] - mean) * rstd;
+          g[it][e] = dy[e] * a1[it][e];
+          c1 += g[it][e]; c2 += g[it][e] * xh[it][e];
+          ds[it][e] += dy[e] * xh[it][e]; dh[it][e] += dy[e];
+        }
+      }
+    }
+    c1 = wave_sum(c1) / d; c2 = wave_sum(c2) / d;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      int ch = lane + 64 * it;
+      if (ch < nch) {
+        float o[4];
+        if (dres) ld4(dres + row * d + ch * 4, o); else { o[0] = o[1] = o[2] = o[3] = 0.f; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] += rstd * (g[it][e] - c1 - xh[it][e] * c2);
+        st4(dx + row * d + ch * 4, o);
+      }
+    }
+  }
+  float* dsb = dscale + (int64_t)b * ld_dmod;
+  float* dhb = dshift + (int64_t)b * ld_dmod;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { atomicAdd(dsb + ch * 4 + e, ds[it][e]); atomicAdd(dhb + ch * 4 + e, dh[it][e]); }
+    }
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// text RMSNorm (one half of the 154 tokens per launch): src row = (m/cnt)*tokens + off + m%cnt
+// -------------------------------------------------------------------------------------------
+template <int NIT, typename TI, typename TO>
+__global__ __launch_bounds__(256) void text_rms_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sp,
+                                                           int rows, int cnt, int tokens, int off, int d, TO* __restrict__ out) {
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= rows) return;
+  const int nch = d >> 2;
+  const TI* xr = x + ((int64_t)(m / cnt) * tokens + off + m % cnt) * d;
+  float v[NIT][4];
+  float q = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) { ld4(xr + ch * 4, v[it]); q += v[it][0] * v[it][0] + v[it][1] * v[it][1] + v[it][2] * v[it][2] + v[it][3] * v[it][3]; }
+  }
+  const float rinv = rsqrtf(wave_sum(q) / d + RMS_EPS);
+  const float s = sp[0];
+  TO* orow = out + (int64_t)m * d;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) {
+      float wv[4], o[4];
+      ld4(w + ch * 4, wv);
+#pragma unroll
+      for (int e = 0; e < 4; e++) o[e] = s * (v[it][e] * rinv * wv[e]);
+      st4(orow + ch * 4, o);
+    }
+  }
+}
+
+template <int NIT, typename TI, typename TG>
+__global__ __launch_bounds__(256) void text_rms_bwd_kernel(const TG* __restrict__ dout, const TI* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ sp, int rows, int cnt, int tokens, int off, int d,
+                                                           float* __restrict__ dw, float* __restrict__ dsp) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = d >> 2;
+  const float s = sp[0];
+  float accw[NIT][4], wv[NIT][4];
+  float accs = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) ld4(w + ch * 4, wv[it]); else { wv[it][0] = wv[it][1] = wv[it][2] = wv[it][3] = 0.f; }
+#pragma unroll
+    for (int e = 0; e < 4; e++) accw[it][e] = 0.f;
+  }
+  for (int m = blockIdx.x * 64 + wave; m < min(rows, (int)(blockIdx.x + 1) * 64); m += 4) {
+    const TI* xr = x + ((int64_t)(m / cnt) * tokens + off + m % cnt) * d;
+    float v[NIT][4];
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      int ch = lane + 64 * it;
+      if (ch < nch) { ld4(xr + ch * 4, v[it]); q += v[it][0] * v[it][0] + v[it][1] * v[it][1] + v[it][2] * v[it][2] + v[it][3] * v[it][3]; }
+    }
+    const float rinv = rsqrtf(wave_sum(q) / d + RMS_EPS);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      int ch = lane + 64 * it;
+      if (ch < nch) {
+        float dy[4];
+        ld4(dout + (int64_t)m * d + ch * 4, dy);
+#pragma unroll
+        for (int e = 0; e < 4; e++) { float xn = v[it][e] * rinv; accw[it][e] += dy[e] * s * xn; accs += dy[e] * xn * wv[it][e]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; it++) {
+    int ch = lane + 64 * it;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) atomicAdd(dw + ch * 4 + e, accw[it][e]);
+    }
+  }
+  accs = wave_sum(accs);
+  if (lane == 0) atomicAdd(dsp, accs);
+}
+
+// -------------------------------------------------------------------------------------------
+// per-head QK RMSNorm + RoPE2d + head split.  8 lanes own one 64-wide head vector (8 elements each).
+// flat index over [row][part q/k/v][head][chunk] == memory order of a qkv row.
+// -------------------------------------------------------------------------------------------
+__device__ __forceinline__ float group8_sum(float v) {
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                               const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                               int64_t total, int tokens, int heads, int s_total, int tok0,
+                                                               bf16_t* __restrict__ Q, bf16_t* __restrict__ K, bf16_t* __restrict__ V) {
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    const int chunk = (int)(gid & 7);
+    int64_t hv = gid >> 3;
+    const int head = (int)(hv % heads); hv /= heads;
+    const int part = (int)(hv % 3);
+    const int64_t row = hv / 3;
+    const int n = (int)(row % tokens);
+    const int64_t b = row / tokens;
+    float x[8];
+    ld8(qkv + gid * 8, x);
+    if (part < 2) {
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) ss += x[e] * x[e];
+      const float rinv = rsqrtf(group8_sum(ss) * (1.f / 64.f) + RMS_EPS);
+      float w[8];
+      ld8((part == 0 ? wq : wk) + chunk * 8, w);
+#pragma unroll
+      for (int e = 0; e < 8; e++) x[e] = x[e] * rinv * w[e];
+      if (rcos) {
+        float c[8], s[8];
+        ld8(rcos + (int64_t)n * 64 + chunk * 8, c);
+        ld8(rsin + (int64_t)n * 64 + chunk * 8, s);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          float a = x[2 * p], bb = x[2 * p + 1];
+          x[2 * p] = a * c[2 * p] - bb * s[2 * p];
+          x[2 * p + 1] = bb * c[2 * p + 1] + a * s[2 * p + 1];
+        }
+      }
+    }
+    bf16_t* dst = (part == 0 ? Q : part == 1 ? K : V) + ((b * heads + head) * (int64_t)s_total + tok0 + n) * 64 + chunk * 8;
+    st8(dst, x);
+  }
+}
+
+template <typename TG, typename TI, typename TO>
+__global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
+                                                               const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                               const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                               int64_t total, int tokens, int heads, int s_total, int tok0,
+                                                               TO* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk) {
+  __shared__ float sdw[2][64];
+  if (threadIdx.x < 128) sdw[threadIdx.x >> 6][threadIdx.x & 63] = 0.f;
+  __syncthreads();
+  float aq[8], ak[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { aq[e] = 0.f; ak[e] = 0.f; }
+  const int chunk = threadIdx.x & 7;  // constant per thread: 256 and gridDim*256 are multiples of 8
+  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
+    int64_t hv = gid >> 3;
+    const int head = (int)(hv % heads); hv /= heads;
+    const int part = (int)(hv % 3);
+    const int64_t row = hv / 3;
+    const int n = (int)(row % tokens);
+    const int64_t b = row / tokens;
+    const TG* src = (part == 0 ? dQ : part == 1 ? dK : dV) + ((b * heads + head) * (int64_t)s_total + tok0 + n) * 64 + chunk * 8;
+    float dz[8];
+    ld8(src, dz);
+    if (part < 2) {
+      float x[8], w[8];
+      ld8(qkv + gid * 8, x);
+      ld8((part == 0 ? wq : wk) + chunk * 8, w);
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) ss += x[e] * x[e];
+      const float rinv = rsqrtf(group8_sum(ss) * (1.f / 64.f) + RMS_EPS);
+      if (rcos) {
+        float c[8], s[8];
+        ld8(rcos + (int64_t)n * 64 + chunk * 8, c);
+        ld8(rsin + (int64_t)n * 64 + chunk * 8, s);
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          float da = dz[2 * p], db = dz[2 * p + 1];
+          dz[2 * p] = da * c[2 * p] + db * s[2 * p + 1];
+          dz[2 * p + 1] = db * c[2 * p + 1] - da * s[2 * p];
+        }
+      }
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        float xh = x[e] * rinv;
+        float dwv = dz[e] * xh;
+        if (part == 0) aq[e] += dwv; else ak[e] += dwv;
+        dz[e] *= w[e];                 // d(xhat)
+        dot += dz[e] * xh;
+        x[e] = xh;
+      }
+      dot = group8_sum(dot) * (1.f / 64.f);
+#pragma unroll
+      for (int e = 0; e < 8; e++) dz[e] = rinv * (dz[e] - x[e] * dot);
+    }
+    st8(dqkv + gid * 8, dz);
+  }
+  // lanes with equal (lane & 7) hold the same weight columns: reduce over the wave, then LDS, then global
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { aq[e] += __shfl_xor(aq[e], o, 64); ak[e] += __shfl_xor(ak[e], o, 64); }
+  }
+  if ((threadIdx.x & 63) < 8) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) { atomicAdd(&sdw[0][chunk * 8 + e], aq[e]); atomicAdd(&sdw[1][chunk * 8 + e], ak[e]); }
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) atomicAdd(dwq + threadIdx.x, sdw[0][threadIdx.x]);
+  else if (threadIdx.x < 128) atomicAdd(dwk + threadIdx.x - 64, sdw[1][threadIdx.x - 64]);
+}
+
+// -------------------------------------------------------------------------------------------
+// column-owner elementwise kernels: block = 2 row-lanes x 128 column threads (8 columns each);
+// grid = (column slabs of 1024, row chunks of CO_RCH rows).
+// -------------------------------------------------------------------------------------------
+constexpr int CO_RCH = 64;
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+template <typename T, bool GELU>
+__global__ __launch_bounds__(256) void mlp_act_fwd_kernel(const T* __restrict__ gu, T* __restrict__ h, int rows, int hidden) {
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+  const int c = blockIdx.x * 1024 + tx * 8;
+  if (c >= hidden) return;
+  const int64_t ldi = GELU ? hidden : 2 * (int64_t)hidden;
+  const int rend = min(rows, (int)(blockIdx.y + 1) * CO_RCH);
+  for (int r = blockIdx.y * CO_RCH + ty; r < rend; r += 2) {
+    float g[8], o[8];
+    ld8(gu + r * ldi + c, g);
+    if constexpr (GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = gelu_f(g[e]);
+    } else {
+      float u[8];
+      ld8(gu + r * ldi + hidden + c, u);
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = silu_f(g[e]) * u[e];
+    }
+    st8(h + (int64_t)r * hidden + c, o);
+  }
+}
+
+__device__ __forceinline__ void colsum_flush(float (&acc)[8], float* sbuf /*[256*8]*/, float* dst, int c, int ncols) {
+  // combine the two row-lanes (ty = 0/1) through LDS, then one atomic per column
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+  if (ty == 1) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) sbuf[tx * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  if (ty == 0 && c < ncols) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) atomicAdd(dst + c + e, acc[e] + sbuf[tx * 8 + e]);
+  }
+  __syncthreads();
+}
+
+template <typename T, bool GELU>
+__global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ gu, T* __restrict__ dgu,
+                                                          int rows, int hidden, float* __restrict__ dbias) {
+  __shared__ float sbuf[1024];
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+  const int c = blockIdx.x * 1024 + tx * 8;
+  const bool act = c < hidden;
+  const int64_t ldi = GELU ? hidden : 2 * (int64_t)hidden;
+  float sg[8], su[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { sg[e] = 0.f; su[e] = 0.f; }
+  const int rend = min(rows, (int)(blockIdx.y + 1) * CO_RCH);
+  if (act) {
+    for (int r = blockIdx.y * CO_RCH + ty; r < rend; r += 2) {
+      float d[8], g[8], og[8];
+      ld8(dh + (int64_t)r * hidden + c, d);
+      ld8(gu + r * ldi + c, g);
+      if constexpr (GELU) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { og[e] = d[e] * gelu_grad_f(g[e]); sg[e] += og[e]; }
+        st8(dgu + r * ldi + c, og);
+      } else {
+        float u[8], ou[8];
+        ld8(gu + r * ldi + hidden + c, u);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float sig = sigmoid_f(g[e]);
+          og[e] = d[e] * u[e] * sig * (1.f + g[e] * (1.f - sig));
+          ou[e] = d[e] * g[e] * sig;
+          sg[e] += og[e]; su[e] += ou[e];
+        }
+        st8(dgu + r * ldi + c, og);
+        st8(dgu + r * ldi + hidden + c, ou);
+      }
+    }
+  }
+  if (dbias) {
+    colsum_flush(sg, sbuf, dbias, c, hidden);
+    if constexpr (!GELU) colsum_flush(su, sbuf, dbias + hidden, c, hidden);
+  }
+}
+
+// dacc = dy * gate[b]; dgate[b] += sum dy*acc; dbias += sum dacc.  grid = (slabs, batch * chunks)
+template <typename TA, typename TO>
+__global__ __launch_bounds__(256) void gate_res_bwd_kernel(const float* __restrict__ dy, const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate,
+                                                           int d, int rpb, int nchunk, TO* __restrict__ dacc,
+                                                           float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias) {
+  __shared__ float sbuf[1024];
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+  const int c = blockIdx.x * 1024 + tx * 8;
+  const bool act = c < d;
+  const int b = blockIdx.y / nchunk, chunk = blockIdx.y % nchunk;
+  float g[8], sgate[8], sb[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) { g[e] = 0.f; sgate[e] = 0.f; sb[e] = 0.f; }
+  if (act) {
+    ld8(gate + (int64_t)b * ld_gate + c, g);
+    const int rend = min(rpb, (chunk + 1) * CO_RCH);
+    for (int rl = chunk * CO_RCH + ty; rl < rend; rl += 2) {
+      const int64_t row = (int64_t)b * rpb + rl;
+      float dv[8], av[8], o[8];
+      ld8(dy + row * d + c, dv);
+      ld8(acc + row * d + c, av);
+#pragma unroll
+      for (int e = 0; e < 8; e++) { o[e] = dv[e] * g[e]; sgate[e] += dv[e] * av[e]; sb[e] += o[e]; }
+      st8(dacc + row * d + c, o);
+    }
+  }
+  colsum_flush(sgate, sbuf, dgate + (int64_t)b * ld_dgate, c, d);
+  if (dbias) colsum_flush(sb, sbuf, dbias, c, d);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int rows, int cols, int64_t ld, float* __restrict__ out) {
+  __shared__ float sbuf[1024];
+  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
+  const int c = blockIdx.x * 1024 + tx * 8;
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) s[e] = 0.f;
+  if (c < cols) {
+    const int rend = min(rows, (int)(blockIdx.y + 1) * CO_RCH);
+    for (int r = blockIdx.y * CO_RCH + ty; r < rend; r += 2) {
+      float v[8];
+      ld8(x + r * ld + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; e++) s[e] += v[e];
+    }
+  }
+  colsum_flush(s, sbuf, out, c, cols);
+}
+
+// y_proj SiLU backward on a small (rows=batch, cols=d) matrix: one thread per column
+template <typename TG, typename TO>
+__global__ void silu_bwd_kernel(const TG* __restrict__ dy, const float* __restrict__ pre, TO* __restrict__ dpre, int rows, int cols, float* __restrict__ dbias) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; r++) {
+    const int64_t i = (int64_t)r * cols + c;
+    const float p = pre[i], sig = sigmoid_f(p);
+    const float g = io<TG>::ld(dy + i) * sig * (1.f + p * (1.f - sig));
+    io<TO>::st(dpre + i, g);
+    s += g;
+  }
+  if (dbias) dbias[c] += s;
+}
+
+template <typename TI, typename TO>
+__global__ void cast_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int64_t n) {
+  const int64_t n8 = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    ld8(src + i * 8, v);
+    st8(dst + i * 8, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 7)) io<TO>::st(dst + n8 * 8 + threadIdx.x, io<TI>::ld(src + n8 * 8 + threadIdx.x));
+}
+
+// patchify: one thread per (b, ch, y, j) moves two horizontally adjacent pixels
+template <typename TI, typename TO, bool TO_TOKENS>
+__global__ void patch_kernel(const TI* __restrict__ src, TO* __restrict__ dst, int batch, int ch, int H, int W) {
+  const int W2 = W >> 1, H2 = H >> 1;
+  const int64_t total = (int64_t)batch * ch * H * W2;
+  for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(g % W2); int64_t r = g / W2;
+    const int y = (int)(r % H); r /= H;
+    const int c = (int)(r % ch); const int64_t b = r / ch;
+    const int64_t img_off = ((b * ch + c) * H + y) * W + 2 * j;
+    const int64_t tok_off = ((b * H2 + (y >> 1)) * W2 + j) * (int64_t)(ch * 4) + c * 4 + (y & 1) * 2;
+    if (TO_TOKENS) { io<TO>::st(dst + tok_off, io<TI>::ld(src + img_off)); io<TO>::st(dst + tok_off + 1, io<TI>::ld(src + img_off + 1)); }
+    else { io<TO>::st(dst + img_off, io<TI>::ld(src + tok_off)); io<TO>::st(dst + img_off + 1, io<TI>::ld(src + tok_off + 1)); }
+  }
+}
+
+template <typename TO>
+__global__ void time_embed_fwd_kernel(const float* __restrict__ t, const float* __restrict__ ts, const float* __restrict__ denom, int batch, int dim, TO* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (i >= dim) return;
+  const float tau = t[b] * ts[0];
+  const int half = dim >> 1;
+  const float v = i < half ? sinf(tau / denom[2 * i]) : cosf(tau / denom[2 * (i - half) + 1]);
+  io<TO>::st(out + (int64_t)b * dim + i, v);
+}
+
+template <typename TG>
+__global__ __launch_bounds__(256) void time_embed_bwd_kernel(const TG* __restrict__ dout, const float* __restrict__ t, const float* __restrict__ ts,
+                                                             const float* __restrict__ denom, int batch, int dim, float* __restrict__ dts) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  const float tau = t[b] * ts[0];
+  const int half = dim >> 1;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < dim; i += 256) {
+    const float g = io<TG>::ld(dout + (int64_t)b * dim + i);
+    if (i < half) { const float dn = denom[2 * i]; s += g * cosf(tau / dn) / dn; }
+    else { const float dn = denom[2 * (i - half) + 1]; s -= g * sinf(tau / dn) / dn; }
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dts, (red[0] + red[1] + red[2] + red[3]) * t[b]);
+}
+
+inline int nit_for(int d) { return (d / 4 + 63) / 64; }
+inline int grid_cap(int64_t n, int bs) { int64_t g = (n + bs - 1) / bs; return (int)(g < 1 ? 1 : g > 4096 ? 4096 : g); }
+
+}  // namespace
+
+#define NIT_SWITCH(nit, ...)                                    \
+  do {                                                          \
+    if (nit <= 1) { constexpr int NIT = 1; __VA_ARGS__; }              \
+    else if (nit <= 2) { constexpr int NIT = 2; __VA_ARGS__; }         \
+    else if (nit <= 3) { constexpr int NIT = 3; __VA_ARGS__; }         \
+    else if (nit <= 4) { constexpr int NIT = 4; __VA_ARGS__; }         \
+    else if (nit <= 6) { constexpr int NIT = 6; __VA_ARGS__; }         \
+    else if (nit <= 9) { constexpr int NIT = 9; __VA_ARGS__; }         \
+    else if (nit <= 12) { constexpr int NIT = 12; __VA_ARGS__; }       \
+    else { constexpr int NIT = 16; __VA_ARGS__; }                      \
+  } while (0)
+
+extern "C" int mmdit_abi_version(void) { return 1; }
+extern "C" const char* mmdit_build_arch(void) { return "gfx950"; }
+
+extern "C" int mmdit_ln_modulate_fwd(const float* x, const float* scale, const float* shift, int64_t ld_mod, int rows, int d, int rpb,
+                                     void* out, int out_dtype, float* mean, float* rstd, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && scale && shift && out && mean && rstd && rows > 0 && d > 0 && d % 4 == 0 && d <= 4096 && rpb > 0 && ld_mod % 4 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d);
+  dim3 grid((rows + 3) / 4);
+  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, bf16_t>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd)); }
+  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, float>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd)); }
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_ln_modulate_bwd(const void* dout, int dout_dtype, const float* x, const float* mean, const float* rstd, const float* scale, int64_t ld_mod,
+                                     const float* dres, int rows, int d, int rpb, float* dx, float* dscale, float* dshift, int64_t ld_dmod, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dout && x && mean && rstd && scale && dx && dscale && dshift && rows > 0 && d % 4 == 0 && d <= 4096 && rpb > 0 && rows % rpb == 0 && ld_mod % 4 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d), nchunk = (rpb + LN_BWD_RCH - 1) / LN_BWD_RCH;
+  dim3 grid((rows / rpb) * nchunk);
+  if (dout_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_kernel<NIT, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dout, x, mean, rstd, scale, ld_mod, dres, d, rpb, nchunk, dx, dscale, dshift, ld_dmod)); }
+  else if (dout_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_kernel<NIT, float>), grid, dim3(256), 0, s, (const float*)dout, x, mean, rstd, scale, ld_mod, dres, d, rpb, nchunk, dx, dscale, dshift, ld_dmod)); }
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_text_rmsnorm_fwd(const void* x, int x_dtype, const float* w1, const float* w2, const float* s1, const float* s2,
+                                      int batch, int tokens, int split, int d, void* out1, void* out2, int out_dtype, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && w1 && w2 && s1 && s2 && out1 && out2 && batch > 0 && split > 0 && split < tokens && d % 4 == 0 && d <= 4096);
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d);
+  for (int half = 0; half < 2; half++) {
+    const int cnt = half ? tokens - split : split, off = half ? split : 0, rows = batch * cnt;
+    const float* w = half ? w2 : w1; const float* sp = half ? s2 : s1; void* out = half ? out2 : out1;
+    dim3 grid((rows + 3) / 4);
+#define TRF(TI, TO) NIT_SWITCH(nit, hipLaunchKernelGGL((text_rms_fwd_kernel<NIT, TI, TO>), grid, dim3(256), 0, s, (const TI*)x, w, sp, rows, cnt, tokens, off, d, (TO*)out))
+    if (x_dtype == MMDIT_F32 && out_dtype == MMDIT_F32) { TRF(float, float); }
+    else if (x_dtype == MMDIT_F32 && out_dtype == MMDIT_BF16) { TRF(float, bf16_t); }
+    else if (x_dtype == MMDIT_BF16 && out_dtype == MMDIT_BF16) { TRF(bf16_t, bf16_t); }
+    else if (x_dtype == MMDIT_BF16 && out_dtype == MMDIT_F32) { TRF(bf16_t, float); }
+    else return MMDIT_ERR_DTYPE;
+#undef TRF
+  }
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_text_rmsnorm_bwd(const void* dout1, const void* dout2, int dout_dtype, const void* x, int x_dtype,
+                                      const float* w1, const float* w2, const float* s1, const float* s2, int batch, int tokens, int split, int d,
+                                      float* dw1, float* dw2, float* ds1, float* ds2, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dout1 && dout2 && x && w1 && w2 && s1 && s2 && dw1 && dw2 && ds1 && ds2 && batch > 0 && split > 0 && split < tokens && d % 4 == 0 && d <= 4096);
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d);
+  for (int half = 0; half < 2; half++) {
+    const int cnt = half ? tokens - split : split, off = half ? split : 0, rows = batch * cnt;
+    const float* w = half ? w2 : w1; const float* sp = half ? s2 : s1; const void* dout = half ? dout2 : dout1;
+    float* dw = half ? dw2 : dw1; float* dsp = half ? ds2 : ds1;
+    dim3 grid((rows + 63) / 64);
+#define TRB(TI, TG) NIT_SWITCH(nit, hipLaunchKernelGGL((text_rms_bwd_kernel<NIT, TI, TG>), grid, dim3(256), 0, s, (const TG*)dout, (const TI*)x, w, sp, rows, cnt, tokens, off, d, dw, dsp))
+    if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_F32) { TRB(float, float); }
+    else if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_BF16) { TRB(float, bf16_t); }
+    else if (x_dtype == MMDIT_BF16 && dout_dtype == MMDIT_BF16) { TRB(bf16_t, bf16_t); }
+    else if (x_dtype == MMDIT_BF16 && dout_dtype == MMDIT_F32) { TRB(bf16_t, float); }
+    else return MMDIT_ERR_DTYPE;
+#undef TRB
+  }
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_qk_norm_rope_fwd(const void* qkv, int qkv_dtype, const float* wq, const float* wk, const float* rope_cos, const float* rope_sin,
+                                      int batch, int tokens, int heads, int s_total, int tok0, void* Q, void* K, void* V, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(qkv && wq && wk && Q && K && V && batch > 0 && tokens > 0 && heads > 0 && tok0 >= 0 && tok0 + tokens <= s_total);
+  MMDIT_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)batch * tokens * 3 * heads * 8;
+  dim3 grid(grid_cap(total, 256));
+  if (qkv_dtype == MMDIT_BF16) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)qkv, wq, wk, rope_cos, rope_sin, total, tokens, heads, s_total, tok0, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
+  else if (qkv_dtype == MMDIT_F32) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)qkv, wq, wk, rope_cos, rope_sin, total, tokens, heads, s_total, tok0, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void* dV, int dq_dtype, const void* qkv, int qkv_dtype,
+                                      const float* wq, const float* wk, const float* rope_cos, const float* rope_sin,
+                                      int batch, int tokens, int heads, int s_total, int tok0, void* dqkv, int dqkv_dtype, float* dwq, float* dwk, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dQ && dK && dV && qkv && wq && wk && dqkv && dwq && dwk && batch > 0 && tokens > 0 && heads > 0 && tok0 >= 0 && tok0 + tokens <= s_total);
+  MMDIT_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr));
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)batch * tokens * 3 * heads * 8;
+  dim3 grid(grid_cap(total, 256 * 8));
+#define QKB(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<TG, TI, TO>), grid, dim3(256), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, total, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk)
+  if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_BF16 && dqkv_dtype == MMDIT_BF16) QKB(bf16_t, bf16_t, bf16_t);
+  else if (dq_dtype == MMDIT_F32 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(float, float, float);
+  else if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(bf16_t, float, float);
+  else return MMDIT_ERR_DTYPE;
+#undef QKB
+  return mmdit_launch_status();
+}
+
+template <bool GELU>
+static int mlp_act_fwd(const void* gu, void* h, int dtype, int rows, int hidden, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(gu && h && rows > 0 && hidden > 0 && hidden % 8 == 0);
+  dim3 grid((hidden + 1023) / 1024, (rows + CO_RCH - 1) / CO_RCH);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MMDIT_BF16) hipLaunchKernelGGL((mlp_act_fwd_kernel<bf16_t, GELU>), grid, dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)h, rows, hidden);
+  else if (dtype == MMDIT_F32) hipLaunchKernelGGL((mlp_act_fwd_kernel<float, GELU>), grid, dim3(256), 0, s, (const float*)gu, (float*)h, rows, hidden);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+template <bool GELU>
+static int mlp_act_bwd(const void* dh, const void* gu, void* dgu, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dh && gu && dgu && rows > 0 && hidden > 0 && hidden % 8 == 0);
+  dim3 grid((hidden + 1023) / 1024, (rows + CO_RCH - 1) / CO_RCH);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MMDIT_BF16) hipLaunchKernelGGL((mlp_act_bwd_kernel<bf16_t, GELU>), grid, dim3(256), 0, s, (const bf16_t*)dh, (const bf16_t*)gu, (bf16_t*)dgu, rows, hidden, dbias);
+  else if (dtype == MMDIT_F32) hipLaunchKernelGGL((mlp_act_bwd_kernel<float, GELU>), grid, dim3(256), 0, s, (const float*)dh, (const float*)gu, (float*)dgu, rows, hidden, dbias);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+extern "C" int mmdit_swiglu_fwd(const void* gu, void* h, int dtype, int rows, int hidden, mmdit_stream_t st) { return mlp_act_fwd<false>(gu, h, dtype, rows, hidden, st); }
+extern "C" int mmdit_swiglu_bwd(const void* dh, const void* gu, void* dgu, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t st) { return mlp_act_bwd<false>(dh, gu, dgu, dtype, rows, hidden, dbias, st); }
+extern "C" int mmdit_gelu_fwd(const void* u, void* h, int dtype, int rows, int hidden, mmdit_stream_t st) { return mlp_act_fwd<true>(u, h, dtype, rows, hidden, st); }
+extern "C" int mmdit_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t st) { return mlp_act_bwd<true>(dh, u, du, dtype, rows, hidden, dbias, st); }
+
+extern "C" int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dy && pre && dpre && rows > 0 && cols > 0);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((cols + 255) / 256);
+  if (dy_dtype == MMDIT_BF16 && dpre_dtype == MMDIT_BF16) hipLaunchKernelGGL((silu_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, pre, (bf16_t*)dpre, rows, cols, dbias);
+  else if (dy_dtype == MMDIT_F32 && dpre_dtype == MMDIT_F32) hipLaunchKernelGGL((silu_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)dy, pre, (float*)dpre, rows, cols, dbias);
+  else if (dy_dtype == MMDIT_F32 && dpre_dtype == MMDIT_BF16) hipLaunchKernelGGL((silu_bwd_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)dy, pre, (bf16_t*)dpre, rows, cols, dbias);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, int rows, int d, int rpb,
+                                       void* dacc, int dacc_dtype, float* dgate, int64_t ld_dgate, float* dbias, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dy && acc && gate && dacc && dgate && rows > 0 && d % 8 == 0 && rpb > 0 && rows % rpb == 0 && ld_gate % 4 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int nchunk = (rpb + CO_RCH - 1) / CO_RCH;
+  dim3 grid((d + 1023) / 1024, (rows / rpb) * nchunk);
+  if (acc_dtype == MMDIT_BF16 && dacc_dtype == MMDIT_BF16) hipLaunchKernelGGL((gate_res_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, dy, (const bf16_t*)acc, gate, ld_gate, d, rpb, nchunk, (bf16_t*)dacc, dgate, ld_dgate, dbias);
+  else if (acc_dtype == MMDIT_F32 && dacc_dtype == MMDIT_F32) hipLaunchKernelGGL((gate_res_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, (const float*)acc, gate, ld_gate, d, rpb, nchunk, (float*)dacc, dgate, ld_dgate, dbias);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* out, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ld % 8 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((cols + 1023) / 1024, (rows + CO_RCH - 1) / CO_RCH);
+  if (dtype == MMDIT_BF16) hipLaunchKernelGGL((colsum_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, rows, cols, ld, out);
+  else if (dtype == MMDIT_F32) hipLaunchKernelGGL((colsum_kernel<float>), grid, dim3(256), 0, s, (const float*)x, rows, cols, ld, out);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(src && dst && n > 0);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(grid_cap(n / 8 + 1, 256));
+  if (src_dtype == MMDIT_F32 && dst_dtype == MMDIT_BF16) hipLaunchKernelGGL((cast_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == MMDIT_BF16 && dst_dtype == MMDIT_F32) hipLaunchKernelGGL((cast_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+template <bool TO_TOKENS>
+static int patch_dispatch(const void* src, int sdt, void* dst, int ddt, int batch, int ch, int H, int W, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(src && dst && batch > 0 && ch > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(grid_cap((int64_t)batch * ch * H * (W / 2), 256));
+#define PK(TI, TO) hipLaunchKernelGGL((patch_kernel<TI, TO, TO_TOKENS>), grid, dim3(256), 0, s, (const TI*)src, (TO*)dst, batch, ch, H, W)
+  if (sdt == MMDIT_F32 && ddt == MMDIT_F32) PK(float, float);
+  else if (sdt == MMDIT_F32 && ddt == MMDIT_BF16) PK(float, bf16_t);
+  else if (sdt == MMDIT_BF16 && ddt == MMDIT_BF16) PK(bf16_t, bf16_t);
+  else if (sdt == MMDIT_BF16 && ddt == MMDIT_F32) PK(bf16_t, float);
+  else return MMDIT_ERR_DTYPE;
+#undef PK
+  return mmdit_launch_status();
+}
+extern "C" int mmdit_patchify(const void* img, int img_dtype, int batch, int ch, int H, int W, void* tokens, int tok_dtype, mmdit_stream_t st) {
+  return patch_dispatch<true>(img, img_dtype, tokens, tok_dtype, batch, ch, H, W, st);
+}
+extern "C" int mmdit_unpatchify(const void* tokens, int tok_dtype, int batch, int ch, int H, int W, void* img, int img_dtype, mmdit_stream_t st) {
+  return patch_dispatch<false>(tokens, tok_dtype, img, img_dtype, batch, ch, H, W, st);
+}
+
+extern "C" int mmdit_time_embed_fwd(const float* t, const float* time_scale, const float* denom, int batch, int dim, void* out, int out_dtype, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(t && time_scale && denom && out && batch > 0 && dim > 0 && dim % 2 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((dim + 255) / 256, batch);
+  if (out_dtype == MMDIT_BF16) hipLaunchKernelGGL((time_embed_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, t, time_scale, denom, batch, dim, (bf16_t*)out);
+  else if (out_dtype == MMDIT_F32) hipLaunchKernelGGL((time_embed_fwd_kernel<float>), grid, dim3(256), 0, s, t, time_scale, denom, batch, dim, (float*)out);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+extern "C" int mmdit_time_embed_bwd(const void* dout, int dout_dtype, const float* t, const float* time_scale, const float* denom, int batch, int dim, float* dtime_scale, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dout && t && time_scale && denom && dtime_scale && batch > 0 && dim > 0 && dim % 2 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  if (dout_dtype == MMDIT_BF16) hipLaunchKernelGGL((time_embed_bwd_kernel<bf16_t>), dim3(batch), dim3(256), 0, s, (const bf16_t*)dout, t, time_scale, denom, batch, dim, dtime_scale);
+  else if (dout_dtype == MMDIT_F32) hipLaunchKernelGGL((time_embed_bwd_kernel<float>), dim3(batch), dim3(256), 0, s, (const float*)dout, t, time_scale, denom, batch, dim, dtime_scale);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}

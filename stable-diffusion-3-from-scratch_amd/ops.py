@@ -1,0 +1,222 @@
+"""Thin tensor-level wrappers over the C ABI (include/mmdit_hip.h).
+
+Every function launches on torch's current HIP stream and never synchronises.
+PyTorch is used only to own device memory; all arithmetic happens in libmmdit_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_SILU, BF16, F32, PREC_BF16, PREC_SPLIT, GemmArgs, check
+
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise RuntimeError(f"unsupported dtype {t.dtype} (the HIP path takes float32 / bfloat16)")
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("mmdit HIP op called with a CPU tensor: the MMDiT hot path has no CPU fallback")
+    return t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _c(t):
+    if t is not None and not t.is_contiguous():
+        raise RuntimeError("mmdit HIP ops need contiguous tensors")
+    return t
+
+
+def torch_dtype(code: int):
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(A, B, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
+         gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16):
+    """C[M,N] = epilogue(A[M,K] B[N,K]^T).  A: (M,K) or k-major (K,M); B: (N,K) or k-major (K,N).
+    gate may be a strided 2-D view (rows = batch) with unit inner stride."""
+    if a_kmajor:
+        K_, M_ = A.shape
+    else:
+        M_, K_ = A.shape
+    if b_kmajor:
+        Kb, N_ = B.shape
+    else:
+        N_, Kb = B.shape
+    if K_ != Kb:
+        raise RuntimeError(f"gemm: inner dimensions differ ({K_} vs {Kb})")
+    M, N, K = M or M_, N or N_, K or K_
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
+    a = GemmArgs()
+    a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), A.stride(0)
+    a.B, a.b_dtype, a.b_kmajor, a.ldb = _p(B), _dt(B), int(b_kmajor), B.stride(0)
+    a.C, a.c_dtype, a.ldc = _p(out), _dt(out), out.stride(0)
+    a.M, a.N, a.K = M, N, K
+    a.bias = _p(bias)
+    a.act = act
+    if gate is not None:
+        a.gate, a.ld_gate, a.rows_per_batch = _p(gate), gate.stride(0), rows_per_batch
+    if residual is not None:
+        a.residual, a.ld_res = _p(residual), residual.stride(0)
+    if aux is not None:
+        a.aux, a.aux_dtype, a.ld_aux = _p(aux), _dt(aux), aux.stride(0)
+    a.accumulate = int(accumulate)
+    a.precision = precision
+    check(_lib.lib().mmdit_gemm(ctypes.byref(a), _s()), "mmdit_gemm")
+    return out
+
+
+def cast(src, dtype, out=None):
+    if out is None:
+        out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    check(_lib.lib().mmdit_cast(_p(_c(src)), _dt(src), _p(_c(out)), _dt(out), src.numel(), _s()), "mmdit_cast")
+    return out
+
+
+def ln_modulate_fwd(x, scale, shift, rows_per_batch, out_dtype):
+    rows, d = x.shape
+    out = torch.empty((rows, d), dtype=out_dtype, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmdit_ln_modulate_fwd(_p(_c(x)), _p(scale), _p(shift), scale.stride(0), rows, d, rows_per_batch,
+                                           _p(out), _dt(out), _p(mean), _p(rstd), _s()), "mmdit_ln_modulate_fwd")
+    return out, mean, rstd
+
+
+def ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rows_per_batch, dscale, dshift):
+    """Returns dx (fp32) = dres + LN-backward; accumulates into the dscale / dshift views (same leading dim)."""
+    rows, d = x.shape
+    dx = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmdit_ln_modulate_bwd(_p(_c(dout)), _dt(dout), _p(x), _p(mean), _p(rstd), _p(scale), scale.stride(0), _p(dres),
+                                           rows, d, rows_per_batch, _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _s()), "mmdit_ln_modulate_bwd")
+    return dx
+
+
+def text_rmsnorm_fwd(x, w1, w2, s1, s2, split, out_dtype):
+    batch, tokens, d = x.shape
+    out1 = torch.empty((batch * split, d), dtype=out_dtype, device=x.device)
+    out2 = torch.empty((batch * (tokens - split), d), dtype=out_dtype, device=x.device)
+    check(_lib.lib().mmdit_text_rmsnorm_fwd(_p(_c(x)), _dt(x), _p(w1), _p(w2), _p(s1), _p(s2), batch, tokens, split, d,
+                                            _p(out1), _p(out2), _dt(out1), _s()), "mmdit_text_rmsnorm_fwd")
+    return out1, out2
+
+
+def text_rmsnorm_bwd(dout1, dout2, x, w1, w2, s1, s2, split):
+    batch, tokens, d = x.shape
+    dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
+    ds1, ds2 = torch.zeros_like(s1), torch.zeros_like(s2)
+    check(_lib.lib().mmdit_text_rmsnorm_bwd(_p(_c(dout1)), _p(_c(dout2)), _dt(dout1), _p(x), _dt(x), _p(w1), _p(w2), _p(s1), _p(s2),
+                                            batch, tokens, split, d, _p(dw1), _p(dw2), _p(ds1), _p(ds2), _s()), "mmdit_text_rmsnorm_bwd")
+    return dw1, dw2, ds1, ds2
+
+
+def qk_norm_rope_fwd(qkv, wq, wk, rope_cos, rope_sin, batch, tokens, heads, s_total, tok0, Q, K, V):
+    check(_lib.lib().mmdit_qk_norm_rope_fwd(_p(_c(qkv)), _dt(qkv), _p(wq), _p(wk), _p(rope_cos), _p(rope_sin), batch, tokens, heads, s_total, tok0,
+                                            _p(Q), _p(K), _p(V), _s()), "mmdit_qk_norm_rope_fwd")
+
+
+def qk_norm_rope_bwd(dQ, dK, dV, qkv, wq, wk, rope_cos, rope_sin, batch, tokens, heads, s_total, tok0, dwq, dwk, out_dtype):
+    dqkv = torch.empty(qkv.shape, dtype=out_dtype, device=qkv.device)
+    check(_lib.lib().mmdit_qk_norm_rope_bwd(_p(dQ), _p(dK), _p(dV), _dt(dQ), _p(qkv), _dt(qkv), _p(wq), _p(wk), _p(rope_cos), _p(rope_sin),
+                                            batch, tokens, heads, s_total, tok0, _p(dqkv), _dt(dqkv), _p(dwq), _p(dwk), _s()), "mmdit_qk_norm_rope_bwd")
+    return dqkv
+
+
+def attn_fwd(Q, K, V, n_img, scale, mode):
+    batch, heads, S, hd = Q.shape
+    if hd != 64:
+        raise RuntimeError("attention kernels are built for head_dim 64 (the reference's dim = 64*num_heads convention)")
+    D = heads * hd
+    Ox = torch.empty((batch, n_img, D), dtype=torch.bfloat16, device=Q.device)
+    Oc = torch.empty((batch, S - n_img, D), dtype=torch.bfloat16, device=Q.device) if S > n_img else None
+    lse = torch.empty((batch, heads, S), dtype=torch.float32, device=Q.device)
+    check(_lib.lib().mmdit_attn_fwd(_p(Q), _p(K), _p(V), batch, heads, S, n_img, float(scale), mode, _p(Ox), _p(Oc), _p(lse), _s()), "mmdit_attn_fwd")
+    return Ox, Oc, lse
+
+
+def attn_bwd(Q, K, V, Ox, Oc, dOx, dOc, lse, n_img, scale, out_dtype):
+    batch, heads, S, hd = Q.shape
+    delta = torch.empty((batch, heads, S), dtype=torch.float32, device=Q.device)
+    dQ = torch.empty(Q.shape, dtype=out_dtype, device=Q.device)
+    dK = torch.empty(Q.shape, dtype=out_dtype, device=Q.device)
+    dV = torch.empty(Q.shape, dtype=out_dtype, device=Q.device)
+    check(_lib.lib().mmdit_attn_bwd(_p(Q), _p(K), _p(V), _p(Ox), _p(Oc), _p(_c(dOx)), _p(_c(dOc)), _p(lse), _p(delta), batch, heads, S, n_img,
+                                    float(scale), _p(dQ), _p(dK), _p(dV), _dt(dQ), _s()), "mmdit_attn_bwd")
+    return dQ, dK, dV
+
+
+def mlp_act_fwd(gu, hidden, gelu=False):
+    rows = gu.shape[0]
+    h = torch.empty((rows, hidden), dtype=gu.dtype, device=gu.device)
+    fn = _lib.lib().mmdit_gelu_fwd if gelu else _lib.lib().mmdit_swiglu_fwd
+    check(fn(_p(_c(gu)), _p(h), _dt(gu), rows, hidden, _s()), "mmdit_mlp_act_fwd")
+    return h
+
+
+def mlp_act_bwd(dh, gu, hidden, dbias, gelu=False):
+    rows = gu.shape[0]
+    dgu = torch.empty_like(gu)
+    fn = _lib.lib().mmdit_gelu_bwd if gelu else _lib.lib().mmdit_swiglu_bwd
+    check(fn(_p(_c(dh)), _p(gu), _p(dgu), _dt(gu), rows, hidden, _p(dbias), _s()), "mmdit_mlp_act_bwd")
+    return dgu
+
+
+def silu_bwd(dy, pre, out_dtype, dbias):
+    rows, cols = pre.shape
+    dpre = torch.empty((rows, cols), dtype=out_dtype, device=pre.device)
+    check(_lib.lib().mmdit_silu_bwd(_p(_c(dy)), _dt(dy), _p(pre), _p(dpre), _dt(dpre), rows, cols, _p(dbias), _s()), "mmdit_silu_bwd")
+    return dpre
+
+
+def gate_residual_bwd(dy, acc, gate, rows_per_batch, dgate, dbias, out_dtype):
+    rows, d = dy.shape
+    dacc = torch.empty((rows, d), dtype=out_dtype, device=dy.device)
+    check(_lib.lib().mmdit_gate_residual_bwd(_p(_c(dy)), _p(acc), _dt(acc), _p(gate), gate.stride(0), rows, d, rows_per_batch,
+                                             _p(dacc), _dt(dacc), _p(dgate), dgate.stride(0), _p(dbias), _s()), "mmdit_gate_residual_bwd")
+    return dacc
+
+
+def colsum(x, out):
+    rows, cols = x.shape
+    check(_lib.lib().mmdit_colsum(_p(x), _dt(x), rows, cols, x.stride(0), _p(out), _s()), "mmdit_colsum")
+    return out
+
+
+def patchify(img, out_dtype):
+    batch, ch, H, W = img.shape
+    tokens = torch.empty((batch * (H // 2) * (W // 2), ch * 4), dtype=out_dtype, device=img.device)
+    check(_lib.lib().mmdit_patchify(_p(_c(img)), _dt(img), batch, ch, H, W, _p(tokens), _dt(tokens), _s()), "mmdit_patchify")
+    return tokens
+
+
+def unpatchify(tokens, batch, ch, H, W, out_dtype):
+    img = torch.empty((batch, ch, H, W), dtype=out_dtype, device=tokens.device)
+    check(_lib.lib().mmdit_unpatchify(_p(_c(tokens)), _dt(tokens), batch, ch, H, W, _p(img), _dt(img), _s()), "mmdit_unpatchify")
+    return img
+
+
+def time_embed_fwd(t, time_scale, denom, out_dtype):
+    batch, dim = t.shape[0], denom.shape[0]
+    out = torch.empty((batch, dim), dtype=out_dtype, device=t.device)
+    check(_lib.lib().mmdit_time_embed_fwd(_p(t), _p(time_scale), _p(denom), batch, dim, _p(out), _dt(out), _s()), "mmdit_time_embed_fwd")
+    return out
+
+
+def time_embed_bwd(dout, t, time_scale, denom):
+    batch, dim = t.shape[0], denom.shape[0]
+    dts = torch.zeros_like(time_scale)
+    check(_lib.lib().mmdit_time_embed_bwd(_p(_c(dout)), _dt(dout), _p(t), _p(time_scale), _p(denom), batch, dim, _p(dts), _s()), "mmdit_time_embed_bwd")
+    return dts

@@ -1,0 +1,314 @@
+"""GPU parity tests of each HIP kernel (through the C ABI) against plain torch fp32 references of the
+same op, on seeded inputs.  Tolerances: fp32 / split-bf16 paths 1e-5..1e-4 relative, bf16 paths
+bounded by bf16 rounding of inputs/outputs (stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import sd3_amd  # noqa: F401
+    from sd3_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return _ops
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).cuda()
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (300, 200, 72), (64, 9216, 768), (1000, 64, 768), (308, 256, 2304)])
+def test_gemm_nt_bf16(ops, M, N, K):
+    A, B = rnd(M, K, seed=1, dtype=torch.bfloat16), rnd(N, K, seed=2, dtype=torch.bfloat16)
+    ref = A.float() @ B.float().T
+    out = ops.gemm(A, B, out_dtype=torch.float32)
+    assert rel(out, ref) < 1e-5
+    outb = ops.gemm(A, B, out_dtype=torch.bfloat16)
+    assert rel(outb, ref) < 4e-3  # bf16 output rounding
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 72), (256, 768, 768)])
+def test_gemm_split_fp32(ops, M, N, K):
+    A, B = rnd(M, K, seed=3), rnd(N, K, seed=4)
+    ref = (A.double() @ B.double().T)
+    out = ops.gemm(A, B, out_dtype=torch.float32, precision=ops.PREC_SPLIT)
+    assert rel(out, ref) < 2e-5  # split-bf16: ~16 mantissa bits per operand
+
+
+@pytest.mark.parametrize("prec", ["bf16", "split"])
+def test_gemm_layouts_dgrad_wgrad(ops, prec):
+    M, N, K = 308, 256, 192  # ragged reduction length for wgrad (M = 308 = 2*154)
+    dt = torch.bfloat16 if prec == "bf16" else torch.float32
+    p = ops.PREC_BF16 if prec == "bf16" else ops.PREC_SPLIT
+    tol = 1e-5 if prec == "bf16" else 2e-5
+    dY, W, X = rnd(M, N, seed=5, dtype=dt), rnd(N, K, seed=6, dtype=dt), rnd(M, K, seed=7, dtype=dt)
+    # dgrad: dX[M,K] = dY[M,N] @ W[N,K]   (B k-major)
+    dX = ops.gemm(dY, W, b_kmajor=True, out_dtype=torch.float32, precision=p)
+    assert rel(dX, dY.double() @ W.double()) < tol
+    # wgrad: dW[N,K] = dY^T[N,M] @ X[M,K]  (both k-major)
+    dW = ops.gemm(dY, X, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, precision=p)
+    assert rel(dW, dY.double().T @ X.double()) < tol
+
+
+def test_gemm_epilogue(ops):
+    Bt, rpb, N, K = 3, 100, 256, 128
+    M = Bt * rpb
+    A, W = rnd(M, K, seed=8, dtype=torch.bfloat16), rnd(N, K, seed=9, dtype=torch.bfloat16)
+    bias, res = rnd(N, seed=10), rnd(M, N, seed=11)
+    mod = rnd(Bt, 3 * N, seed=12)
+    gate = mod[:, N:2 * N]
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(A, W, out_dtype=torch.float32, bias=bias, gate=gate, rows_per_batch=rpb, residual=res, aux=aux)
+    acc = A.float() @ W.float().T + bias
+    ref = res + gate.repeat_interleave(rpb, 0) * acc
+    assert rel(out, ref) < 1e-5
+    assert rel(aux, acc) < 4e-3
+    # silu + aux (pre-activation) + accumulate
+    pre = torch.empty((M, N), dtype=torch.float32, device="cuda")
+    o2 = ops.gemm(A, W, out_dtype=torch.bfloat16, bias=bias, act=ops.ACT_SILU, aux=pre)
+    assert rel(pre, acc) < 1e-5
+    assert rel(o2, F.silu(acc)) < 4e-3
+    c = res.clone()
+    ops.gemm(A, W, out=c, accumulate=True)
+    assert rel(c, res + A.float() @ W.float().T) < 1e-5
+    # residual without gate
+    o3 = ops.gemm(A, W, out_dtype=torch.float32, residual=res)
+    assert rel(o3, res + A.float() @ W.float().T) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ row kernels
+@pytest.mark.parametrize("d,rpb,Bt", [(768, 256, 3), (256, 154, 2), (128, 64, 2), (1024, 77, 2)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_ln_modulate(ops, d, rpb, Bt, dt):
+    rows = Bt * rpb
+    x = rnd(rows, d, seed=1) * 2 + 0.5
+    mod = rnd(Bt, 4 * d, seed=2, scale=0.3)
+    scale, shift = mod[:, d:2 * d], mod[:, 3 * d:]
+    out, mean, rstd = ops.ln_modulate_fwd(x, scale, shift, rpb, dt)
+    xr = x.clone().requires_grad_(True)
+    sr, hr = scale.clone().requires_grad_(True), shift.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (d,)) * (1 + sr.repeat_interleave(rpb, 0)) + hr.repeat_interleave(rpb, 0)
+    tol = 1e-5 if dt == torch.float32 else 4e-3
+    assert rel(out, ref) < tol
+    assert rel(mean, x.mean(-1)) < 1e-5
+    dout = rnd(rows, d, seed=3).to(dt)
+    dres = rnd(rows, d, seed=4)
+    ref.backward(dout.float())
+    dmod = torch.zeros((Bt, 2 * d), device="cuda")
+    dx = ops.ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rpb, dmod[:, :d], dmod[:, d:])
+    assert rel(dx, xr.grad + dres) < 2e-5
+    assert rel(dmod[:, :d], sr.grad) < 2e-5
+    assert rel(dmod[:, d:], hr.grad) < 2e-5
+
+
+@pytest.mark.parametrize("xdt", [torch.float32, torch.bfloat16])
+def test_text_rmsnorm(ops, xdt):
+    Bt, d = 3, 2304
+    x = (rnd(Bt, 154, d, seed=1) * 30).to(xdt)
+    w1, w2 = 1 + 0.1 * rnd(d, seed=2), 1 + 0.1 * rnd(d, seed=3)
+    s1, s2 = torch.tensor([0.01], device="cuda"), torch.tensor([0.02], device="cuda")
+    o1, o2 = ops.text_rmsnorm_fwd(x, w1, w2, s1, s2, 77, torch.float32)
+    xf = x.float()
+    w1r, w2r, s1r, s2r = [t.clone().requires_grad_(True) for t in (w1, w2, s1, s2)]
+    r1 = s1r * F.rms_norm(xf[:, :77], (d,), w1r, torch.finfo(torch.float32).eps)
+    r2 = s2r * F.rms_norm(xf[:, 77:], (d,), w2r, torch.finfo(torch.float32).eps)
+    assert rel(o1, r1.reshape(-1, d)) < 1e-5 and rel(o2, r2.reshape(-1, d)) < 1e-5
+    g1, g2 = rnd(Bt * 77, d, seed=4), rnd(Bt * 77, d, seed=5)
+    (r1.reshape(-1, d) * g1).sum().backward()
+    (r2.reshape(-1, d) * g2).sum().backward()
+    dw1, dw2, ds1, ds2 = ops.text_rmsnorm_bwd(g1, g2, x, w1, w2, s1, s2, 77)
+    assert rel(dw1, w1r.grad) < 2e-5 and rel(dw2, w2r.grad) < 2e-5
+    assert rel(ds1, s1r.grad) < 2e-5 and rel(ds2, s2r.grad) < 2e-5
+
+
+def _rope_tables(h2, w2):
+    inv = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    fh = (torch.arange(h2).float()[:, None] * inv[None]).repeat_interleave(2, -1)[:, None, :].expand(h2, w2, -1)
+    fw = (torch.arange(w2).float()[:, None] * inv[None]).repeat_interleave(2, -1)[None, :, :].expand(h2, w2, -1)
+    fr = torch.cat([fh, fw], -1).reshape(h2 * w2, 64)
+    return fr.cos().contiguous().cuda(), fr.sin().contiguous().cuda()
+
+
+def _rot_half(x):
+    x = x.reshape(*x.shape[:-1], -1, 2)
+    a, b = x.unbind(-1)
+    return torch.stack((-b, a), -1).reshape(*x.shape[:-2], -1)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_qk_norm_rope(ops, dt):
+    Bt, H, h2, w2, Mtxt = 2, 3, 4, 6, 10
+    N = h2 * w2
+    S = N + Mtxt
+    d = H * 64
+    cos, sin = _rope_tables(h2, w2)
+    wq, wk = 1 + 0.1 * rnd(64, seed=1), 1 + 0.1 * rnd(64, seed=2)
+    qkv_x = rnd(Bt * N, 3 * d, seed=3).to(dt)
+    qkv_c = rnd(Bt * Mtxt, 3 * d, seed=4).to(dt)
+    Q = torch.zeros((Bt, H, S, 64), dtype=torch.bfloat16, device="cuda")
+    K, V = torch.zeros_like(Q), torch.zeros_like(Q)
+    ops.qk_norm_rope_fwd(qkv_x, wq, wk, cos, sin, Bt, N, H, S, 0, Q, K, V)
+    ops.qk_norm_rope_fwd(qkv_c, wq, wk, None, None, Bt, Mtxt, H, S, N, Q, K, V)
+
+    def ref(qkv, L, rope, wq_, wk_):
+        q, k, v = qkv.float().reshape(Bt, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+        q = F.rms_norm(q, (64,), wq_, torch.finfo(torch.float32).eps)
+        k = F.rms_norm(k, (64,), wk_, torch.finfo(torch.float32).eps)
+        if rope:
+            q = q * cos + _rot_half(q) * sin
+            k = k * cos + _rot_half(k) * sin
+        return q, k, v
+
+    xr, cr = qkv_x.float().requires_grad_(True), qkv_c.float().requires_grad_(True)
+    wqr, wkr = wq.clone().requires_grad_(True), wk.clone().requires_grad_(True)
+    qx, kx, vx = ref(xr, N, True, wqr, wkr)
+    qc, kc, vc = ref(cr, Mtxt, False, wqr, wkr)
+    Qr, Kr, Vr = torch.cat([qx, qc], 2), torch.cat([kx, kc], 2), torch.cat([vx, vc], 2)
+    assert rel(Q, Qr) < 4e-3 and rel(K, Kr) < 4e-3 and rel(V, Vr) < 4e-3
+    gdt = dt
+    dQ, dK, dV = rnd(Bt, H, S, 64, seed=5).to(gdt), rnd(Bt, H, S, 64, seed=6).to(gdt), rnd(Bt, H, S, 64, seed=7).to(gdt)
+    (Qr * dQ.float()).sum().backward(retain_graph=True)
+    (Kr * dK.float()).sum().backward(retain_graph=True)
+    (Vr * dV.float()).sum().backward()
+    dwq, dwk = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
+    dx = ops.qk_norm_rope_bwd(dQ, dK, dV, qkv_x, wq, wk, cos, sin, Bt, N, H, S, 0, dwq, dwk, dt)
+    dc = ops.qk_norm_rope_bwd(dQ, dK, dV, qkv_c, wq, wk, None, None, Bt, Mtxt, H, S, N, dwq, dwk, dt)
+    tol = 2e-5 if dt == torch.float32 else 6e-3
+    assert rel(dx, xr.grad) < tol and rel(dc, cr.grad) < tol
+    assert rel(dwq, wqr.grad) < tol and rel(dwk, wkr.grad) < tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_mlp_act(ops, dt, gelu):
+    rows, hidden = 300, 1536
+    gu = rnd(rows, hidden if gelu else 2 * hidden, seed=1).to(dt)
+    gr = gu.float().requires_grad_(True)
+    if gelu:
+        ref = F.gelu(gr)
+    else:
+        g, u = gr.chunk(2, -1)
+        ref = F.silu(g) * u
+    h = ops.mlp_act_fwd(gu, hidden, gelu)
+    tol = 1e-5 if dt == torch.float32 else 4e-3
+    assert rel(h, ref) < tol
+    dh = rnd(rows, hidden, seed=2).to(dt)
+    ref.backward(dh.float())
+    db = torch.zeros(gu.shape[1], device="cuda")
+    dgu = ops.mlp_act_bwd(dh, gu, hidden, db, gelu)
+    assert rel(dgu, gr.grad) < (2e-5 if dt == torch.float32 else 5e-3)
+    assert rel(db, gr.grad.sum(0)) < (2e-5 if dt == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gate_residual_bwd_colsum_silu(ops, dt):
+    Bt, rpb, d = 3, 154, 768
+    rows = Bt * rpb
+    dy, acc = rnd(rows, d, seed=1), rnd(rows, d, seed=2).to(dt)
+    mod = rnd(Bt, 2 * d, seed=3)
+    gate = mod[:, d:]
+    dmod = torch.zeros((Bt, 2 * d), device="cuda")
+    db = torch.zeros(d, device="cuda")
+    dacc = ops.gate_residual_bwd(dy, acc, gate, rpb, dmod[:, :d], db, dt)
+    ref = dy * gate.repeat_interleave(rpb, 0)
+    tol = 2e-5 if dt == torch.float32 else 4e-3
+    assert rel(dacc, ref) < tol
+    assert rel(dmod[:, :d], (dy * acc.float()).reshape(Bt, rpb, d).sum(1)) < 2e-5
+    assert rel(db, ref.sum(0)) < 2e-5
+    cs = torch.zeros(d, device="cuda")
+    ops.colsum(acc, cs)
+    assert rel(cs, acc.float().sum(0)) < 2e-5
+    pre = rnd(Bt, d, seed=4)
+    dyy = rnd(Bt, d, seed=5)
+    pr = pre.clone().requires_grad_(True)
+    F.silu(pr).backward(dyy)
+    dbb = torch.zeros(d, device="cuda")
+    dpre = ops.silu_bwd(dyy, pre, torch.float32, dbb)
+    assert rel(dpre, pr.grad) < 2e-5 and rel(dbb, pr.grad.sum(0)) < 2e-5
+
+
+def test_patchify_unpatchify_time_embed_cast(ops):
+    x = rnd(2, 16, 6, 10, seed=1)
+    tok = ops.patchify(x, torch.float32)
+    ref = x.reshape(2, 16, 3, 2, 5, 2).permute(0, 2, 4, 1, 3, 5).reshape(2 * 15, 64)
+    assert torch.equal(tok, ref)
+    img = ops.unpatchify(tok, 2, 16, 6, 10, torch.float32)
+    assert torch.equal(img, x)
+    dim = 256
+    denom = (torch.tensor(10000.0) ** ((2 * torch.arange(dim)) / dim)).float().cuda()
+    t = torch.tensor([0.02, 0.5, 0.98], device="cuda")
+    ts = torch.tensor([1000.0], device="cuda", requires_grad=True)
+    e = (t * ts)[:, None] / denom[None]
+    ref = torch.cat((e[:, ::2].sin(), e[:, 1::2].cos()), 1)
+    out = ops.time_embed_fwd(t, ts.detach(), denom, torch.float32)
+    assert (out - ref).abs().max() < 2e-4  # sin/cos of arguments up to 1e3 in fp32
+    g = rnd(3, dim, seed=2)
+    ref.backward(g)
+    dts = ops.time_embed_bwd(g, t, ts.detach(), denom)
+    assert abs(float(dts) - float(ts.grad)) < 1e-3 * (abs(float(ts.grad)) + 1e-3)
+    w = rnd(1003, seed=3)
+    assert torch.equal(ops.cast(w, torch.bfloat16), w.to(torch.bfloat16))
+
+
+# -------------------------------------------------------------------------------------- attention
+def _attn_ref(Q, K, V, scale, oracle):
+    q, k, v = Q.float(), K.float(), V.float()
+    if oracle:  # Attention.py:277-284
+        a = (Q @ K.mT) * scale
+        a = a.softmax(-1)
+        return (a @ V).float()
+    return ((q @ k.mT) * scale).softmax(-1) @ v
+
+
+@pytest.mark.parametrize("Bt,H,N,Mt", [(2, 3, 64, 30), (1, 2, 256, 154), (2, 2, 24, 154), (1, 1, 100, 0)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_attention_fwd(ops, Bt, H, N, Mt, mode):
+    S = N + Mt
+    Q, K, V = [rnd(Bt, H, S, 64, seed=s).to(torch.bfloat16) for s in (1, 2, 3)]
+    Ox, Oc, lse = ops.attn_fwd(Q, K, V, N, 0.125, mode)
+    ref = _attn_ref(Q, K, V, 0.125, mode == 1)
+    refm = ref.permute(0, 2, 1, 3).reshape(Bt, S, H * 64)
+    out = torch.cat([Ox, Oc], 1) if Mt else Ox
+    assert rel(out, refm) < (3e-3 if mode == 1 else 5e-3)
+    lse_ref = torch.logsumexp((Q.float() @ K.float().mT) * 0.125, -1)
+    assert (lse - lse_ref).abs().max() < 2e-2
+
+
+@pytest.mark.parametrize("Bt,H,N,Mt,last", [(2, 3, 64, 30, False), (1, 2, 256, 154, False), (2, 2, 24, 154, True)])
+def test_attention_bwd(ops, Bt, H, N, Mt, last):
+    S = N + Mt
+    Q, K, V = [rnd(Bt, H, S, 64, seed=s).to(torch.bfloat16) for s in (1, 2, 3)]
+    Ox, Oc, lse = ops.attn_fwd(Q, K, V, N, 0.125, 0)
+    dOx = rnd(Bt, N, H * 64, seed=4).to(torch.bfloat16)
+    dOc = None if last else rnd(Bt, Mt, H * 64, seed=5).to(torch.bfloat16)
+    dQ, dK, dV = ops.attn_bwd(Q, K, V, Ox, Oc, dOx, dOc, lse, N, 0.125, torch.float32)
+    qr, kr, vr = [t.float().requires_grad_(True) for t in (Q, K, V)]
+    ref = (((qr @ kr.mT) * 0.125).softmax(-1) @ vr).permute(0, 2, 1, 3).reshape(Bt, S, H * 64)
+    dO = torch.cat([dOx.float(), torch.zeros(Bt, Mt, H * 64, device="cuda") if last else dOc.float()], 1)
+    ref.backward(dO)
+    # bf16 P / dS operands: ~1e-2 relative
+    assert rel(dQ, qr.grad) < 1.5e-2 and rel(dK, kr.grad) < 1.5e-2 and rel(dV, vr.grad) < 1.5e-2
+
+
+def test_attention_oracle_mode_matches_cpu_oracle(ops):
+    """mode 1 must reproduce the reference's CPU attention branch far below the 1e-3 parity bar."""
+    from oracle.mmdit_oracle import attention_core
+    Bt, H, S = 1, 2, 410
+    Q, K, V = [rnd(Bt, H, S, 64, seed=s) for s in (1, 2, 3)]
+    Qb, Kb, Vb = Q.to(torch.bfloat16), K.to(torch.bfloat16), V.to(torch.bfloat16)
+    Ox, Oc, _ = ops.attn_fwd(Qb, Kb, Vb, 256, 0.125, 1)
+    ref = attention_core(Q.cpu(), K.cpu(), V.cpu(), 0.125, "oracle_bf16").permute(0, 2, 1, 3).reshape(Bt, S, H * 64)
+    out = torch.cat([Ox, Oc], 1).float().cpu()
+    assert rel(out, ref) < 3e-4
