@@ -1,0 +1,167 @@
+"""Benchmark of the MMDiT-B flow-matching TRAINING step on MI355X (BASELINE.json metric).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = one optimizer step on one synthetic batch per GPU (per-GPU batch 64, weak scaling):
+synthetic bf16 latents (64,16,32,32) + Gemma-2-2b-shaped text embeds (64,154,2304) + pooled (64,768)
+already resident in HBM -> noise -> MMDiT-B forward (HIP) -> rectified-flow MSE -> backward (HIP) ->
+RCCL gradient all-reduce (N>1) -> unscale, clip(1.0), AdamW, scheduler.  Nothing is skipped or cached.
+Rank 0 prints ONE JSON line.  value = N * 64 * K / max-over-ranks wall time.
+
+roofline: the dominant kernel (by total time) is the MFMA GEMM; every GEMM launch of three extra
+steps after the timed region is bracketed with HIP events on its launch stream, achieved = its
+algorithmic FLOPs (2*M*N*K per launch) / average launch duration; peak = 2.5 PFLOP/s dense bf16.
+cpu_baseline: the CPU oracle restatement of the reference (oracle/, validated bit-exact against the
+reference in the build container) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_CFG = dict(dim=768, num_heads=12, num_blocks=12)
+TRAIN_GFLOP_PER_IMG = 293.3   # 3 x 97.78 GFLOP forward (GEMM + attention matmuls, MAC = 2 FLOP)
+PEAK_BF16 = 2.5e15            # dense MFMA bf16 peak per MI355X (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """fwd + bwd + clip + AdamW of the oracle on MMDiT-B, batch 8, host cores only."""
+    import torch
+    from oracle import mmdit_oracle as O
+    from oracle.weights import make_state_dict
+    threads = torch.get_num_threads()
+    cfg = O.OracleConfig(**B_CFG)
+    tr = O.OracleTrainer(make_state_dict(0, **B_CFG), cfg, lr=1e-4, warmup_steps=0)
+    g = torch.Generator().manual_seed(0)
+    bs = 8
+
+    def batch():
+        x0 = torch.randn((bs, 16, 32, 32), generator=g)
+        c = torch.randn((bs, 154, 2304), generator=g)
+        c[:, :77] *= 30
+        c[:, 77:, 1024:] = 0
+        return x0, torch.randn(x0.shape, generator=g), torch.sigmoid(torch.randn((bs,), generator=g)), c, torch.randn((bs, 768), generator=g)
+
+    tr.step(*batch())  # warm-up
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < seconds_budget and n < 20):
+        tr.step(*batch())
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * bs / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} optimizer steps of MMDiT-B (fp32 weights, reference CPU attention branch), batch {bs}, fwd+bwd+clip+AdamW, torch CPU {threads} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs an MI355X: the MMDiT hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=torch.device(f"cuda:{local_rank}"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
+
+    import sd3_amd  # noqa: F401
+    from sd3_amd import ops
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.manual_seed(1234)
+    net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu", device=dev,
+                     positional_encoding="RoPE2d", checkpoint_MLP=False, checkpoint_attn=False, **B_CFG)
+    trainer = model_trainer(net, batchSize=args.batch, accumulation_steps=1, totalSteps=10 ** 9, lr=1e-4, ema_update_freq=10 ** 9, ema_decay=0.999,
+                            warmup_steps=1000, use_lr_scheduler=False, device=dev, saveDir="/tmp/bench_ckpt", numSaveSteps=10 ** 9,
+                            null_prob_pooled=0.1, null_prob_gemma=0.316, null_prob_bert=0.316, use_amp=True, max_res=256,
+                            device_rng=True, use_ema=False)
+    net.train()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        step += 1
+        trainer.train_step(step)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step += 1
+        loss = trainer.train_step(step)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et)
+    loss_val = float(loss)
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        ops.PROFILE = []
+        for _ in range(3):
+            step += 1
+            trainer.train_step(step)
+        torch.cuda.synchronize()
+        stats = {}
+        for name, flops, e0, e1 in ops.PROFILE:
+            s = stats.setdefault(name, [0, 0.0, 0.0])
+            s[0] += 1
+            s[1] += flops
+            s[2] += e0.elapsed_time(e1) * 1e-3
+        ops.PROFILE = None
+        tot_t = sum(s[2] for s in stats.values())
+        tot_f = sum(s[1] for s in stats.values())
+        dom = max(stats.items(), key=lambda kv: kv[1][2])
+        roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1][1] / dom[1][2] / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": round(dom[1][1] / dom[1][2] / PEAK_BF16, 4), "traffic": None,
+                    "avg_launch_us": round(dom[1][2] / dom[1][0] * 1e6, 2), "launches_per_step": dom[1][0] // 3,
+                    "all_gemm": {"achieved": round(tot_f / tot_t / 1e12, 1), "frac": round(tot_f / tot_t / PEAK_BF16, 4),
+                                 "ms_per_step": round(tot_t / 3 * 1e3, 3), "gflop_per_step": round(tot_f / 3 / 1e9, 1)},
+                    "by_kernel": {k: {"tflops": round(v[1] / v[2] / 1e12, 1), "ms_per_step": round(v[2] / 3 * 1e3, 3), "launches_per_step": v[0] // 3} for k, v in sorted(stats.items())}}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        value = world * args.batch * args.steps / elapsed
+        out = {"metric": "train images/sec MMDiT-B 256^2 bf16", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "MMDiT-B (12 blocks, d=768, 12 heads, SwiGLU 4x, RoPE2d) 256^2 images -> 32x32x16 latents, synthetic "
+                                      "Gemma-2-2b-shaped text embeds (154x2304) + pooled (768); fwd+bwd+grad-allreduce+clip+AdamW (fp32 master weights)",
+                          "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+               "mfma_roofline_frac_step": round(value * TRAIN_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16), 4), "final_loss": round(loss_val, 5)}
+        if roofline is not None:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -36,7 +36,7 @@ extern "C" {
 #define MMDIT_ACT_SILU 1
 
 #define MMDIT_PREC_BF16 0       /* single-pass bf16 MFMA operands, fp32 accumulate */
-#define MMDIT_PREC_SPLIT 1      /* split-bf16 (hi+lo) 3-pass MFMA: fp32-grade products */
+#define MMDIT_PREC_SPLIT 1      /* 3-term split-bf16, 6-pass MFMA: fp32-exact products (parity mode) */
 
 typedef void* mmdit_stream_t;   /* hipStream_t */
 

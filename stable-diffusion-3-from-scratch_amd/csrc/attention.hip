@@ -176,14 +176,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) rs += __expf(s[kb][r] - mn);
+          for (int r = 0; r < 16; r++) rs += expf(s[kb][r] - mn);
         rs += __shfl_xor(rs, 32, 64);
-        l = l * __expf(m - mn) + rs; m = mn;
+        l = l * expf(m - mn) + rs; m = mn;
       } else {
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) s[kb][r] = __expf(s[kb][r] - m) / l;   // softmax output, rounded to bf16 by pack_frag
+          for (int r = 0; r < 16; r++) s[kb][r] = expf(s[kb][r] - m) / l;   // softmax output, rounded to bf16 by pack_frag
         pv(s, vt(cur));
       }
       if (j + 1 < nkv) {
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         float v4[4] = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
         st4(dst + db * 32 + 8 * g + 4 * (lane >> 5), v4);
       }
-    if (lane < 32) lse[(int64_t)bh * S + q] = ORACLE ? m + __logf(l) : m * LN2 + __logf(l);
+    if (lane < 32) lse[(int64_t)bh * S + q] = ORACLE ? m + logf(l) : m * LN2 + logf(l);
   }
 }
 

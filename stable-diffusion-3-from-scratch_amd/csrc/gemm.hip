@@ -5,8 +5,11 @@
 // global -> registers -> LDS (double buffered, one barrier per K-tile).
 //   row-major operand tile  : LDS [128 rows][64 k] bf16, pitch 144 B (conflict-free ds_read_b128)
 //   k-major operand tile    : LDS [64 k][128 rows] bf16, pitch 320 B, fragments via ds_read_b64_tr_b16
-// SPLIT precision: fp32 operands are split into bf16 hi + lo while staging and the
-// product is formed as hi*hi + hi*lo + lo*hi (fp32-grade, 3 MFMA passes) -- the parity mode.
+// SPLIT precision (parity mode): fp32 operands are split exactly into three bf16 pieces
+// a = a0 + a1 + a2 (8+8+8 significand bits) while staging and the product is formed from the six
+// MFMA passes with weight >= 2^-16 (a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0): fp32-exact products,
+// fp32 accumulation.  A 2-term split (1e-5 relative) is not enough: the bf16 rounding points of the
+// attention core amplify an upstream error d to ~sqrt(d * 2^-8).
 #include "common.h"
 
 namespace {
@@ -56,7 +59,7 @@ __device__ __forceinline__ void load_tile(Stage<T, SPLIT>& st, const T* base, in
 }
 
 template <typename T, bool KM, bool SPLIT>
-__device__ __forceinline__ void store_tile(const Stage<T, SPLIT>& st, char* hi, char* lo, int tid) {
+__device__ __forceinline__ void store_tile(const Stage<T, SPLIT>& st, char* hi, char* mid, char* lo, int tid) {
 #pragma unroll
   for (int i = 0; i < CHUNKS; i++) {
     int c = tid + 256 * i, r, kc;
@@ -66,15 +69,23 @@ __device__ __forceinline__ void store_tile(const Stage<T, SPLIT>& st, char* hi, 
       *LDS_PTR(u32x4, hi + off) = st.v[i];
     } else {
       float f[8] = {st.v[i][0][0], st.v[i][0][1], st.v[i][0][2], st.v[i][0][3], st.v[i][1][0], st.v[i][1][1], st.v[i][1][2], st.v[i][1][3]};
-      uint32_t h[4], l[4];
+      uint32_t h[4], md[4], l[4];
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         bf16_t h0 = f2bf(f[2 * j]), h1 = f2bf(f[2 * j + 1]);
         h[j] = (uint32_t)h0 | ((uint32_t)h1 << 16);
-        if constexpr (SPLIT) l[j] = pack_bf2(f[2 * j] - bf2f(h0), f[2 * j + 1] - bf2f(h1));
+        if constexpr (SPLIT) {
+          const float r0 = f[2 * j] - bf2f(h0), r1 = f[2 * j + 1] - bf2f(h1);     // exact
+          const bf16_t m0 = f2bf(r0), m1 = f2bf(r1);
+          md[j] = (uint32_t)m0 | ((uint32_t)m1 << 16);
+          l[j] = pack_bf2(r0 - bf2f(m0), r1 - bf2f(m1));                           // exact residual, 8 bits left
+        }
       }
       *LDS_PTR(u32x4, hi + off) = (u32x4){h[0], h[1], h[2], h[3]};
-      if constexpr (SPLIT) *LDS_PTR(u32x4, lo + off) = (u32x4){l[0], l[1], l[2], l[3]};
+      if constexpr (SPLIT) {
+        *LDS_PTR(u32x4, mid + off) = (u32x4){md[0], md[1], md[2], md[3]};
+        *LDS_PTR(u32x4, lo + off) = (u32x4){l[0], l[1], l[2], l[3]};
+      }
     }
   }
 }
@@ -97,7 +108,7 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int r0, int ks, in
 
 template <typename TA, typename TB, bool A_KM, bool B_KM, bool SPLIT, typename TC, typename TAUX>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-  constexpr int NT = SPLIT ? 4 : 2;                  // tiles per stage: A_hi, B_hi, (A_lo, B_lo)
+  constexpr int NT = SPLIT ? 6 : 2;                  // tiles per stage: A0, B0, (A1, B1, A2, B2)
   constexpr int NSTAGE = SPLIT ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -123,8 +134,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
   load_tile<TA, A_KM, SPLIT>(sa, A, p.lda, m0, 0, p.M, p.K, tid);
   load_tile<TB, B_KM, SPLIT>(sb, B, p.ldb, n0, 0, p.N, p.K, tid);
-  store_tile<TA, A_KM, SPLIT>(sa, tile_ptr(0, 0), tile_ptr(0, 2), tid);
-  store_tile<TB, B_KM, SPLIT>(sb, tile_ptr(0, 1), tile_ptr(0, 3), tid);
+  store_tile<TA, A_KM, SPLIT>(sa, tile_ptr(0, 0), tile_ptr(0, 2), tile_ptr(0, 4), tid);
+  store_tile<TB, B_KM, SPLIT>(sb, tile_ptr(0, 1), tile_ptr(0, 3), tile_ptr(0, 5), tid);
   __syncthreads();
 
   int cur = 0;
@@ -144,17 +155,20 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int j = 0; j < 2; j++) b[j] = load_frag<B_KM>(tb, wn * 64 + j * 32, ks, lane);
       if constexpr (SPLIT) {
-        bf16x8 al[2], bl[2];
+        bf16x8 a1[2], b1[2], a2[2], b2[2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) al[i] = load_frag<A_KM>(tile_ptr(cur, 2), wm * 64 + i * 32, ks, lane);
+        for (int i = 0; i < 2; i++) { a1[i] = load_frag<A_KM>(tile_ptr(cur, 2), wm * 64 + i * 32, ks, lane); a2[i] = load_frag<A_KM>(tile_ptr(cur, 4), wm * 64 + i * 32, ks, lane); }
 #pragma unroll
-        for (int j = 0; j < 2; j++) bl[j] = load_frag<B_KM>(tile_ptr(cur, 3), wn * 64 + j * 32, ks, lane);
+        for (int j = 0; j < 2; j++) { b1[j] = load_frag<B_KM>(tile_ptr(cur, 3), wn * 64 + j * 32, ks, lane); b2[j] = load_frag<B_KM>(tile_ptr(cur, 5), wn * 64 + j * 32, ks, lane); }
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 2; j++) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], b[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b2[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
           }
       } else {
@@ -167,8 +181,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     if (more) {
       if constexpr (NSTAGE == 1) __syncthreads();
       const int nxt = NSTAGE == 1 ? 0 : cur ^ 1;
-      store_tile<TA, A_KM, SPLIT>(sa, tile_ptr(nxt, 0), tile_ptr(nxt, 2), tid);
-      store_tile<TB, B_KM, SPLIT>(sb, tile_ptr(nxt, 1), tile_ptr(nxt, 3), tid);
+      store_tile<TA, A_KM, SPLIT>(sa, tile_ptr(nxt, 0), tile_ptr(nxt, 2), tile_ptr(nxt, 4), tid);
+      store_tile<TB, B_KM, SPLIT>(sb, tile_ptr(nxt, 1), tile_ptr(nxt, 3), tile_ptr(nxt, 5), tid);
       __syncthreads();
       cur = nxt;
     }
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 
 template <typename TA, typename TB, bool A_KM, bool B_KM, bool SPLIT, typename TC, typename TAUX>
 int launch(const GemmParams& p, hipStream_t s) {
-  constexpr int smem = (SPLIT ? 4 : 4) * TILE_BYTES;  // 2 stages x 2 tiles, or 1 stage x 4 tiles
+  constexpr int smem = (SPLIT ? 6 : 4) * TILE_BYTES;  // 2 stages x 2 tiles, or 1 stage x 6 tiles
   auto k = gemm_kernel<TA, TB, A_KM, B_KM, SPLIT, TC, TAUX>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {

@@ -1,0 +1,234 @@
+"""Flow-matching trainer: mirror of the reference's src/model_trainer.py for the hot path.
+
+Kept from the reference (file:line into src/model_trainer.py): constructor kwargs (117-147), AdamW
+(lr, eps 1e-8, wd 0.01, betas (0.9, 0.999); 260), constant-with-warmup / cosine schedule (25-41, 263),
+GradScaler state (266-269), CPU EMA copy updated every ema_update_freq steps (256, 537-541), the step
+(378-503): t ~ sigmoid(N(0,1)); null masks with p = (pooled, gemma, bert); x_t = (1-t) x0 + t eps;
+loss = mean((v - (eps - x0))^2) / accumulation_steps; scale -> backward -> unscale -> clip_grad_norm_(1.0)
+-> step -> scheduler.step(step) -> scaler.update -> zero_grad; six-file checkpoints through
+diff_model.saveModel (545-548).
+
+MI355X-native differences: one process per GPU, every rank is a model rank (no loader GPUs: batches come
+from `data_source`, synthetic by default); gradient averaging is sd3_amd.reducer.GradReducer (bucketed
+RCCL all-reduce on a side HIP stream, fired block by block from the backward schedule, skipped on
+non-final accumulation micro-steps) instead of DistributedDataParallel; no wandb (stdout / JSONL log).
+The loss, AdamW and the scheduler stay in PyTorch-ROCm as BASELINE.json's north_star prescribes.
+"""
+import copy
+import json
+import math
+import os
+import time
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .helpers.multi_gpu_helpers import is_main_process
+from .helpers.TimeSampler import TimeSampler
+from .reducer import GradReducer, broadcast_parameters
+
+
+def get_scheduler(optimizer, num_warmup_steps, num_training_steps, use_lr_scheduler):
+    """HF get_cosine_schedule_with_warmup (num_cycles 0.5) / get_constant_schedule_with_warmup lambdas."""
+    if use_lr_scheduler:
+        def lr_lambda(step):
+            if step < num_warmup_steps:
+                return float(step) / float(max(1, num_warmup_steps))
+            progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
+    else:
+        def lr_lambda(step):
+            if step < num_warmup_steps:
+                return float(step) / float(max(1.0, num_warmup_steps))
+            return 1.0
+    return torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda)
+
+
+def init_distributed():
+    """env:// rendezvous, backend nccl (= RCCL on ROCm) with a gloo fallback (model_trainer.py:46-79)."""
+    if dist.is_initialized():
+        return
+    if "RANK" not in os.environ:
+        return
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = "nccl" if torch.cuda.is_available() else "gloo"
+    dist.init_process_group(backend, init_method="env://", world_size=int(os.environ["WORLD_SIZE"]), rank=int(os.environ["RANK"]))
+
+
+class SyntheticData:
+    """Synthetic (x0, text, pooled) batches shaped like the loader-GPU wire format (model_trainer.py:353-355):
+    bf16 latents (B,16,res/8,res/8), bf16 text (B,154,2304) with Gemma-like large variance on tokens 0..76 and
+    the ModernBERT zero padding on features 1024.. of tokens 77..153, bf16 pooled (B,class_dim)."""
+
+    def __init__(self, batch, inCh, class_dim, latent_hw, device, seed=1234, resample=True):
+        self.g = torch.Generator(device=device).manual_seed(seed)
+        self.shape = (batch, inCh, latent_hw[0], latent_hw[1])
+        self.batch, self.class_dim, self.device, self.resample = batch, class_dim, device, resample
+        self._cache = None
+
+    def __call__(self):
+        if self._cache is not None and not self.resample:
+            return self._cache
+        x0 = torch.randn(self.shape, generator=self.g, device=self.device).to(torch.bfloat16)
+        c = torch.randn((self.batch, 154, 2304), generator=self.g, device=self.device)
+        c[:, :77] *= 30.0
+        c[:, 77:, 1024:] = 0
+        cp = torch.randn((self.batch, self.class_dim), generator=self.g, device=self.device).to(torch.bfloat16)
+        self._cache = (x0, c.to(torch.bfloat16), cp)
+        return self._cache
+
+
+class model_trainer:
+    def __init__(self, diff_model, batchSize, accumulation_steps, totalSteps, lr, ema_update_freq, ema_decay, warmup_steps, use_lr_scheduler,
+                 device, saveDir, numSaveSteps, null_prob_pooled=0.1, null_prob_gemma=0.1, null_prob_bert=0.1, text_loss_weight=0.0,
+                 load_ema_file=None, optimFile=None, schedulerFile=None, scalerFile=None, use_amp=True, wandb_name=None,
+                 wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
+                 bucket_indices_path=None, data_parquet_folder=None, max_res=256,
+                 data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None):
+        self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
+        self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
+        self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
+        self.null_prob_pooled, self.null_prob_gemma, self.null_prob_bert = null_prob_pooled, null_prob_gemma, null_prob_bert
+        self.use_amp, self.max_res, self.log_file = use_amp, max_res, log_file
+        self.device_rng = device_rng
+        if text_loss_weight != 0.0:
+            raise RuntimeError("text_loss is out of scope on the HIP path (text_loss_weight must be 0)")
+        if loader_to_model_gpu not in (None, {}):
+            raise RuntimeError("loader GPUs are not used: every rank is a model rank; pass a data_source instead")
+
+        init_distributed()
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.subgroup = None
+        self.model = diff_model
+        self.device = self.model.device
+        self.dev = self.model.dev
+        broadcast_parameters(self.model)
+        self.reducer = GradReducer(self.subgroup)
+        if self.reducer.enabled:
+            if hasattr(self.model, "grad_reducer"):
+                self.model.grad_reducer = self.reducer           # overlapped: fired from the backward schedule
+            else:
+                self.reducer.attach_hooks(self.model.parameters())
+
+        self.ema_model_cpu = None
+        if use_ema:
+            red, self.model.grad_reducer = getattr(self.model, "grad_reducer", None), None
+            self.ema_model_cpu = copy.deepcopy(self.model).cpu()
+            self.ema_model_cpu.eval()
+            if hasattr(self.model, "grad_reducer"):
+                self.model.grad_reducer = red
+
+        fused = bool(fused_optimizer and self.device.type == "cuda")
+        self.optim = torch.optim.AdamW(self.model.parameters(), lr=lr, eps=1e-8, weight_decay=0.01, betas=(0.9, 0.999), fused=fused)
+        self.scheduler = get_scheduler(self.optim, num_warmup_steps=warmup_steps, num_training_steps=totalSteps, use_lr_scheduler=use_lr_scheduler)
+        self.grad_scaler = torch.amp.GradScaler("cuda", enabled=self.device.type == "cuda") if self.use_amp else None
+
+        if load_ema_file and self.ema_model_cpu is not None:
+            self.ema_model_cpu.load_state_dict(torch.load(load_ema_file, map_location="cpu", weights_only=False))
+        if optimFile and not reset_optim:
+            self.optim.load_state_dict(torch.load(optimFile, map_location=self.device, weights_only=False))
+        if schedulerFile:
+            self.scheduler.load_state_dict(torch.load(schedulerFile, map_location=self.device, weights_only=False))
+        if scalerFile and self.grad_scaler is not None:
+            self.grad_scaler.load_state_dict(torch.load(scalerFile, map_location=self.device, weights_only=False))
+
+        self.wandb_id = None if reset_wandb else self.model.wandb_id
+        self.start_step = self.model.start_step * self.accumulation_steps
+        self.time_sampler = TimeSampler(weighted=True)
+        self.data_source = data_source or SyntheticData(batchSize, self.model.inCh, self.model.class_dim, (max_res // 8, max_res // 8), self.device,
+                                                        seed=1234 + self.rank)
+        self._gen = torch.Generator(device=self.device).manual_seed(4321 + self.rank) if device_rng else None
+        self.last_loss = None
+        if is_main_process():
+            total_params = sum(p.numel() for p in self.model.parameters()) / 1e6
+            print(f"Number of parameters in the model: {total_params:.2f}M")
+
+    # ------------------------------------------------------------------------------------------
+    def _sample_conditioning(self, n):
+        """t and the three null masks (model_trainer.py:378-387).  The reference draws them from the CPU
+        default generator and moves them; device_rng=True draws on the GPU (no host round trip)."""
+        if self.device_rng:
+            t = self.time_sampler(n, generator=self._gen, device=self.device)
+            r = torch.rand((3, n), generator=self._gen, device=self.device)
+            return t, r[0] < self.null_prob_pooled, r[1] < self.null_prob_gemma, r[2] < self.null_prob_bert
+        t = self.time_sampler(n)
+        pp, pg, pb = torch.rand(n), torch.rand(n), torch.rand(n)
+        mk = lambda p, thr: torch.where(p < thr, 1, 0).to(torch.bool).to(self.device)
+        return t, mk(pp, self.null_prob_pooled), mk(pg, self.null_prob_gemma), mk(pb, self.null_prob_bert)
+
+    def micro_step(self, final: bool):
+        """One forward/backward micro-step; returns the (already /accumulation_steps) loss tensor."""
+        with torch.no_grad():
+            batch_x_0, batch_txt, batch_txt_pooled = self.data_source()
+            t_vals, n_pooled, n_gemma, n_bert = self._sample_conditioning(batch_x_0.shape[0])
+            batch_x_t, epsilon_t = self.model.noise_batch(batch_x_0, t_vals)
+        self.reducer.skip = not final
+        v_pred = self.model(batch_x_t.detach(), t_vals, batch_txt, batch_txt_pooled, n_pooled, n_gemma, n_bert)
+        labels = epsilon_t - batch_x_0.to(epsilon_t.device)
+        loss = nn.MSELoss(reduction="none")(v_pred, labels.detach().to(v_pred.dtype)).flatten(1, -1).mean()
+        loss = loss / self.accumulation_steps
+        if self.grad_scaler is not None:
+            self.grad_scaler.scale(loss).backward()
+        else:
+            loss.backward()
+        if final:
+            self.reducer.finish()
+        return loss.detach()
+
+    def optimizer_step(self, step):
+        if self.grad_scaler is not None:
+            self.grad_scaler.unscale_(self.optim)
+        if self.use_amp:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+        if self.grad_scaler is not None:
+            self.grad_scaler.step(self.optim)
+        else:
+            self.optim.step()
+        self.scheduler.step(step)
+        if self.grad_scaler is not None:
+            self.grad_scaler.update()
+        self.optim.zero_grad()
+
+    def train_step(self, step):
+        """One optimizer step = accumulation_steps micro-steps + clip + AdamW."""
+        loss = None
+        for k in range(self.accumulation_steps):
+            l = self.micro_step(final=(k == self.accumulation_steps - 1))
+            loss = l if loss is None else loss + l
+        self.optimizer_step(step)
+        self.last_loss = loss
+        return loss
+
+    def update_ema(self):
+        with torch.no_grad():
+            for ema_param, param in zip(self.ema_model_cpu.parameters(), self.model.parameters()):
+                if param.requires_grad:
+                    ema_param.data.mul_(self.ema_decay).add_(param.cpu().data, alpha=(1.0 - self.ema_decay))
+
+    def train(self):
+        if dist.is_initialized():
+            dist.barrier()
+        self.model.train()
+        batch_loss, t0 = 0.0, time.time()
+        opt_steps = self.start_step // self.accumulation_steps
+        for step in range(opt_steps, self.totalSteps):
+            loss = self.train_step(step + 1)
+            n = step + 1
+            batch_loss += float(loss) if n % self.log_steps == 0 else 0.0
+            if n % self.log_steps == 0 and is_main_process():
+                rec = {"step": n, "loss": float(loss), "lr": self.optim.param_groups[0]["lr"],
+                       "images_per_sec": self.world * self.batchSize * self.accumulation_steps * self.log_steps / (time.time() - t0)}
+                print(json.dumps(rec), flush=True)
+                if self.log_file:
+                    with open(self.log_file, "a") as f:
+                        f.write(json.dumps(rec) + "\n")
+                t0 = time.time()
+            if self.ema_model_cpu is not None and n % self.ema_update_freq == 0:
+                self.update_ema()
+            if n % self.numSaveSteps == 0 and is_main_process():
+                self.model.wandb_id = self.wandb_id
+                self.model.saveModel(saveDir=self.saveDir, EMA_state_dict=self.ema_model_cpu.state_dict() if self.ema_model_cpu is not None else None,
+                                     optimizer=self.optim, scheduler=self.scheduler, grad_scalar=self.grad_scaler, step=n)
+                print("Saving model")

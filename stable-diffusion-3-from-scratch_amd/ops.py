@@ -12,6 +12,10 @@ from ._lib import ACT_NONE, ACT_SILU, BF16, F32, PREC_BF16, PREC_SPLIT, GemmArgs
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16}
 
+# bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
+# (entries: (kernel variant, algorithmic FLOPs, start event, end event)); None = no instrumentation.
+PROFILE = None
+
 
 def _dt(t: torch.Tensor) -> int:
     try:
@@ -75,6 +79,14 @@ def gemm(A, B, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, out=No
         a.aux, a.aux_dtype, a.ld_aux = _p(aux), _dt(aux), aux.stride(0)
     a.accumulate = int(accumulate)
     a.precision = precision
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        check(_lib.lib().mmdit_gemm(ctypes.byref(a), _s()), "mmdit_gemm")
+        e1.record()
+        layout = "nt" if not (a_kmajor or b_kmajor) else ("dgrad" if not a_kmajor else "wgrad")
+        PROFILE.append((f"gemm_{layout}_{'bf16' if precision == PREC_BF16 else 'split'}_c{_dt(out)}", 2.0 * M * N * K, e0, e1))
+        return out
     check(_lib.lib().mmdit_gemm(ctypes.byref(a), _s()), "mmdit_gemm")
     return out
 
