@@ -72,6 +72,10 @@ typedef struct {
   int precision;
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
+/* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,
+ * precision, act, accumulate, aux dtype) share one grid, e.g. the image and the text stream of a block
+ * (Attention.py:130-135 issues them as separate Linears) or all weight-gradient GEMMs of a block. */
+int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream);
 
 /* dtype conversion of n elements (bf16 shadow copies of the fp32 master weights; the
  * reference gets these from torch.autocast, model_trainer.py:416). n%8==0 not required. */

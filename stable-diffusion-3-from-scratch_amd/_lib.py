@@ -39,6 +39,7 @@ _SIGNATURES = {
     "mmdit_abi_version": ([], _i),
     "mmdit_build_arch": ([], ctypes.c_char_p),
     "mmdit_gemm": ([ctypes.POINTER(GemmArgs), _vp], _i),
+    "mmdit_gemm_grouped": ([ctypes.POINTER(GemmArgs), _i, _vp], _i),
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),

@@ -1,10 +1,16 @@
-// MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,K] * B[N,K]^T), fp32 accumulate.
+// MFMA GEMM for gfx950:  C[M,N] = epilogue(A[M,K] * B[N,K]^T), fp32 accumulate, grouped launches.
 //
-// v1 structure: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave a 64x64
-// sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  Operands are staged
-// global -> registers -> LDS (double buffered, one barrier per K-tile).
-//   row-major operand tile  : LDS [128 rows][64 k] bf16, pitch 144 B (conflict-free ds_read_b128)
-//   k-major operand tile    : LDS [64 k][128 rows] bf16, pitch 320 B, fragments via ds_read_b64_tr_b16
+// Structure: 128x128x64 block tile, 256 threads = 4 waves (2x2), each wave a 64x64 sub-tile =
+// 2x2 v_mfma_f32_32x32x16_bf16 accumulators.  Operands are staged global -> registers -> LDS
+// (double buffered, one barrier per K-tile).
+//   row-major operand tile : LDS [128 rows][64 k] bf16, pitch 144 B (conflict-free ds_read_b128)
+//   k-major operand tile   : LDS [64 k][128 rows] bf16, pitch 320 B, fragments via ds_read_b64_tr_b16
+// The MFMA is issued as D^T = B_frag * A_frag so that each lane ends up owning ONE output row and
+// groups of 4 consecutive output columns: the epilogue (bias, SiLU, gate*acc+residual, aux copy,
+// accumulate) then runs on 8/16-byte vectors instead of scalars.
+// Grouped launch: up to MAXG independent problems of the same variant share one grid (image + text
+// stream of a block, or all weight-gradient GEMMs of a block) so that small problems still fill the
+// 256 CUs; the linear tile id is remapped so that each XCD (private L2) gets a contiguous tile range.
 // SPLIT precision (parity mode): fp32 operands are split exactly into three bf16 pieces
 // a = a0 + a1 + a2 (8+8+8 significand bits) while staging and the product is formed from the six
 // MFMA passes with weight >= 2^-16 (a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0): fp32-exact products,
@@ -19,30 +25,34 @@ constexpr int RM_PITCH = 144;            // bytes per row of a row-major tile (6
 constexpr int KM_PITCH = 320;            // bytes per k-row of a k-major tile (128 bf16 + 64 B pad)
 constexpr int TILE_BYTES = 20480;        // max(128*144, 64*320)
 constexpr int CHUNKS = 4;                // 16-byte (8 x bf16) chunks per thread per operand tile
+constexpr int MAXG = 12;                 // problems per grouped launch
+constexpr int NXCD = 8;
 
-struct GemmParams {
+struct Problem {
   const void* A; const void* B; void* C; void* aux;
   const float* bias; const float* gate; const float* residual;
   int64_t lda, ldb, ldc, ld_gate, ld_res, ld_aux;
   int M, N, K;
-  int rows_per_batch, act, accumulate;
+  int rows_per_batch, tiles_n, tile_start;
+};
+struct GroupParams {
+  Problem p[MAXG];
+  int count, total_tiles, act, accumulate;
 };
 
 // ---- staging registers -----------------------------------------------------------------------
-template <typename T, bool SPLIT> struct Stage;
-template <> struct Stage<bf16_t, false> { u32x4 v[CHUNKS]; };
-template <> struct Stage<float, false> { f32x4 v[CHUNKS][2]; };
-template <> struct Stage<float, true> { f32x4 v[CHUNKS][2]; };
+template <typename T> struct Stage;
+template <> struct Stage<bf16_t> { u32x4 v[CHUNKS]; };
+template <> struct Stage<float> { f32x4 v[CHUNKS][2]; };
 
 template <bool KM>
 __device__ __forceinline__ void chunk_coords(int c, int& r, int& kc) {
-  // returns tile row index r (0..127) and k index kc (0..63, multiple of 8 for row-major; any for k-major)
   if (!KM) { r = c >> 3; kc = (c & 7) * 8; }        // 8 chunks of 8 k per row
   else { kc = c >> 4; r = (c & 15) * 8; }           // 16 chunks of 8 rows per k-row
 }
 
-template <typename T, bool KM, bool SPLIT>
-__device__ __forceinline__ void load_tile(Stage<T, SPLIT>& st, const T* base, int64_t ld, int row0, int k0, int rows, int K, int tid) {
+template <typename T, bool KM>
+__device__ __forceinline__ void load_tile(Stage<T>& st, const T* base, int64_t ld, int row0, int k0, int rows, int K, int tid) {
 #pragma unroll
   for (int i = 0; i < CHUNKS; i++) {
     int c = tid + 256 * i, r, kc;
@@ -59,7 +69,7 @@ __device__ __forceinline__ void load_tile(Stage<T, SPLIT>& st, const T* base, in
 }
 
 template <typename T, bool KM, bool SPLIT>
-__device__ __forceinline__ void store_tile(const Stage<T, SPLIT>& st, char* hi, char* mid, char* lo, int tid) {
+__device__ __forceinline__ void store_tile(const Stage<T>& st, char* hi, char* mid, char* lo, int tid) {
 #pragma unroll
   for (int i = 0; i < CHUNKS; i++) {
     int c = tid + 256 * i, r, kc;
@@ -107,16 +117,30 @@ __device__ __forceinline__ bf16x8 load_frag(const char* tile, int r0, int ks, in
 }
 
 template <typename TA, typename TB, bool A_KM, bool B_KM, bool SPLIT, typename TC, typename TAUX>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_kernel(GroupParams gp) {
   constexpr int NT = SPLIT ? 6 : 2;                  // tiles per stage: A0, B0, (A1, B1, A2, B2)
   constexpr int NSTAGE = SPLIT ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  // ---- tile id -> (problem, m-tile, n-tile); contiguous tile ranges per XCD (block b runs on XCD b % 8)
+  int t = blockIdx.x;
+  {
+    const int T = gp.total_tiles, q = T / NXCD, r = T % NXCD, xcd = t % NXCD, j = t / NXCD;
+    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  int pi = 0;
+#pragma unroll 1
+  for (int i = 1; i < gp.count; i++) pi = (t >= gp.p[i].tile_start) ? i : pi;
+  const Problem& p = gp.p[pi];
+  t -= p.tile_start;
+  const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const TA* A = (const TA*)p.A;
   const TB* B = (const TB*)p.B;
+  const int M = p.M, N = p.N, K = p.K;
+  const int64_t lda = p.lda, ldb = p.ldb;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -126,14 +150,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
 
-  Stage<TA, SPLIT> sa;
-  Stage<TB, SPLIT> sb;
-  const int nk = (p.K + BK - 1) / BK;
-
+  Stage<TA> sa;
+  Stage<TB> sb;
+  const int nk = (K + BK - 1) / BK;
   auto tile_ptr = [&](int stage, int which) { return smem + (stage * NT + which) * TILE_BYTES; };
 
-  load_tile<TA, A_KM, SPLIT>(sa, A, p.lda, m0, 0, p.M, p.K, tid);
-  load_tile<TB, B_KM, SPLIT>(sb, B, p.ldb, n0, 0, p.N, p.K, tid);
+  load_tile<TA, A_KM>(sa, A, lda, m0, 0, M, K, tid);
+  load_tile<TB, B_KM>(sb, B, ldb, n0, 0, N, K, tid);
   store_tile<TA, A_KM, SPLIT>(sa, tile_ptr(0, 0), tile_ptr(0, 2), tile_ptr(0, 4), tid);
   store_tile<TB, B_KM, SPLIT>(sb, tile_ptr(0, 1), tile_ptr(0, 3), tile_ptr(0, 5), tid);
   __syncthreads();
@@ -142,8 +165,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
   for (int kt = 0; kt < nk; kt++) {
     const bool more = kt + 1 < nk;
     if (more) {
-      load_tile<TA, A_KM, SPLIT>(sa, A, p.lda, m0, (kt + 1) * BK, p.M, p.K, tid);
-      load_tile<TB, B_KM, SPLIT>(sb, B, p.ldb, n0, (kt + 1) * BK, p.N, p.K, tid);
+      load_tile<TA, A_KM>(sa, A, lda, m0, (kt + 1) * BK, M, K, tid);
+      load_tile<TB, B_KM>(sb, B, ldb, n0, (kt + 1) * BK, N, K, tid);
     }
     const char* ta = tile_ptr(cur, 0);
     const char* tb = tile_ptr(cur, 1);
@@ -154,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
       for (int i = 0; i < 2; i++) a[i] = load_frag<A_KM>(ta, wm * 64 + i * 32, ks, lane);
 #pragma unroll
       for (int j = 0; j < 2; j++) b[j] = load_frag<B_KM>(tb, wn * 64 + j * 32, ks, lane);
+      // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, columns (lanes) = m
       if constexpr (SPLIT) {
         bf16x8 a1[2], b1[2], a2[2], b2[2];
 #pragma unroll
@@ -164,18 +188,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
         for (int i = 0; i < 2; i++)
 #pragma unroll
           for (int j = 0; j < 2; j++) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i], b[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b1[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b2[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b1[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a2[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2[j], a[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a1[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
           }
       } else {
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
       }
     }
     if (more) {
@@ -188,37 +212,63 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
+  // ---- epilogue: lane owns row m, 4 consecutive columns per register group -------------------------
   TC* C = (TC*)p.C;
   TAUX* AUX = (TAUX*)p.aux;
+  const float* bias = p.bias;
+  const float* gate = p.gate;
+  const float* res = p.residual;
 #pragma unroll
   for (int i = 0; i < 2; i++) {
+    const int row = m0 + wm * 64 + i * 32 + (lane & 31);
+    if (row >= M) continue;
+    const float* grow = gate ? gate + (int64_t)(row / p.rows_per_batch) * p.ld_gate : nullptr;
 #pragma unroll
     for (int j = 0; j < 2; j++) {
-      const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-      if (col >= p.N) continue;
-      const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= p.M) continue;
-        float v = acc[i][j][r] + bv;
-        if (AUX) io<TAUX>::st(AUX + (int64_t)row * p.ld_aux + col, v);
-        if (p.act == MMDIT_ACT_SILU) v = silu_f(v);
-        if (p.residual) {
-          float g = p.gate ? p.gate[(int64_t)(row / p.rows_per_batch) * p.ld_gate + col] : 1.f;
-          v = p.residual[(int64_t)row * p.ld_res + col] + g * v;
+      for (int g = 0; g < 4; g++) {
+        const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (col >= N) continue;
+        float v[4] = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+        if (bias) {
+          float b4[4];
+          ld4(bias + col, b4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b4[e];
+        }
+        if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
+        if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        if (res) {
+          float r4[4];
+          ld4(res + (int64_t)row * p.ld_res + col, r4);
+          if (grow) {
+            float g4[4];
+            ld4(grow + col, g4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = r4[e] + g4[e] * v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += r4[e];
+          }
         }
         TC* cp = C + (int64_t)row * p.ldc + col;
-        if (p.accumulate) v += io<TC>::ld(cp);
-        io<TC>::st(cp, v);
+        if (gp.accumulate) {
+          float c4[4];
+          ld4(cp, c4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += c4[e];
+        }
+        st4(cp, v);
       }
     }
   }
 }
 
 template <typename TA, typename TB, bool A_KM, bool B_KM, bool SPLIT, typename TC, typename TAUX>
-int launch(const GemmParams& p, hipStream_t s) {
+int launch(const GroupParams& gp, hipStream_t s) {
   constexpr int smem = (SPLIT ? 6 : 4) * TILE_BYTES;  // 2 stages x 2 tiles, or 1 stage x 6 tiles
   auto k = gemm_kernel<TA, TB, A_KM, B_KM, SPLIT, TC, TAUX>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
@@ -227,13 +277,12 @@ int launch(const GemmParams& p, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
-  hipLaunchKernelGGL(k, grid, dim3(256), smem, s, p);
+  hipLaunchKernelGGL(k, dim3(gp.total_tiles), dim3(256), smem, s, gp);
   return mmdit_launch_status();
 }
 
 template <typename TA, typename TB, bool SPLIT, typename TC, typename TAUX>
-int dispatch_layout(const mmdit_gemm_args* a, const GemmParams& p, hipStream_t s) {
+int dispatch_layout(const mmdit_gemm_args* a, const GroupParams& p, hipStream_t s) {
   if (!a->a_kmajor && !a->b_kmajor) return launch<TA, TB, false, false, SPLIT, TC, TAUX>(p, s);
   if (!a->a_kmajor && a->b_kmajor) return launch<TA, TB, false, true, SPLIT, TC, TAUX>(p, s);
   if (a->a_kmajor && a->b_kmajor) return launch<TA, TB, true, true, SPLIT, TC, TAUX>(p, s);
@@ -241,8 +290,7 @@ int dispatch_layout(const mmdit_gemm_args* a, const GemmParams& p, hipStream_t s
 }
 
 template <typename TA, typename TB, bool SPLIT>
-int dispatch_out(const mmdit_gemm_args* a, const GemmParams& p, hipStream_t s) {
-  const int aux_dt = a->aux ? a->aux_dtype : a->c_dtype;
+int dispatch_out(const mmdit_gemm_args* a, int aux_dt, const GroupParams& p, hipStream_t s) {
   if (a->c_dtype == MMDIT_F32 && aux_dt == MMDIT_F32) return dispatch_layout<TA, TB, SPLIT, float, float>(a, p, s);
   if (a->c_dtype == MMDIT_F32 && aux_dt == MMDIT_BF16) return dispatch_layout<TA, TB, SPLIT, float, bf16_t>(a, p, s);
   if (a->c_dtype == MMDIT_BF16 && aux_dt == MMDIT_BF16) return dispatch_layout<TA, TB, SPLIT, bf16_t, bf16_t>(a, p, s);
@@ -252,27 +300,57 @@ int dispatch_out(const mmdit_gemm_args* a, const GemmParams& p, hipStream_t s) {
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
-}  // namespace
-
-extern "C" int mmdit_gemm(const mmdit_gemm_args* a, mmdit_stream_t stream) {
-  MMDIT_CHECK_ARG(a && a->A && a->B && a->C);
-  MMDIT_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0);
-  const int esa = a->a_dtype == MMDIT_F32 ? 4 : 2, esb = a->b_dtype == MMDIT_F32 ? 4 : 2;
-  MMDIT_CHECK_ARG(aligned16(a->A) && aligned16(a->B));
-  MMDIT_CHECK_ARG((a->lda * esa) % 16 == 0 && (a->ldb * esb) % 16 == 0);
+int check_problem(const mmdit_gemm_args* a) {
+  MMDIT_CHECK_ARG(a->A && a->B && a->C);
+  MMDIT_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 4 == 0);
+  const int esa = a->a_dtype == MMDIT_F32 ? 4 : 2, esb = a->b_dtype == MMDIT_F32 ? 4 : 2, esc = a->c_dtype == MMDIT_F32 ? 4 : 2;
+  MMDIT_CHECK_ARG(aligned16(a->A) && aligned16(a->B) && ((uintptr_t)a->C & (4 * esc - 1)) == 0);
+  MMDIT_CHECK_ARG((a->lda * esa) % 16 == 0 && (a->ldb * esb) % 16 == 0 && a->ldc % 4 == 0);
   if (a->a_kmajor) { MMDIT_CHECK_ARG(a->M % 8 == 0 && a->lda >= a->M); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->lda >= a->K); }
   if (a->b_kmajor) { MMDIT_CHECK_ARG(a->N % 8 == 0 && a->ldb >= a->N); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->ldb >= a->K); }
   MMDIT_CHECK_ARG(a->ldc >= a->N);
-  if (a->gate) MMDIT_CHECK_ARG(a->residual && a->rows_per_batch > 0);
+  if (a->bias) MMDIT_CHECK_ARG(aligned16(a->bias));
+  if (a->gate) MMDIT_CHECK_ARG(a->residual && a->rows_per_batch > 0 && aligned16(a->gate) && a->ld_gate % 4 == 0);
+  if (a->residual) MMDIT_CHECK_ARG(aligned16(a->residual) && a->ld_res % 4 == 0);
+  if (a->aux) MMDIT_CHECK_ARG(a->ld_aux % 4 == 0 && ((uintptr_t)a->aux & 7) == 0);
   if (a->accumulate) MMDIT_CHECK_ARG(a->c_dtype == MMDIT_F32);
-  GemmParams p;
-  p.A = a->A; p.B = a->B; p.C = a->C; p.aux = a->aux;
-  p.bias = a->bias; p.gate = a->gate; p.residual = a->residual;
-  p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ld_gate = a->ld_gate; p.ld_res = a->ld_res; p.ld_aux = a->ld_aux;
-  p.M = a->M; p.N = a->N; p.K = a->K;
-  p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1; p.act = a->act; p.accumulate = a->accumulate;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
+  const mmdit_gemm_args* a0 = &args[0];
+  GroupParams gp;
+  int aux_dt = -1, tiles = 0;
+  for (int i = 0; i < count; i++) {
+    const mmdit_gemm_args* a = &args[i];
+    int rc = check_problem(a);
+    if (rc) return rc;
+    // one kernel variant per launch: dtypes, layouts, precision, activation and accumulate must agree
+    MMDIT_CHECK_ARG(a->a_dtype == a0->a_dtype && a->b_dtype == a0->b_dtype && a->c_dtype == a0->c_dtype && a->a_kmajor == a0->a_kmajor &&
+                    a->b_kmajor == a0->b_kmajor && a->precision == a0->precision && a->act == a0->act && a->accumulate == a0->accumulate);
+    if (a->aux) { MMDIT_CHECK_ARG(aux_dt < 0 || aux_dt == a->aux_dtype); aux_dt = a->aux_dtype; }
+    Problem& p = gp.p[i];
+    p.A = a->A; p.B = a->B; p.C = a->C; p.aux = a->aux;
+    p.bias = a->bias; p.gate = a->gate; p.residual = a->residual;
+    p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ld_gate = a->ld_gate; p.ld_res = a->ld_res; p.ld_aux = a->ld_aux;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
+    p.tiles_n = (a->N + BN - 1) / BN;
+    p.tile_start = tiles;
+    tiles += p.tiles_n * ((a->M + BM - 1) / BM);
+  }
+  if (aux_dt < 0) aux_dt = a0->c_dtype;
+  gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate;
   hipStream_t s = (hipStream_t)stream;
-  if (a->precision == MMDIT_PREC_BF16 && a->a_dtype == MMDIT_BF16 && a->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a, p, s);
-  if (a->precision == MMDIT_PREC_SPLIT && a->a_dtype == MMDIT_F32 && a->b_dtype == MMDIT_F32) return dispatch_out<float, float, true>(a, p, s);
+  if (a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a0, aux_dt, gp, s);
+  if (a0->precision == MMDIT_PREC_SPLIT && a0->a_dtype == MMDIT_F32 && a0->b_dtype == MMDIT_F32) return dispatch_out<float, float, true>(a0, aux_dt, gp, s);
   return MMDIT_ERR_DTYPE;
+}
+
+extern "C" int mmdit_gemm(const mmdit_gemm_args* a, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(a);
+  return mmdit_gemm_grouped(a, 1, stream);
 }

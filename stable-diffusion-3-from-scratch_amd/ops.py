@@ -47,28 +47,24 @@ def torch_dtype(code: int):
 
 
 # ---------------------------------------------------------------------------------------------
-def gemm(A, B, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-         gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16):
-    """C[M,N] = epilogue(A[M,K] B[N,K]^T).  A: (M,K) or k-major (K,M); B: (N,K) or k-major (K,N).
-    gate may be a strided 2-D view (rows = batch) with unit inner stride."""
+def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16):
     if a_kmajor:
-        K_, M_ = A.shape
+        K_, M = A.shape
     else:
-        M_, K_ = A.shape
+        M, K_ = A.shape
     if b_kmajor:
-        Kb, N_ = B.shape
+        Kb, N = B.shape
     else:
-        N_, Kb = B.shape
+        N, Kb = B.shape
     if K_ != Kb:
         raise RuntimeError(f"gemm: inner dimensions differ ({K_} vs {Kb})")
-    M, N, K = M or M_, N or N_, K or K_
     if out is None:
         out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
-    a = GemmArgs()
     a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), A.stride(0)
     a.B, a.b_dtype, a.b_kmajor, a.ldb = _p(B), _dt(B), int(b_kmajor), B.stride(0)
     a.C, a.c_dtype, a.ldc = _p(out), _dt(out), out.stride(0)
-    a.M, a.N, a.K = M, N, K
+    a.M, a.N, a.K = M, N, K_
     a.bias = _p(bias)
     a.act = act
     if gate is not None:
@@ -79,16 +75,35 @@ def gemm(A, B, *, M=None, N=None, K=None, a_kmajor=False, b_kmajor=False, out=No
         a.aux, a.aux_dtype, a.ld_aux = _p(aux), _dt(aux), aux.stride(0)
     a.accumulate = int(accumulate)
     a.precision = precision
+    return out
+
+
+def _variant(a, out):
+    layout = "nt" if not (a.a_kmajor or a.b_kmajor) else ("dgrad" if not a.a_kmajor else "wgrad")
+    return f"gemm_{layout}_{'bf16' if a.precision == PREC_BF16 else 'split'}_c{_dt(out)}"
+
+
+def gemm_grouped(problems):
+    """problems: list of dicts of gemm() keyword arguments (plus 'A', 'B'), all of one kernel variant.
+    One launch; returns the list of outputs."""
+    n = len(problems)
+    arr = (GemmArgs * n)()
+    outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        check(_lib.lib().mmdit_gemm(ctypes.byref(a), _s()), "mmdit_gemm")
+        check(_lib.lib().mmdit_gemm_grouped(arr, n, _s()), "mmdit_gemm_grouped")
         e1.record()
-        layout = "nt" if not (a_kmajor or b_kmajor) else ("dgrad" if not a_kmajor else "wgrad")
-        PROFILE.append((f"gemm_{layout}_{'bf16' if precision == PREC_BF16 else 'split'}_c{_dt(out)}", 2.0 * M * N * K, e0, e1))
-        return out
-    check(_lib.lib().mmdit_gemm(ctypes.byref(a), _s()), "mmdit_gemm")
-    return out
+        PROFILE.append((_variant(arr[0], outs[0]), sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
+        return outs
+    check(_lib.lib().mmdit_gemm_grouped(arr, n, _s()), "mmdit_gemm_grouped")
+    return outs
+
+
+def gemm(A, B, **kw):
+    """C[M,N] = epilogue(A[M,K] B[N,K]^T).  A: (M,K) or k-major (K,M); B: (N,K) or k-major (K,N).
+    gate may be a strided 2-D view (rows = batch) with unit inner stride."""
+    return gemm_grouped([dict(A=A, B=B, **kw)])[0]
 
 
 def cast(src, dtype, out=None):
