@@ -120,6 +120,8 @@ def main():
 
     roofline = None
     if rank == 0 and not args.no_roofline:
+        from sd3_amd import engine
+        overlap, engine._WG_OVERLAP = engine._WG_OVERLAP, False   # serialise the side-stream wgrad launches: clean per-kernel durations
         ops.PROFILE = []
         for _ in range(3):
             step += 1
@@ -132,6 +134,7 @@ def main():
             s[1] += flops
             s[2] += e0.elapsed_time(e1) * 1e-3
         ops.PROFILE = None
+        engine._WG_OVERLAP = overlap
         tot_t = sum(s[2] for s in stats.values())
         tot_f = sum(s[1] for s in stats.values())
         dom = max(stats.items(), key=lambda kv: kv[1][2])

@@ -70,6 +70,9 @@ typedef struct {
   void* aux; int aux_dtype; int64_t ld_aux;
   int accumulate;
   int precision;
+  int split_k;    /* >1: K is split over split_k workgroups per tile which add atomically into a PRE-ZEROED fp32 C
+                     (skinny problems, e.g. the per-sample modulation GEMMs with M = batch); bf16 precision, K%64==0,
+                     no act/aux/gate/accumulate */
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 /* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,

@@ -31,6 +31,7 @@ class GemmArgs(ctypes.Structure):
         ("aux", _vp), ("aux_dtype", _i), ("ld_aux", _i64),
         ("accumulate", _i),
         ("precision", _i),
+        ("split_k", _i),
     ]
 
 

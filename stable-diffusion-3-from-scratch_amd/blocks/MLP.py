@@ -41,6 +41,7 @@ class _MLPFn(torch.autograd.Function):
         dbdown = torch.zeros(d2.shape[1], dtype=torch.float32, device=d2.device)
         ops.colsum(d2, dbdown)
         dx, g = engine.mlp_core_bwd(m, w, m.act(d2), xa, gu, h, d2.device)
+        engine.wgrad_join(d2.device)
         return None, dx.float().view(ctx.shp), g.Wup, g.bup, g.Wdown, dbdown
 
 

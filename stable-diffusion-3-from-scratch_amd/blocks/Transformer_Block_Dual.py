@@ -32,6 +32,7 @@ class _BlockFn(torch.autograd.Function):
         w = blk.weights(m)
         dX_, dC_, dy, g = engine.block_bwd(m, w, sv, dX.reshape(B * N, d).float().contiguous(),
                                            None if dC is None else dC.reshape(B * Mt, d).float().contiguous(), None, ctx.dims, ctx.rope)
+        engine.wgrad_join(dX.device)
         ctx.sv = None
         out = {}
         blk.scatter_grads(g, out)

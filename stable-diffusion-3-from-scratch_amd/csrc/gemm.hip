@@ -16,29 +16,18 @@
 // MFMA passes with weight >= 2^-16 (a0b0 + a0b1 + a1b0 + a0b2 + a1b1 + a2b0): fp32-exact products,
 // fp32 accumulation.  A 2-term split (1e-5 relative) is not enough: the bf16 rounding points of the
 // attention core amplify an upstream error d to ~sqrt(d * 2^-8).
-#include "common.h"
+#include "gemm_common.h"
+#include <stdlib.h>
+
+using namespace gemm;
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BN = 128;
 constexpr int RM_PITCH = 144;            // bytes per row of a row-major tile (64 bf16 + 16 B pad)
 constexpr int KM_PITCH = 320;            // bytes per k-row of a k-major tile (128 bf16 + 64 B pad)
 constexpr int TILE_BYTES = 20480;        // max(128*144, 64*320)
 constexpr int CHUNKS = 4;                // 16-byte (8 x bf16) chunks per thread per operand tile
-constexpr int MAXG = 12;                 // problems per grouped launch
-constexpr int NXCD = 8;
-
-struct Problem {
-  const void* A; const void* B; void* C; void* aux;
-  const float* bias; const float* gate; const float* residual;
-  int64_t lda, ldb, ldc, ld_gate, ld_res, ld_aux;
-  int M, N, K;
-  int rows_per_batch, tiles_n, tile_start;
-};
-struct GroupParams {
-  Problem p[MAXG];
-  int count, total_tiles, act, accumulate;
-};
 
 // ---- staging registers -----------------------------------------------------------------------
 template <typename T> struct Stage;
@@ -122,18 +111,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupParams gp) {
   constexpr int NSTAGE = SPLIT ? 1 : 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  // ---- tile id -> (problem, m-tile, n-tile); contiguous tile ranges per XCD (block b runs on XCD b % 8)
-  int t = blockIdx.x;
-  {
-    const int T = gp.total_tiles, q = T / NXCD, r = T % NXCD, xcd = t % NXCD, j = t / NXCD;
-    t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  }
-  int pi = 0;
-#pragma unroll 1
-  for (int i = 1; i < gp.count; i++) pi = (t >= gp.p[i].tile_start) ? i : pi;
-  const Problem& p = gp.p[pi];
-  t -= p.tile_start;
-  const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+  int tm, tn, sk;
+  const Problem& p = locate_tile(gp, tm, tn, sk);   // split_k is always 1 on this path
+  const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -212,59 +192,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupParams gp) {
     }
   }
 
-  // ---- epilogue: lane owns row m, 4 consecutive columns per register group -------------------------
-  TC* C = (TC*)p.C;
-  TAUX* AUX = (TAUX*)p.aux;
-  const float* bias = p.bias;
-  const float* gate = p.gate;
-  const float* res = p.residual;
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int row = m0 + wm * 64 + i * 32 + (lane & 31);
-    if (row >= M) continue;
-    const float* grow = gate ? gate + (int64_t)(row / p.rows_per_batch) * p.ld_gate : nullptr;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        const int col = n0 + wn * 64 + j * 32 + 8 * g + 4 * (lane >> 5);
-        if (col >= N) continue;
-        float v[4] = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
-        if (bias) {
-          float b4[4];
-          ld4(bias + col, b4);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += b4[e];
-        }
-        if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
-        if (gp.act == MMDIT_ACT_SILU) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
-        }
-        if (res) {
-          float r4[4];
-          ld4(res + (int64_t)row * p.ld_res + col, r4);
-          if (grow) {
-            float g4[4];
-            ld4(grow + col, g4);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = r4[e] + g4[e] * v[e];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += r4[e];
-          }
-        }
-        TC* cp = C + (int64_t)row * p.ldc + col;
-        if (gp.accumulate) {
-          float c4[4];
-          ld4(cp, c4);
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += c4[e];
-        }
-        st4(cp, v);
-      }
-    }
-  }
+  epilogue<TC, TAUX>(acc, p, gp, m0, n0, wm, wn, lane, sk);
 }
 
 template <typename TA, typename TB, bool A_KM, bool B_KM, bool SPLIT, typename TC, typename TAUX>
@@ -319,11 +247,32 @@ int check_problem(const mmdit_gemm_args* a) {
 
 }  // namespace
 
+// Tile-configuration heuristic of the LDS-DMA path.  Bigger tiles halve the L2->CU traffic per FLOP (a 128x128
+// tile needs ~64 B/clk/CU at full MFMA rate, about what the L2 can deliver) but need enough tiles to fill 256 CUs.
+static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k) {
+  static const char* force = getenv("MMDIT_GEMM_CFG");
+  if (force) return atoi(force);
+  long t256 = 0, t256x128 = 0;
+  for (int i = 0; i < count; i++) {
+    t256 += (long)((args[i].M + 255) / 256) * ((args[i].N + 255) / 256);
+    t256x128 += (long)((args[i].M + 255) / 256) * ((args[i].N + 127) / 128);
+  }
+  if (t256 * split_k >= 232) return CFG_256x256;
+  if (t256x128 * split_k >= 232) return CFG_256x128;
+  return CFG_128x128;
+}
+
 extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
   const mmdit_gemm_args* a0 = &args[0];
   GroupParams gp;
-  int aux_dt = -1, tiles = 0;
+  int aux_dt = -1;
+  // LDS-DMA fast path: bf16 operands, every K a multiple of the 64-wide K-tile (MMDIT_GEMM_NO_DMA=1 forces
+  // the register-staged kernel, for A/B measurements)
+  static const bool no_dma = getenv("MMDIT_GEMM_NO_DMA") != nullptr;
+  static const char* raster_env = getenv("MMDIT_GEMM_RASTER");
+  bool dma = !no_dma && a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16;
+  const int split_k = a0->split_k > 1 ? a0->split_k : 1;
   for (int i = 0; i < count; i++) {
     const mmdit_gemm_args* a = &args[i];
     int rc = check_problem(a);
@@ -332,19 +281,37 @@ extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_
     MMDIT_CHECK_ARG(a->a_dtype == a0->a_dtype && a->b_dtype == a0->b_dtype && a->c_dtype == a0->c_dtype && a->a_kmajor == a0->a_kmajor &&
                     a->b_kmajor == a0->b_kmajor && a->precision == a0->precision && a->act == a0->act && a->accumulate == a0->accumulate);
     if (a->aux) { MMDIT_CHECK_ARG(aux_dt < 0 || aux_dt == a->aux_dtype); aux_dt = a->aux_dtype; }
+    MMDIT_CHECK_ARG((a->split_k > 1 ? a->split_k : 1) == split_k);
+    if (a->K % BK != 0) dma = false;
+    if (a->a_kmajor && a->M < 8) dma = false;
+    if (a->b_kmajor && a->N < 8) dma = false;
+  }
+  int bm = BM, bn = BN, cfg = CFG_128x128;
+  if (dma) { cfg = pick_dma_cfg(args, count, split_k); dma_cfg_tile(cfg, bm, bn); }
+  int tiles = 0;
+  for (int i = 0; i < count; i++) {
+    const mmdit_gemm_args* a = &args[i];
     Problem& p = gp.p[i];
     p.A = a->A; p.B = a->B; p.C = a->C; p.aux = a->aux;
     p.bias = a->bias; p.gate = a->gate; p.residual = a->residual;
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ld_gate = a->ld_gate; p.ld_res = a->ld_res; p.ld_aux = a->ld_aux;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
-    p.tiles_n = (a->N + BN - 1) / BN;
+    p.tiles_n = (a->N + bn - 1) / bn;
+    p.tiles_m = (a->M + bm - 1) / bm;
     p.tile_start = tiles;
-    tiles += p.tiles_n * ((a->M + BM - 1) / BM);
+    tiles += p.tiles_n * p.tiles_m;
   }
   if (aux_dt < 0) aux_dt = a0->c_dtype;
-  gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate;
+  gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = split_k;
+  gp.raster = raster_env ? atoi(raster_env) : 8;   // n-tiles per rasterization group (see locate_tile)
+  if (split_k > 1) {
+    // split-K slices accumulate atomically into a pre-zeroed fp32 C: only on the DMA path, plain epilogue
+    MMDIT_CHECK_ARG(dma && a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE && !a0->accumulate && split_k <= 64);
+    for (int i = 0; i < count; i++) MMDIT_CHECK_ARG(!args[i].aux && !args[i].gate);
+  }
   hipStream_t s = (hipStream_t)stream;
+  if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a0, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_SPLIT && a0->a_dtype == MMDIT_F32 && a0->b_dtype == MMDIT_F32) return dispatch_out<float, float, true>(a0, aux_dt, gp, s);
   return MMDIT_ERR_DTYPE;

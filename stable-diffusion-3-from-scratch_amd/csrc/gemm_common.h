@@ -1,0 +1,121 @@
+// Shared declarations of the GEMM translation units (gemm.hip: register-staged general / parity kernel
+// and host dispatch; gemm_dma.hip: LDS-DMA fast kernels).
+#pragma once
+#include "common.h"
+
+namespace gemm {
+
+constexpr int BK = 64;
+constexpr int MAXG = 12;                 // problems per grouped launch
+constexpr int NXCD = 8;
+
+struct Problem {
+  const void* A; const void* B; void* C; void* aux;
+  const float* bias; const float* gate; const float* residual;
+  int64_t lda, ldb, ldc, ld_gate, ld_res, ld_aux;
+  int M, N, K;
+  int rows_per_batch, tiles_n, tiles_m, tile_start;
+};
+struct GroupParams {
+  Problem p[MAXG];
+  int count, total_tiles, act, accumulate, split_k, raster;
+};
+
+// block id -> (problem, m-tile, n-tile, split-K slice).
+//  * XCD chunking: block b is observed to run on XCD b % 8 (private 4 MB L2 each); every XCD gets a contiguous
+//    range of the tile sequence (used for L2 locality only, never for correctness).
+//  * Rasterization inside a problem: tiles are walked in column groups of gp.raster n-tiles, m fastest between
+//    groups' rows, so that one group of B panels (raster*BN rows of the weight) stays L2-resident while the
+//    A row panels stream past it once.
+__device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int& tm, int& tn, int& sk) {
+  int b = blockIdx.x;
+  sk = b % gp.split_k;
+  b /= gp.split_k;
+  const int T = gp.total_tiles, q = T / NXCD, r = T % NXCD, xcd = b % NXCD, j = b / NXCD;
+  int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  int pi = 0;
+#pragma unroll 1
+  for (int i = 1; i < gp.count; i++) pi = (t >= gp.p[i].tile_start) ? i : pi;
+  const Problem& p = gp.p[pi];
+  t -= p.tile_start;
+  const int gw = gp.raster, per_group = gw * p.tiles_m, grp = t / per_group, rem = t - grp * per_group;
+  const int w = min(gw, p.tiles_n - grp * gw);   // width of this (possibly last, narrower) column group
+  tm = rem / w;
+  tn = grp * gw + rem - tm * w;
+  return p;
+}
+
+// epilogue: lane owns row m, 4 consecutive columns per accumulator register group.
+// split-K slices (gp.split_k > 1) add their partial sums atomically into a pre-zeroed fp32 C;
+// bias / residual are contributed by slice 0 only.
+template <typename TC, typename TAUX, int MI = 2, int NJ = 2>
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, int sk) {
+  TC* C = (TC*)p.C;
+  TAUX* AUX = (TAUX*)p.aux;
+  const bool first = sk == 0;
+  const float* bias = first ? p.bias : nullptr;
+  const float* gate = p.gate;
+  const float* res = first ? p.residual : nullptr;
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    const int row = m0 + wm * (MI * 32) + i * 32 + (lane & 31);
+    if (row >= p.M) continue;
+    const float* grow = gate ? gate + (int64_t)(row / p.rows_per_batch) * p.ld_gate : nullptr;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const int col = n0 + wn * (NJ * 32) + j * 32 + 8 * g + 4 * (lane >> 5);
+        if (col >= p.N) continue;
+        float v[4] = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+        if (bias) {
+          float b4[4];
+          ld4(bias + col, b4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b4[e];
+        }
+        if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
+        if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        if (res) {
+          float r4[4];
+          ld4(res + (int64_t)row * p.ld_res + col, r4);
+          if (grow) {
+            float g4[4];
+            ld4(grow + col, g4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = r4[e] + g4[e] * v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += r4[e];
+          }
+        }
+        TC* cp = C + (int64_t)row * p.ldc + col;
+        if constexpr (sizeof(TC) == 4) {
+          if (gp.split_k > 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) atomicAdd((float*)cp + e, v[e]);
+            continue;
+          }
+        }
+        if (gp.accumulate) {
+          float c4[4];
+          ld4(cp, c4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += c4[e];
+        }
+        st4(cp, v);
+      }
+    }
+  }
+}
+
+
+// tile configurations of the LDS-DMA kernel (gemm_dma.hip)
+enum DmaCfg { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2 };
+inline void dma_cfg_tile(int cfg, int& bm, int& bn) { bm = cfg == CFG_128x128 ? 128 : 256; bn = cfg == CFG_256x256 ? 256 : 128; }
+int launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, const GroupParams& gp, hipStream_t s);
+
+}  // namespace gemm

@@ -76,13 +76,60 @@ def _dgrad(m, dY, W, out_dtype, **kw):
     return ops.gemm(dY, W, b_kmajor=True, out_dtype=out_dtype, precision=m.prec, **kw)
 
 
+# Weight gradients are off the critical path of the backward pass (only the optimizer consumes them), so the
+# deferred grouped wgrad launch of a block runs on a side HIP stream and fills the tail bubbles of the next
+# block's dgrad / row kernels on the main stream.  MMDIT_WGRAD_STREAM=0 disables it.
+import os as _os
+_WG_OVERLAP = _os.environ.get("MMDIT_WGRAD_STREAM", "1") != "0"
+_wg_streams = {}
+
+
+def wgrad_stream(device):
+    st = _wg_streams.get(device)
+    if st is None:
+        st = _wg_streams[device] = torch.cuda.Stream(device=device)
+    return st
+
+
+def wgrad_join(device):
+    """Make the current stream wait for every weight-gradient launch issued so far."""
+    st = _wg_streams.get(device)
+    if st is not None:
+        torch.cuda.current_stream(device).wait_stream(st)
+
+
 def _wgrad_flush(m, pending):
-    """pending: list of (setter, descriptor).  One grouped launch (<= 12 problems per launch)."""
-    for i in range(0, len(pending), 12):
-        chunk = pending[i:i + 12]
-        outs = _group(m, [d for _, d in chunk])
-        for (setter, _), o in zip(chunk, outs):
-            setter(o)
+    """pending: list of (setter, descriptor).  Grouped launches (<= 12 problems each), on the side stream."""
+    if not pending:
+        return
+    overlap = _WG_OVERLAP and pending[0][1]["A"].is_cuda
+    if overlap:
+        dev = pending[0][1]["A"].device
+        for _, d in pending:   # outputs come from the main stream's pool; inputs must outlive the side-stream reads
+            d["out"] = torch.empty((d["A"].shape[1], d["B"].shape[1]), dtype=F32, device=dev)
+        side = wgrad_stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        ctx = torch.cuda.stream(side)
+    else:
+        ctx = _NullCtx()
+    with ctx:
+        for i in range(0, len(pending), 12):
+            chunk = pending[i:i + 12]
+            outs = _group(m, [d for _, d in chunk])
+            for (setter, _), o in zip(chunk, outs):
+                setter(o)
+    if overlap:
+        for _, d in pending:
+            d["A"].record_stream(side)
+            d["B"].record_stream(side)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 # ----------------------------------------------------------------------------------------------
@@ -221,7 +268,7 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
 
     # ---- modulation vectors and y_proj
     dmod_a = m.act(dmod)
-    dyp = _dgrad(m, dmod_a, w.Wmod, F32)
+    dyp = _dgrad(m, dmod_a, w.Wmod, F32, **({"split_k": 16} if m.fast else {}))   # M = batch: 6 tiles, K = 12 d
     defer(g, "Wmod", dmod_a, sv.yp)
     g.by = torch.zeros(d, dtype=F32, device=dev)
     dpre = ops.silu_bwd(dyp, sv.pre, m.T, g.by)
@@ -300,7 +347,7 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     dmodo = torch.zeros_like(sv.modo)
     dX = ops.ln_modulate_bwd(dlnf, sv.Xf, sv.muf, sv.rsf, sv.modo[:, d:], None, N, dmodo[:, d:], dmodo[:, :d])
     dmodo_a = m.act(dmodo)
-    dy_acc = _dgrad(m, dmodo_a, W.Wmod_out, F32)
+    dy_acc = _dgrad(m, dmodo_a, W.Wmod_out, F32, **({"split_k": 4} if m.fast else {}))
     defer("Wmod_out", dmodo_a, sv.y)
 
     dC = None
@@ -309,7 +356,7 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
         dX, dC, dy_acc, g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, dy_acc, sv.dims, rope)
         sv.blocks[i] = None  # free saved activations as we go
         if on_grads is not None:
-            on_grads(_grad_tensors(g.blocks[i]))
+            on_grads(_grad_tensors(g.blocks[i]), _wg_streams.get(dev))
 
     # patch embedding
     g.bpe = torch.zeros(d, dtype=F32, device=dev)
@@ -336,5 +383,6 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     g.time_scale = ops.time_embed_bwd(dpe, sv.t, W.time_scale, W.denom)
     _wgrad_flush(m, pending)
     if on_grads is not None:
-        on_grads([v for v in vars(g).values() if torch.is_tensor(v)])
+        on_grads([v for v in vars(g).values() if torch.is_tensor(v)], _wg_streams.get(dev))
+    wgrad_join(dev)
     return g

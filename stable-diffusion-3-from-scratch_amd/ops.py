@@ -48,7 +48,7 @@ def torch_dtype(code: int):
 
 # ---------------------------------------------------------------------------------------------
 def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16):
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1):
     if a_kmajor:
         K_, M = A.shape
     else:
@@ -60,7 +60,10 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     if K_ != Kb:
         raise RuntimeError(f"gemm: inner dimensions differ ({K_} vs {Kb})")
     if out is None:
-        out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
+        if split_k > 1:
+            out = torch.zeros((M, N), dtype=torch.float32, device=A.device)   # slices accumulate atomically
+        else:
+            out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
     a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), A.stride(0)
     a.B, a.b_dtype, a.b_kmajor, a.ldb = _p(B), _dt(B), int(b_kmajor), B.stride(0)
     a.C, a.c_dtype, a.ldc = _p(out), _dt(out), out.stride(0)
@@ -75,6 +78,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
         a.aux, a.aux_dtype, a.ld_aux = _p(aux), _dt(aux), aux.stride(0)
     a.accumulate = int(accumulate)
     a.precision = precision
+    a.split_k = split_k
     return out
 
 

@@ -22,6 +22,7 @@ class GradReducer:
         self._pending = []       # tensors waiting for a bucket
         self._pending_bytes = 0
         self._inflight = []      # (flat, tensors, work)
+        self._after = None
         self.skip = False        # True on non-final gradient-accumulation micro-steps (no_sync semantics)
 
     def _side(self, device):
@@ -30,7 +31,11 @@ class GradReducer:
         return self._stream
 
     # ---- called by the engine (or the hook fallback) as gradients become final -----------------
-    def add(self, tensors):
+    def add(self, tensors, after=None):
+        """tensors: gradients that are final once the current stream (and `after`, the stream that produced
+        the weight gradients, if given) reach this point."""
+        if after is not None:
+            self._after = after
         if not self.enabled or self.skip:
             return
         for t in tensors:
@@ -48,6 +53,8 @@ class GradReducer:
         if tensors[0].is_cuda:
             side = self._side(tensors[0].device)
             side.wait_stream(torch.cuda.current_stream())
+            if self._after is not None:
+                side.wait_stream(self._after)
             with torch.cuda.stream(side):
                 self._launch(tensors)
         else:

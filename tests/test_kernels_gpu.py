@@ -314,3 +314,24 @@ def test_attention_oracle_mode_matches_cpu_oracle(ops):
     r = rel(out, ref)
     print(f"[attn oracle-mode] rel-L2 vs CPU oracle core = {r:.3e}")
     assert r < 3e-4
+
+
+@pytest.mark.parametrize("layout", ["nt", "dgrad", "wgrad"])
+def test_gemm_dma_path_and_split_k(ops, layout):
+    """K % 64 == 0 takes the global_load_lds kernel; ragged M/N are clamped; split-K slices add atomically."""
+    M, N, K = 200, 136, 256
+    if layout == "nt":
+        A, B = rnd(M, K, seed=21, dtype=torch.bfloat16), rnd(N, K, seed=22, dtype=torch.bfloat16)
+        ref, kw = A.double() @ B.double().T, {}
+    elif layout == "dgrad":
+        A, B = rnd(M, K, seed=21, dtype=torch.bfloat16), rnd(K, N, seed=22, dtype=torch.bfloat16)
+        ref, kw = A.double() @ B.double(), dict(b_kmajor=True)
+    else:
+        A, B = rnd(K, M, seed=21, dtype=torch.bfloat16), rnd(K, N, seed=22, dtype=torch.bfloat16)
+        ref, kw = A.double().T @ B.double(), dict(a_kmajor=True, b_kmajor=True)
+    assert rel(ops.gemm(A, B, out_dtype=torch.float32, **kw), ref) < 1e-5
+    assert rel(ops.gemm(A, B, out_dtype=torch.bfloat16, **kw), ref) < 4e-3
+    bias = rnd(N, seed=23)
+    res = rnd(M, N, seed=24)
+    out = ops.gemm(A, B, bias=bias, residual=res, split_k=3, **kw)
+    assert rel(out, ref + bias.double() + res.double()) < 1e-5
