@@ -85,7 +85,7 @@ class model_trainer:
                  load_ema_file=None, optimFile=None, schedulerFile=None, scalerFile=None, use_amp=True, wandb_name=None,
                  wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
-                 data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None):
+                 data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
@@ -105,7 +105,7 @@ class model_trainer:
         self.device = self.model.device
         self.dev = self.model.dev
         broadcast_parameters(self.model)
-        self.reducer = GradReducer(self.subgroup)
+        self.reducer = GradReducer(self.subgroup, force=force_reducer)
         if self.reducer.enabled:
             if hasattr(self.model, "grad_reducer"):
                 self.model.grad_reducer = self.reducer           # overlapped: fired from the backward schedule

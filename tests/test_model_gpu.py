@@ -270,3 +270,39 @@ def test_product_path_has_no_cpu_fallback():
             net(torch.zeros(1, 16, 4, 4), torch.tensor([0.5]), torch.zeros(1, 154, 2304), torch.zeros(1, 768))
         finally:
             net.device = torch.device("cuda:0")
+
+
+def test_trainer_step_and_reducer_path_single_rank():
+    """Two optimizer steps of the mirrored trainer; the RCCL reducer path (side stream, bucket flush fired from the
+    backward schedule, ReduceOp.AVG) is forced on with a one-rank nccl group and must not change the result."""
+    import torch.distributed as dist
+    import sd3_amd  # noqa: F401
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+
+    def run(force):
+        torch.manual_seed(0)
+        net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                         device=torch.device("cuda:0"), positional_encoding="RoPE2d", **CONFIGS["micro"])
+        net.load_state_dict(make_state_dict(0, **CONFIGS["micro"]))
+        tr = model_trainer(net, batchSize=4, accumulation_steps=2, totalSteps=10, lr=1e-3, ema_update_freq=1, ema_decay=0.9, warmup_steps=2,
+                           use_lr_scheduler=False, device=torch.device("cuda:0"), saveDir="/tmp/_t", numSaveSteps=100, null_prob_pooled=0.1,
+                           null_prob_gemma=0.316, null_prob_bert=0.316, max_res=128, device_rng=True, use_ema=True, force_reducer=force)
+        losses = [float(tr.train_step(s)) for s in (1, 2)]
+        tr.update_ema()
+        torch.cuda.synchronize()
+        return losses, [p.detach().clone() for p in net.parameters()], tr
+
+    l0, p0, _ = run(False)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        l1, p1, tr = run(True)
+        assert tr.reducer.enabled
+    finally:
+        dist.destroy_process_group()
+    assert all(np.isfinite(l0)) and l0[0] > 0
+    assert np.allclose(l0, l1, rtol=1e-5)
+    for a, b in zip(p0, p1):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
