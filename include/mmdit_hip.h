@@ -73,6 +73,9 @@ typedef struct {
   int split_k;    /* >1: K is split over split_k workgroups per tile which add atomically into a PRE-ZEROED fp32 C
                      (skinny problems, e.g. the per-sample modulation GEMMs with M = batch); bf16 precision, K%64==0,
                      no act/aux/gate/accumulate */
+  int stream_k;   /* !=0: stream-K decomposition allowed: C is fp32 and PRE-ZEROED, the (tile, K-tile) units of the whole
+                     launch are split evenly over the resident workgroups and partial tiles are added atomically (weight
+                     gradients: few output tiles, very long reductions).  Ignored when the fast path does not apply. */
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 /* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,

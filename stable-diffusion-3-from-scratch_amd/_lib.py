@@ -32,6 +32,7 @@ class GemmArgs(ctypes.Structure):
         ("accumulate", _i),
         ("precision", _i),
         ("split_k", _i),
+        ("stream_k", _i),
     ]
 
 

@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupParams gp) {
     }
   }
 
-  epilogue<TC, TAUX>(acc, p, gp, m0, n0, wm, wn, lane, sk);
+  __syncthreads();   // every wave is done with the operand tiles: their LDS is reused by the epilogue
+  epilogue<TC, TAUX>(acc, p, gp, m0, n0, wm, wn, lane, sk, smem + wave * EP_WAVE_BYTES);
 }
 
 template <typename TA, typename TB, bool A_KM, bool B_KM, bool SPLIT, typename TC, typename TAUX>
@@ -249,17 +250,19 @@ int check_problem(const mmdit_gemm_args* a) {
 
 // Tile-configuration heuristic of the LDS-DMA path.  Bigger tiles halve the L2->CU traffic per FLOP (a 128x128
 // tile needs ~64 B/clk/CU at full MFMA rate, about what the L2 can deliver) but need enough tiles to fill 256 CUs.
-static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k) {
+static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k) {
   static const char* force = getenv("MMDIT_GEMM_CFG");
   if (force) return atoi(force);
-  long t256 = 0, t256x128 = 0;
+  if (stream_k) return CFG_256x256;   // no quantisation with stream-K: take the fewest bytes per FLOP
+  // Wave quantisation decides (measured, tools/gemm_bench.py): a "round" of 128x128 tiles (2 workgroups per CU)
+  // costs 1.0, a round of 256x256 tiles (1 per CU, 4x the FLOPs each) 1.58.
+  long t128 = 0, t256 = 0;
   for (int i = 0; i < count; i++) {
+    t128 += (long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128);
     t256 += (long)((args[i].M + 255) / 256) * ((args[i].N + 255) / 256);
-    t256x128 += (long)((args[i].M + 255) / 256) * ((args[i].N + 127) / 128);
   }
-  if (t256 * split_k >= 232) return CFG_256x256;
-  if (t256x128 * split_k >= 232) return CFG_256x128;
-  return CFG_128x128;
+  const double c128 = (double)((t128 * split_k + 511) / 512), c256 = 1.58 * (double)((t256 * split_k + 255) / 256);
+  return c256 < c128 ? CFG_256x256 : CFG_128x128;
 }
 
 extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) {
@@ -287,8 +290,11 @@ extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_
     if (a->b_kmajor && a->N < 8) dma = false;
   }
   int bm = BM, bn = BN, cfg = CFG_128x128;
-  if (dma) { cfg = pick_dma_cfg(args, count, split_k); dma_cfg_tile(cfg, bm, bn); }
-  int tiles = 0;
+  // stream-K for the weight gradients (k-major A): fp32 C must be pre-zeroed by the caller (a0->stream_k)
+  static const bool no_sk = getenv("MMDIT_GEMM_NO_STREAMK") != nullptr;
+  const bool stream_k = dma && !no_sk && a0->stream_k && a0->c_dtype == MMDIT_F32 && split_k == 1 && a0->act == MMDIT_ACT_NONE && !a0->accumulate;
+  if (dma) { cfg = pick_dma_cfg(args, count, split_k, stream_k); dma_cfg_tile(cfg, bm, bn); }
+  int tiles = 0, units = 0;
   for (int i = 0; i < count; i++) {
     const mmdit_gemm_args* a = &args[i];
     Problem& p = gp.p[i];
@@ -300,10 +306,19 @@ extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_
     p.tiles_n = (a->N + bn - 1) / bn;
     p.tiles_m = (a->M + bm - 1) / bm;
     p.tile_start = tiles;
+    p.nk = a->K / BK;
+    p.unit_start = units;
     tiles += p.tiles_n * p.tiles_m;
+    units += p.tiles_n * p.tiles_m * p.nk;
+    if (stream_k) MMDIT_CHECK_ARG(!a->aux && !a->gate && a->stream_k);
   }
+  gp.stream_k = stream_k; gp.total_units = units;
   if (aux_dt < 0) aux_dt = a0->c_dtype;
   gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = split_k;
+  static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation: 1 = no DMA in the main loop, 2 = no LDS reads / MFMA
+  gp.debug = debug_env ? atoi(debug_env) : 0;
+  static const char* epi_env = getenv("MMDIT_GEMM_EPI");
+  gp.epi_direct = epi_env ? (atoi(epi_env) == 0) : 0;
   gp.raster = raster_env ? atoi(raster_env) : 8;   // n-tiles per rasterization group (see locate_tile)
   if (split_k > 1) {
     // split-K slices accumulate atomically into a pre-zeroed fp32 C: only on the DMA path, plain epilogue

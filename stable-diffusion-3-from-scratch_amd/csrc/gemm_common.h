@@ -15,10 +15,12 @@ struct Problem {
   int64_t lda, ldb, ldc, ld_gate, ld_res, ld_aux;
   int M, N, K;
   int rows_per_batch, tiles_n, tiles_m, tile_start;
+  int nk, unit_start;   // stream-K: K-tiles per output tile, first (tile, K-tile) unit of this problem
 };
 struct GroupParams {
   Problem p[MAXG];
-  int count, total_tiles, act, accumulate, split_k, raster;
+  int count, total_tiles, act, accumulate, split_k, raster, debug, epi_direct;
+  int stream_k, total_units;   // stream-K: every workgroup gets an equal share of the (tile, K-tile) units
 };
 
 // block id -> (problem, m-tile, n-tile, split-K slice).
@@ -45,11 +47,86 @@ __device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int
   return p;
 }
 
-// epilogue: lane owns row m, 4 consecutive columns per accumulator register group.
-// split-K slices (gp.split_k > 1) add their partial sums atomically into a pre-zeroed fp32 C;
-// bias / residual are contributed by slice 0 only.
+// Epilogue.  The accumulators hold C^T fragments (lane = output row, 4 consecutive columns per register
+// group), which would make every global store touch 32 different rows.  Each wave therefore stages its
+// 32-row x 64-column block through a wave-private LDS region (pitch 272 B: conflict-free 16-B writes and
+// reads) and then walks it row-contiguously: one wave instruction covers 4 rows x 256 B (fp32) / 128 B (bf16)
+// so C / aux stores and the residual / gate / bias loads are fully coalesced.
+// split-K slices (gp.split_k > 1) add their partial sums atomically into a pre-zeroed fp32 C; bias / residual
+// are contributed by slice 0 only.
+constexpr int EP_PITCH = 272;
+constexpr int EP_WAVE_BYTES = 32 * EP_PITCH;   // LDS bytes each wave needs for the epilogue
+
 template <typename TC, typename TAUX, int MI = 2, int NJ = 2>
-__device__ __forceinline__ void epilogue(const f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, int sk) {
+__device__ __forceinline__ void epilogue(const f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
+                                         int lane, int sk, char* stage /* wave-private, EP_WAVE_BYTES */, bool atomic_out = false) {
+  static_assert(NJ == 2, "wave sub-tile must be 64 columns wide");
+  TC* C = (TC*)p.C;
+  TAUX* AUX = (TAUX*)p.aux;
+  const bool first = sk == 0;
+  const float* bias = first ? p.bias : nullptr;
+  const float* gate = p.gate;
+  const float* res = first ? p.residual : nullptr;
+  const int c4 = (lane & 15) * 4, col = n0 + wn * 64 + c4;
+  float b4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias && col < p.N) ld4(bias + col, b4);
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *LDS_PTR(f32x4, stage + (lane & 31) * EP_PITCH + (j * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
+            (f32x4){acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int r = it * 4 + (lane >> 4);
+      const f32x4 t = *LDS_PTR(const f32x4, stage + r * EP_PITCH + c4 * 4);
+      const int row = m0 + wm * (MI * 32) + i * 32 + r;
+      if (row >= p.M || col >= p.N) continue;
+      float v[4] = {t[0] + b4[0], t[1] + b4[1], t[2] + b4[2], t[3] + b4[3]};
+      if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
+      if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+      }
+      if (res) {
+        float r4[4];
+        ld4(res + (int64_t)row * p.ld_res + col, r4);
+        if (gate) {
+          float g4[4];
+          ld4(gate + (int64_t)(row / p.rows_per_batch) * p.ld_gate + col, g4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = r4[e] + g4[e] * v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += r4[e];
+        }
+      }
+      TC* cp = C + (int64_t)row * p.ldc + col;
+      if constexpr (sizeof(TC) == 4) {
+        if (gp.split_k > 1 || atomic_out) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) atomicAdd((float*)cp + e, v[e]);
+          continue;
+        }
+      }
+      if (gp.accumulate) {
+        float c4v[4];
+        ld4(cp, c4v);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += c4v[e];
+      }
+      st4(cp, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+}
+
+// previous form kept for A/B measurements (MMDIT_GEMM_EPI=0): every lane stores its own row directly
+template <typename TC, typename TAUX, int MI = 2, int NJ = 2>
+__device__ __forceinline__ void epilogue_direct(const f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, int sk) {
   TC* C = (TC*)p.C;
   TAUX* AUX = (TAUX*)p.aux;
   const bool first = sk == 0;

@@ -55,32 +55,16 @@ __device__ __forceinline__ bf16x8 load_frag_sw(const char* tile, int r0, int ks,
   }
 }
 
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) {
+// one (tile, K-range) segment: accumulate K-tiles [kt0, kt1) of output tile (tm, tn) of problem p
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM>
+__device__ __forceinline__ void mainloop(const Problem& p, const GroupParams& gp, int m0, int n0, int kt0, int kt1, f32x16 (&acc)[MI][NJ],
+                                         char* smem, int wave, int lane, int wm, int wn) {
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
   constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  int tm, tn, sk;
-  const Problem& p = locate_tile(gp, tm, tn, sk);
-  const int m0 = tm * TBM, n0 = tn * TBN;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
   const int M = p.M, N = p.N;
   const int64_t lda = p.lda, ldb = p.ldb;
-
-  f32x16 acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; i++)
-#pragma unroll
-    for (int j = 0; j < NJ; j++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-
-  const int nk_all = p.K / BK, per = (nk_all + gp.split_k - 1) / gp.split_k;
-  const int kt0 = sk * per, kt1 = min(nk_all, kt0 + per);
-
   if (kt0 < kt1) {
     dma_tile<A_KM, TBM, NW>(A, lda, m0, kt0 * BK, M, smem, wave, lane);
     dma_tile<B_KM, TBN, NW>(B, ldb, n0, kt0 * BK, N, smem + A_BYTES, wave, lane);
@@ -90,12 +74,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   for (int kt = kt0; kt < kt1; kt++) {
     const int cur = (kt - kt0) & 1;
     char* nxt = smem + (cur ^ 1) * STAGE;
-    if (kt + 1 < kt1) {
+    if (kt + 1 < kt1 && !(gp.debug & 1)) {
       dma_tile<A_KM, TBM, NW>(A, lda, m0, (kt + 1) * BK, M, nxt, wave, lane);
       dma_tile<B_KM, TBN, NW>(B, ldb, n0, (kt + 1) * BK, N, nxt + A_BYTES, wave, lane);
     }
     const char* ta = smem + cur * STAGE;
     const char* tb = ta + A_BYTES;
+    if (!(gp.debug & 2))
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ks++) {
       bf16x8 a[MI], b[NJ];
@@ -103,16 +88,67 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       for (int i = 0; i < MI; i++) a[i] = load_frag_sw<A_KM, TBM>(ta, wm * (MI * 32) + i * 32, ks, lane);
 #pragma unroll
       for (int j = 0; j < NJ; j++) b[j] = load_frag_sw<B_KM, TBN>(tb, wn * (NJ * 32) + j * 32, ks, lane);
-      // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m (vector epilogue)
+      // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m
 #pragma unroll
       for (int i = 0; i < MI; i++)
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __syncthreads();   // also releases the operand LDS for the epilogue / the next segment
   }
-  epilogue<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk);
+}
+
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) {
+  constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  f32x16 acc[MI][NJ];
+
+  if (gp.stream_k) {
+    // stream-K: the (tile, K-tile) units of all problems are split evenly over the resident workgroups; a
+    // workgroup walks its contiguous unit range segment by segment and adds each partial tile atomically into
+    // the pre-zeroed fp32 C.  Used for the weight gradients: few output tiles, very long reductions.
+    const long long U = gp.total_units, G = gridDim.x;
+    int u = (int)(blockIdx.x * U / G);
+    const int u_end = (int)((blockIdx.x + 1) * U / G);
+    while (u < u_end) {
+      int pi = 0;
+#pragma unroll 1
+      for (int i = 1; i < gp.count; i++) pi = (u >= gp.p[i].unit_start) ? i : pi;
+      const Problem& p = gp.p[pi];
+      const int local = u - p.unit_start, t = local / p.nk, k0 = local - t * p.nk, k1 = min(p.nk, k0 + (u_end - u));
+      const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+#pragma unroll
+      for (int i = 0; i < MI; i++)
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+      mainloop<WM, WN, MI, NJ, A_KM, B_KM>(p, gp, tm * TBM, tn * TBN, k0, k1, acc, smem, wave, lane, wm, wn);
+      epilogue<TC, TAUX, MI, NJ>(acc, p, gp, tm * TBM, tn * TBN, wm, wn, lane, k0 == 0 ? 0 : 1, smem + wave * EP_WAVE_BYTES, true);
+      __syncthreads();   // epilogue staging reads done before the next segment's DMA overwrites the LDS
+      u += k1 - k0;
+    }
+    return;
+  }
+
+  int tm, tn, sk;
+  const Problem& p = locate_tile(gp, tm, tn, sk);
+  const int m0 = tm * TBM, n0 = tn * TBN;
+#pragma unroll
+  for (int i = 0; i < MI; i++)
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  const int nk_all = p.K / BK, per = (nk_all + gp.split_k - 1) / gp.split_k;
+  const int kt0 = sk * per, kt1 = min(nk_all, kt0 + per);
+  mainloop<WM, WN, MI, NJ, A_KM, B_KM>(p, gp, m0, n0, kt0, kt1, acc, smem, wave, lane, wm, wn);
+  if (gp.epi_direct) epilogue_direct<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk);
+  else epilogue<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk, smem + wave * EP_WAVE_BYTES);
 }
 
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
@@ -125,7 +161,9 @@ int launch_cfg(const GroupParams& gp, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL(k, dim3(gp.total_tiles * gp.split_k), dim3(64 * WM * WN), smem, s, gp);
+  // stream-K: one resident workgroup per slot (256 CUs x workgroups that fit per CU by LDS)
+  const int grid = gp.stream_k ? 256 * (smem <= 65536 ? 2 : 1) : gp.total_tiles * gp.split_k;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);
   return mmdit_launch_status();
 }
 

@@ -63,8 +63,9 @@ def _group(m, problems):
 
 
 def _wg(dY, X):
-    """Problem descriptor of dW[N,K] = dY[M,N]^T X[M,K] (fp32 out)."""
-    return dict(A=dY, B=X, a_kmajor=True, b_kmajor=True, out_dtype=F32)
+    """Problem descriptor of dW[N,K] = dY[M,N]^T X[M,K] (fp32 out, zero-initialised: stream-K adds partial tiles)."""
+    # stream-K only pays for long reductions (rows >= 2048); the per-sample GEMMs (rows = batch) stay regular
+    return dict(A=dY, B=X, a_kmajor=True, b_kmajor=True, out_dtype=F32, stream_k=dY.shape[0] >= 2048)
 
 
 def _wgrad(m, dY, X):
@@ -106,18 +107,20 @@ def _wgrad_flush(m, pending):
     if overlap:
         dev = pending[0][1]["A"].device
         for _, d in pending:   # outputs come from the main stream's pool; inputs must outlive the side-stream reads
-            d["out"] = torch.empty((d["A"].shape[1], d["B"].shape[1]), dtype=F32, device=dev)
+            d["out"] = torch.zeros((d["A"].shape[1], d["B"].shape[1]), dtype=F32, device=dev)
         side = wgrad_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         ctx = torch.cuda.stream(side)
     else:
         ctx = _NullCtx()
     with ctx:
-        for i in range(0, len(pending), 12):
-            chunk = pending[i:i + 12]
-            outs = _group(m, [d for _, d in chunk])
-            for (setter, _), o in zip(chunk, outs):
-                setter(o)
+        for flag in (True, False):     # one launch per kernel variant: stream-K (long reductions) / regular
+            part = [pd for pd in pending if bool(pd[1].get("stream_k")) == flag]
+            for i in range(0, len(part), 12):
+                chunk = part[i:i + 12]
+                outs = _group(m, [d for _, d in chunk])
+                for (setter, _), o in zip(chunk, outs):
+                    setter(o)
     if overlap:
         for _, d in pending:
             d["A"].record_stream(side)
@@ -146,7 +149,8 @@ def mlp_core_bwd(m, w, dacc, x_act, gu, h, dev):
     dbup = torch.zeros(gu.shape[1], dtype=F32, device=dev)
     dgu = ops.mlp_act_bwd(dh, gu, w.hidden, dbup, w.gelu)
     dx = _dgrad(m, dgu, w.Wup, m.T)
-    gWdown, gWup = _group(m, [_wg(dacc, h), _wg(dgu, x_act)])
+    ds = [_wg(dacc, h), _wg(dgu, x_act)]
+    gWdown, gWup = _group(m, ds) if ds[0]["stream_k"] == ds[1]["stream_k"] else (_group(m, ds[:1])[0], _group(m, ds[1:])[0])
     return dx, NS(Wup=gWup, bup=dbup, Wdown=gWdown)
 
 

@@ -48,7 +48,7 @@ def torch_dtype(code: int):
 
 # ---------------------------------------------------------------------------------------------
 def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1):
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False):
     if a_kmajor:
         K_, M = A.shape
     else:
@@ -60,7 +60,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     if K_ != Kb:
         raise RuntimeError(f"gemm: inner dimensions differ ({K_} vs {Kb})")
     if out is None:
-        if split_k > 1:
+        if split_k > 1 or stream_k:
             out = torch.zeros((M, N), dtype=torch.float32, device=A.device)   # slices accumulate atomically
         else:
             out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
@@ -79,6 +79,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     a.accumulate = int(accumulate)
     a.precision = precision
     a.split_k = split_k
+    a.stream_k = int(stream_k)
     return out
 
 

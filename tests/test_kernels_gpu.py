@@ -335,3 +335,15 @@ def test_gemm_dma_path_and_split_k(ops, layout):
     res = rnd(M, N, seed=24)
     out = ops.gemm(A, B, bias=bias, residual=res, split_k=3, **kw)
     assert rel(out, ref + bias.double() + res.double()) < 1e-5
+
+
+def test_gemm_stream_k_grouped_wgrad(ops):
+    """Weight-gradient group (long reductions, few tiles) through the stream-K decomposition vs fp64 references."""
+    probs, refs = [], []
+    for i, (Mr, N, K) in enumerate([(1024, 256, 384), (640, 128, 128), (64, 512, 256), (1024, 72, 200)]):
+        dY, X = rnd(Mr, N, seed=40 + i, dtype=torch.bfloat16), rnd(Mr, K, seed=50 + i, dtype=torch.bfloat16)
+        probs.append(dict(A=dY, B=X, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
+        refs.append(dY.double().T @ X.double())
+    outs = ops.gemm_grouped(probs)
+    for o, r in zip(outs, refs):
+        assert rel(o, r) < 1e-5

@@ -45,8 +45,8 @@ def main():
             f"{name} fwd bf16out (img)": (lambda: ops.gemm(Ax, W, out_dtype=torch.bfloat16), 2.0 * Mx * N * K),
             f"{name} fwd grouped img+txt": (lambda: ops.gemm_grouped([dict(A=Ax, B=W, out_dtype=torch.bfloat16), dict(A=Ac, B=W, out_dtype=torch.bfloat16)]), 2.0 * (Mx + Mc) * N * K),
             f"{name} dgrad grouped img+txt": (lambda: ops.gemm_grouped([dict(A=dYx, B=W, b_kmajor=True, out_dtype=torch.bfloat16), dict(A=dYc, B=W, b_kmajor=True, out_dtype=torch.bfloat16)]), 2.0 * (Mx + Mc) * N * K),
-            f"{name} wgrad (img)": (lambda: ops.gemm(dYx, Ax, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32), 2.0 * Mx * N * K),
-            f"{name} wgrad grouped img+txt": (lambda: ops.gemm_grouped([dict(A=dYx, B=Ax, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32), dict(A=dYc, B=Ac, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32)]), 2.0 * (Mx + Mc) * N * K),
+            f"{name} wgrad (img)": (lambda: ops.gemm(dYx, Ax, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True), 2.0 * Mx * N * K),
+            f"{name} wgrad grouped img+txt": (lambda: ops.gemm_grouped([dict(A=dYx, B=Ax, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True), dict(A=dYc, B=Ac, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True)]), 2.0 * (Mx + Mc) * N * K),
         }
         if name in ("out", "w3"):
             aux = torch.empty((Mx, N), dtype=torch.bfloat16, device=dev)
@@ -58,7 +58,7 @@ def main():
     probs, fl = [], 0.0
     for name, N, K in shapes:
         for Mr in (Mx, Mc):
-            probs.append(dict(A=rnd(Mr, N), B=rnd(Mr, K), a_kmajor=True, b_kmajor=True, out_dtype=torch.float32))
+            probs.append(dict(A=rnd(Mr, N), B=rnd(Mr, K), a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
             fl += 2.0 * Mr * N * K
     t = bench(lambda: ops.gemm_grouped(probs), args.reps)
     print(f"{'block wgrads, 8 problems grouped':<34}{'':>21}{t * 1e6:>10.1f}{fl / t / 1e12:>10.1f}")
