@@ -111,13 +111,14 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
       for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, P144, kb * 32, ks, lane), qf[ks], s[kb], 0, 0, 0);
+      if (ORACLE) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int key = j * KT + kb * 32 + acc_row(r, lane);
-        float v;
-        if (ORACLE) v = bf2f(f2bf(bf2f(f2bf(s[kb][r])) * scale));   // Attention.py:277: bf16 matmul, then bf16 * scale
-        else v = s[kb][r] * (scale * LOG2E);
-        s[kb][r] = key < S ? v : -INFINITY;
+        for (int r = 0; r < 16; r++) s[kb][r] = bf2f(f2bf(bf2f(f2bf(s[kb][r])) * scale));   // Attention.py:277: bf16 matmul, then bf16 * scale
+      }
+      if ((j + 1) * KT > S) {   // only the last (ragged) tile has keys to mask: wave-uniform branch
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (j * KT + kb * 32 + acc_row(r, lane) >= S) s[kb][r] = -INFINITY;
       }
     }
   };
@@ -156,13 +157,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
       f32x16 s[2];
       scores(j, kt(cur), s);
       if (!ORACLE) {
-        const float mn = fmaxf(m, tile_max(s));
-        const float alpha = exp2f(m - mn);
+        // raw scores; m is tracked in the scaled log2 domain: p = exp2(s*c - m) as one fma + v_exp_f32
+        const float c = scale * LOG2E;
+        const float mn = fmaxf(m, tile_max(s) * c);
+        const float alpha = fast_exp2(m - mn);
         float rs = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-          for (int r = 0; r < 16; r++) { const float p = exp2f(s[kb][r] - mn); s[kb][r] = p; rs += p; }
+          for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -mn)); s[kb][r] = p; rs += p; }
         rs += __shfl_xor(rs, 32, 64);
         l = l * alpha + rs; m = mn;
 #pragma unroll
@@ -290,10 +293,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, P144, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vtile, P144, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
       }
+      const bool ragged = (j + 1) * KT > S;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const int key = j * KT + kb * 32 + acc_row(r, lane);
-        const float p = key < S ? exp2f(s[r] * (scale * LOG2E) - lq) : 0.f;
+        float p = fast_exp2(fmaf(s[r], scale * LOG2E, -lq));
+        if (ragged && j * KT + kb * 32 + acc_row(r, lane) >= S) p = 0.f;
         s[r] = p * (dp[r] - dq_delta);
       }
 #pragma unroll
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(128) void attn_bwd_dkv_kernel(const bf16_t* __restr
         for (int e = 0; e < 4; e++) {
           const int r = g * 4 + e;
           const bool ok = (key < S) && (jq * KT + r0 + e < S);
-          const float p = ok ? exp2f(s[r] * (scale * LOG2E) - l4[e]) : 0.f;
+          const float p = ok ? fast_exp2(fmaf(s[r], scale * LOG2E, -l4[e])) : 0.f;
           s[r] = p;
           ds[r] = p * (dp[r] - d4[e]);
         }

@@ -16,15 +16,15 @@ typedef uint16_t bf16_t;  // raw storage type for bf16 in global memory
 
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
-// round-to-nearest-even fp32 -> bf16 (NaN preserved as quiet NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// round-to-nearest-even fp32 -> bf16 on the hardware converter (v_cvt_pk_bf16_f32: one instruction per pair)
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __builtin_bit_cast(float, ((uint32_t)h) << 16); }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }   // raw v_exp_f32
 
 // generic scalar load/store by dtype tag
 template <typename T> struct io;

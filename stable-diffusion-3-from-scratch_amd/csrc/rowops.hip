@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
 }
 
 // adaLN backward: block = (batch b, chunk of RCH rows); wave w takes rows w, w+4, ...
-constexpr int LN_BWD_RCH = 64;
+constexpr int LN_BWD_RCH = 16;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
 template <int NIT, typename TG>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
                                                          const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
@@ -114,12 +114,26 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ 
   }
   float* dsb = dscale + (int64_t)b * ld_dmod;
   float* dhb = dshift + (int64_t)b * ld_dmod;
+  if constexpr (NIT <= 6) {
+    // combine the 4 waves in LDS (<= 48 KB), then one atomic per column per block
+    __shared__ float red[2][4][NIT * 256];
 #pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    int ch = lane + 64 * it;
-    if (ch < nch) {
+    for (int it = 0; it < NIT; it++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) { atomicAdd(dsb + ch * 4 + e, ds[it][e]); atomicAdd(dhb + ch * 4 + e, dh[it][e]); }
+      for (int e = 0; e < 4; e++) { red[0][wave][(it * 64 + lane) * 4 + e] = ds[it][e]; red[1][wave][(it * 64 + lane) * 4 + e] = dh[it][e]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < d; c += 256) {
+      atomicAdd(dsb + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+      atomicAdd(dhb + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      int ch = lane + 64 * it;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) { atomicAdd(dsb + ch * 4 + e, ds[it][e]); atomicAdd(dhb + ch * 4 + e, dh[it][e]); }
+      }
     }
   }
 }
@@ -420,6 +434,7 @@ __global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ 
   }
 }
 
+constexpr int GR_RCH = 16;
 // dacc = dy * gate[b]; dgate[b] += sum dy*acc; dbias += sum dacc.  grid = (slabs, batch * chunks)
 template <typename TA, typename TO>
 __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const float* __restrict__ dy, const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate,
@@ -435,8 +450,8 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const float* __restri
   for (int e = 0; e < 8; e++) { g[e] = 0.f; sgate[e] = 0.f; sb[e] = 0.f; }
   if (act) {
     ld8(gate + (int64_t)b * ld_gate + c, g);
-    const int rend = min(rpb, (chunk + 1) * CO_RCH);
-    for (int rl = chunk * CO_RCH + ty; rl < rend; rl += 2) {
+    const int rend = min(rpb, (chunk + 1) * GR_RCH);
+    for (int rl = chunk * GR_RCH + ty; rl < rend; rl += 2) {
       const int64_t row = (int64_t)b * rpb + rl;
       float dv[8], av[8], o[8];
       ld8(dy + row * d + c, dv);
@@ -698,7 +713,7 @@ extern "C" int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc
                                        void* dacc, int dacc_dtype, float* dgate, int64_t ld_dgate, float* dbias, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(dy && acc && gate && dacc && dgate && rows > 0 && d % 8 == 0 && rpb > 0 && rows % rpb == 0 && ld_gate % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
-  const int nchunk = (rpb + CO_RCH - 1) / CO_RCH;
+  const int nchunk = (rpb + GR_RCH - 1) / GR_RCH;
   dim3 grid((d + 1023) / 1024, (rows / rpb) * nchunk);
   if (acc_dtype == MMDIT_BF16 && dacc_dtype == MMDIT_BF16) hipLaunchKernelGGL((gate_res_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, dy, (const bf16_t*)acc, gate, ld_gate, d, rpb, nchunk, (bf16_t*)dacc, dgate, ld_dgate, dbias);
   else if (acc_dtype == MMDIT_F32 && dacc_dtype == MMDIT_F32) hipLaunchKernelGGL((gate_res_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, (const float*)acc, gate, ld_gate, d, rpb, nchunk, (float*)dacc, dgate, ld_dgate, dbias);

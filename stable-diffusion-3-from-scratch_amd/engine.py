@@ -99,6 +99,18 @@ def wgrad_join(device):
         torch.cuda.current_stream(device).wait_stream(st)
 
 
+def _zeros_views(shapes, dev):
+    """One zero-filled fp32 arena (one memset launch) carved into views of the given shapes."""
+    sizes = [int(torch.Size(s).numel()) for s in shapes]
+    pad = [(n + 3) // 4 * 4 for n in sizes]           # keep every view 16-byte aligned
+    flat = torch.zeros(sum(pad), dtype=F32, device=dev)
+    out, off = [], 0
+    for s, n, p in zip(shapes, sizes, pad):
+        out.append(flat[off:off + n].view(s))
+        off += p
+    return out
+
+
 def _wgrad_flush(m, pending):
     """pending: list of (setter, descriptor).  Grouped launches (<= 12 problems each), on the side stream."""
     if not pending:
@@ -106,8 +118,10 @@ def _wgrad_flush(m, pending):
     overlap = _WG_OVERLAP and pending[0][1]["A"].is_cuda
     if overlap:
         dev = pending[0][1]["A"].device
-        for _, d in pending:   # outputs come from the main stream's pool; inputs must outlive the side-stream reads
-            d["out"] = torch.zeros((d["A"].shape[1], d["B"].shape[1]), dtype=F32, device=dev)
+        # outputs come from the main stream's pool (one zeroed arena: stream-K adds partial tiles atomically);
+        # inputs must outlive the side-stream reads (record_stream below)
+        for (_, d), o in zip(pending, _zeros_views([(d["A"].shape[1], d["B"].shape[1]) for _, d in pending], dev)):
+            d["out"] = o
         side = wgrad_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         ctx = torch.cuda.stream(side)
@@ -215,31 +229,33 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
     S, dev = N + Mt, dX2.device
     both = not w.last
     ms = _mod_views(sv.mod, d, w.last)
-    dmod = torch.zeros_like(sv.mod)
-    dms = _mod_views(dmod, d, w.last)
     g = NS(mlp_x=NS(), mlp_c=NS() if both else None)
+    # every atomically-accumulated small gradient of the block comes from ONE zeroed arena (one memset launch)
+    hx = sv.gu_x.shape[1]
+    shapes = [tuple(sv.mod.shape), (d,), (hx,), (64,), (64,), (64,), (64,), (d,)] + ([(d,), (sv.gu_c.shape[1],)] if both else [])
+    zs = _zeros_views(shapes, dev)
+    dmod, g.mlp_x.bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c, g.by = zs[:8]
+    if both:
+        g.mlp_c.bdown, g.mlp_c.bup = zs[8], zs[9]
+    dms = _mod_views(dmod, d, w.last)
     pending = []   # deferred weight-gradient GEMMs: (setter, descriptor)
 
     def defer(ns, name, dY, Xa):
         pending.append((lambda o, ns=ns, name=name: setattr(ns, name, o), _wg(dY, Xa)))
 
     # ---- MLP: gated residual -> down-proj -> activation -> up-proj -> adaLN
-    g.mlp_x.bdown = torch.zeros(d, dtype=F32, device=dev)
     dacc_x = ops.gate_residual_bwd(dX2, sv.acc_mx, ms.gate2x, N, dms.gate2x, g.mlp_x.bdown, m.T)
     probs = [dict(A=dacc_x, B=w.mlp_x.Wdown, b_kmajor=True, out_dtype=m.T)]
     if both:
-        g.mlp_c.bdown = torch.zeros(d, dtype=F32, device=dev)
         dacc_c = ops.gate_residual_bwd(dC2, sv.acc_mc, ms.gate2c, Mt, dms.gate2c, g.mlp_c.bdown, m.T)
         probs.append(dict(A=dacc_c, B=w.mlp_c.Wdown, b_kmajor=True, out_dtype=m.T))
     dh = _group(m, probs)
     defer(g.mlp_x, "Wdown", dacc_x, sv.h_x)
-    g.mlp_x.bup = torch.zeros(sv.gu_x.shape[1], dtype=F32, device=dev)
     dgu_x = ops.mlp_act_bwd(dh[0], sv.gu_x, w.mlp_x.hidden, g.mlp_x.bup, w.mlp_x.gelu)
     probs = [dict(A=dgu_x, B=w.mlp_x.Wup, b_kmajor=True, out_dtype=m.T)]
     defer(g.mlp_x, "Wup", dgu_x, sv.ln2x)
     if both:
         defer(g.mlp_c, "Wdown", dacc_c, sv.h_c)
-        g.mlp_c.bup = torch.zeros(sv.gu_c.shape[1], dtype=F32, device=dev)
         dgu_c = ops.mlp_act_bwd(dh[1], sv.gu_c, w.mlp_c.hidden, g.mlp_c.bup, w.mlp_c.gelu)
         probs.append(dict(A=dgu_c, B=w.mlp_c.Wup, b_kmajor=True, out_dtype=m.T))
         defer(g.mlp_c, "Wup", dgu_c, sv.ln2c)
@@ -260,8 +276,6 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
 
     # ---- attention core + QK norm / RoPE
     dQ, dK, dV = ops.attn_bwd(sv.Q, sv.K, sv.V, sv.Ox, sv.Oc, dOx, dOc, sv.lse, N, 64 ** -0.5, m.T)
-    g.wq_x, g.wk_x = torch.zeros(64, dtype=F32, device=dev), torch.zeros(64, dtype=F32, device=dev)
-    g.wq_c, g.wk_c = torch.zeros(64, dtype=F32, device=dev), torch.zeros(64, dtype=F32, device=dev)
     dqkv_x = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, g.wq_x, g.wk_x, m.T)
     dqkv_c = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, g.wq_c, g.wk_c, m.T)
     dln1 = _group(m, [dict(A=dqkv_x, B=w.Wqkv_x, b_kmajor=True, out_dtype=m.T), dict(A=dqkv_c, B=w.Wqkv_c, b_kmajor=True, out_dtype=m.T)])
@@ -274,7 +288,6 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
     dmod_a = m.act(dmod)
     dyp = _dgrad(m, dmod_a, w.Wmod, F32, **({"split_k": 16} if m.fast else {}))   # M = batch: 6 tiles, K = 12 d
     defer(g, "Wmod", dmod_a, sv.yp)
-    g.by = torch.zeros(d, dtype=F32, device=dev)
     dpre = ops.silu_bwd(dyp, sv.pre, m.T, g.by)
     dy_acc = _dgrad(m, dpre, w.Wy, F32, residual=dy_acc)
     defer(g, "Wy", dpre, sv.y)
