@@ -167,10 +167,11 @@ int mmdit_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int rows,
 int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, mmdit_stream_t stream);
 
 /* Backward of  Y = X + gate[b,:] * acc  (Transformer_Block_Dual.py:64-66,70-76):
- * dacc = dy * gate[b,:] (dtype dacc_dtype); dgate[b,:] += sum_rows dy*acc; dbias[:] += sum_rows dacc (optional). */
+ * dacc = dy * gate[b,:] (dtype dacc_dtype); dgate[b,:] += sum_rows dy*acc; dbias[b*ld_dbias + :] += sum_rows dacc (optional;
+ * ld_dbias = 0: one shared row, ld_dbias > 0: per-batch partial rows that the caller column-sums -- far less atomic contention). */
 int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate,
                             int rows, int d, int rows_per_batch, void* dacc, int dacc_dtype,
-                            float* dgate, int64_t ld_dgate, float* dbias, mmdit_stream_t stream);
+                            float* dgate, int64_t ld_dgate, float* dbias, int64_t ld_dbias, mmdit_stream_t stream);
 
 /* Column sums: out[c] += sum_r x[r,c]  (bias gradients). */
 int mmdit_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* out, mmdit_stream_t stream);

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupParams gp) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   int tm, tn, sk;
-  const Problem& p = locate_tile(gp, tm, tn, sk);   // split_k is always 1 on this path
+  const Problem& p = locate_tile(gp, blockIdx.x, tm, tn, sk);   // split_k is always 1 on this path
   const int m0 = tm * BM, n0 = tn * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -313,6 +313,8 @@ extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_
     if (stream_k) MMDIT_CHECK_ARG(!a->aux && !a->gate && a->stream_k);
   }
   gp.stream_k = stream_k; gp.total_units = units;
+  static const bool no_persist = getenv("MMDIT_GEMM_NO_PERSIST") != nullptr;
+  gp.persistent = !no_persist;
   if (aux_dt < 0) aux_dt = a0->c_dtype;
   gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = split_k;
   static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation: 1 = no DMA in the main loop, 2 = no LDS reads / MFMA

@@ -20,7 +20,7 @@ struct Problem {
 struct GroupParams {
   Problem p[MAXG];
   int count, total_tiles, act, accumulate, split_k, raster, debug, epi_direct;
-  int stream_k, total_units;   // stream-K: every workgroup gets an equal share of the (tile, K-tile) units
+  int stream_k, total_units, persistent;   // stream-K: every workgroup gets an equal share of the (tile, K-tile) units
 };
 
 // block id -> (problem, m-tile, n-tile, split-K slice).
@@ -29,8 +29,8 @@ struct GroupParams {
 //  * Rasterization inside a problem: tiles are walked in column groups of gp.raster n-tiles, m fastest between
 //    groups' rows, so that one group of B panels (raster*BN rows of the weight) stays L2-resident while the
 //    A row panels stream past it once.
-__device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int& tm, int& tn, int& sk) {
-  int b = blockIdx.x;
+__device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int work, int& tm, int& tn, int& sk) {
+  int b = work;
   sk = b % gp.split_k;
   b /= gp.split_k;
   const int T = gp.total_tiles, q = T / NXCD, r = T % NXCD, xcd = b % NXCD, j = b / NXCD;

@@ -58,14 +58,14 @@ __device__ __forceinline__ bf16x8 load_frag_sw(const char* tile, int r0, int ks,
 // one (tile, K-range) segment: accumulate K-tiles [kt0, kt1) of output tile (tm, tn) of problem p
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM>
 __device__ __forceinline__ void mainloop(const Problem& p, const GroupParams& gp, int m0, int n0, int kt0, int kt1, f32x16 (&acc)[MI][NJ],
-                                         char* smem, int wave, int lane, int wm, int wn) {
+                                         char* smem, int wave, int lane, int wm, int wn, bool prefetched = false) {
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
   constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
   const int M = p.M, N = p.N;
   const int64_t lda = p.lda, ldb = p.ldb;
-  if (kt0 < kt1) {
+  if (kt0 < kt1 && !prefetched) {   // prefetched: the previous tile of this persistent workgroup already issued K-tile kt0 into stage 0
     dma_tile<A_KM, TBM, NW>(A, lda, m0, kt0 * BK, M, smem, wave, lane);
     dma_tile<B_KM, TBN, NW>(B, ldb, n0, kt0 * BK, N, smem + A_BYTES, wave, lane);
   }
@@ -135,25 +135,47 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     return;
   }
 
-  int tm, tn, sk;
-  const Problem& p = locate_tile(gp, tm, tn, sk);
-  const int m0 = tm * TBM, n0 = tn * TBN;
+  // Persistent tile loop: a resident workgroup walks tiles blockIdx.x, +gridDim.x, ...  The first K-tile of the
+  // NEXT tile is DMA'd into stage 0 before the epilogue of the current one (cross-tile prefetch), so the prologue
+  // latency hides under the C stores; the epilogue stages C through stage 1.
+  constexpr int STAGE = (TBM + TBN) * 128, NW = WM * WN;
+  const int total = gp.total_tiles * gp.split_k;
+  bool pref = false;
+  for (int work = blockIdx.x; work < total; work += gridDim.x) {
+    int tm, tn, sk;
+    const Problem& p = locate_tile(gp, work, tm, tn, sk);
+    const int m0 = tm * TBM, n0 = tn * TBN;
 #pragma unroll
-  for (int i = 0; i < MI; i++)
+    for (int i = 0; i < MI; i++)
 #pragma unroll
-    for (int j = 0; j < NJ; j++)
+      for (int j = 0; j < NJ; j++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-  const int nk_all = p.K / BK, per = (nk_all + gp.split_k - 1) / gp.split_k;
-  const int kt0 = sk * per, kt1 = min(nk_all, kt0 + per);
-  mainloop<WM, WN, MI, NJ, A_KM, B_KM>(p, gp, m0, n0, kt0, kt1, acc, smem, wave, lane, wm, wn);
-  if (gp.epi_direct) epilogue_direct<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk);
-  else epilogue<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk, smem + wave * EP_WAVE_BYTES);
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+    const int nk_all = p.K / BK, per = (nk_all + gp.split_k - 1) / gp.split_k;
+    const int kt0 = sk * per, kt1 = min(nk_all, kt0 + per);
+    mainloop<WM, WN, MI, NJ, A_KM, B_KM>(p, gp, m0, n0, kt0, kt1, acc, smem, wave, lane, wm, wn, pref);
+    pref = false;
+    const int nwork = work + gridDim.x;
+    if (nwork < total && !(gp.debug & 4)) {
+      int tm2, tn2, sk2;
+      const Problem& q = locate_tile(gp, nwork, tm2, tn2, sk2);
+      const int nk2 = q.K / BK, per2 = (nk2 + gp.split_k - 1) / gp.split_k, k02 = sk2 * per2;
+      if (k02 < min(nk2, k02 + per2)) {
+        dma_tile<A_KM, TBM, NW>((const bf16_t*)q.A, q.lda, tm2 * TBM, k02 * BK, q.M, smem, wave, lane);
+        dma_tile<B_KM, TBN, NW>((const bf16_t*)q.B, q.ldb, tn2 * TBN, k02 * BK, q.N, smem + TBM * 128, wave, lane);
+        pref = true;
+      }
+    }
+    if (gp.epi_direct) epilogue_direct<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk);
+    else epilogue<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk, smem + STAGE + wave * EP_WAVE_BYTES);
+    __syncthreads();   // stage 1 (epilogue staging) is free again before the next tile's second K-tile lands in it
+  }
 }
 
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
 int launch_cfg(const GroupParams& gp, hipStream_t s) {
-  constexpr int smem = 2 * (WM * MI * 32 + WN * NJ * 32) * 128;
+  constexpr int stage = (WM * MI * 32 + WN * NJ * 32) * 128, ep = WM * WN * EP_WAVE_BYTES;
+  constexpr int smem = 2 * stage + (ep > stage ? ep - stage : 0);   // the epilogue stages C behind stage 0 (which may hold a prefetched K-tile)
   auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
@@ -162,7 +184,9 @@ int launch_cfg(const GroupParams& gp, hipStream_t s) {
     attr_done = true;
   }
   // stream-K: one resident workgroup per slot (256 CUs x workgroups that fit per CU by LDS)
-  const int grid = gp.stream_k ? 256 * (smem <= 65536 ? 2 : 1) : gp.total_tiles * gp.split_k;
+  const int slots = 256 * (smem <= 80 * 1024 ? 2 : 1);
+  const int work = gp.total_tiles * gp.split_k;
+  const int grid = gp.stream_k ? slots : (gp.persistent && work > slots ? slots : work);
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);
   return mmdit_launch_status();
 }

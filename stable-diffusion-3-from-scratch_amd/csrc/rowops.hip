@@ -439,7 +439,7 @@ constexpr int GR_RCH = 16;
 template <typename TA, typename TO>
 __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const float* __restrict__ dy, const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate,
                                                            int d, int rpb, int nchunk, TO* __restrict__ dacc,
-                                                           float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias) {
+                                                           float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias) {
   __shared__ float sbuf[1024];
   const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
   const int c = blockIdx.x * 1024 + tx * 8;
@@ -462,7 +462,7 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const float* __restri
     }
   }
   colsum_flush(sgate, sbuf, dgate + (int64_t)b * ld_dgate, c, d);
-  if (dbias) colsum_flush(sb, sbuf, dbias, c, d);
+  if (dbias) colsum_flush(sb, sbuf, dbias + (int64_t)b * ld_dbias, c, d);   // ld_dbias > 0: per-batch partial rows (low contention)
 }
 
 template <typename T>
@@ -663,7 +663,7 @@ extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void
   MMDIT_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr));
   hipStream_t s = (hipStream_t)stream;
   const int64_t total = (int64_t)batch * tokens * 3 * heads * 8;
-  dim3 grid(grid_cap(total, 256 * 8));
+  dim3 grid(grid_cap(total, 256 * 32));   // few, long-running blocks: every block ends with 128 atomics on the same two cache lines
 #define QKB(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<TG, TI, TO>), grid, dim3(256), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, total, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk)
   if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_BF16 && dqkv_dtype == MMDIT_BF16) QKB(bf16_t, bf16_t, bf16_t);
   else if (dq_dtype == MMDIT_F32 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(float, float, float);
@@ -710,13 +710,13 @@ extern "C" int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, vo
 }
 
 extern "C" int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, int rows, int d, int rpb,
-                                       void* dacc, int dacc_dtype, float* dgate, int64_t ld_dgate, float* dbias, mmdit_stream_t stream) {
+                                       void* dacc, int dacc_dtype, float* dgate, int64_t ld_dgate, float* dbias, int64_t ld_dbias, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(dy && acc && gate && dacc && dgate && rows > 0 && d % 8 == 0 && rpb > 0 && rows % rpb == 0 && ld_gate % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (rpb + GR_RCH - 1) / GR_RCH;
   dim3 grid((d + 1023) / 1024, (rows / rpb) * nchunk);
-  if (acc_dtype == MMDIT_BF16 && dacc_dtype == MMDIT_BF16) hipLaunchKernelGGL((gate_res_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, dy, (const bf16_t*)acc, gate, ld_gate, d, rpb, nchunk, (bf16_t*)dacc, dgate, ld_dgate, dbias);
-  else if (acc_dtype == MMDIT_F32 && dacc_dtype == MMDIT_F32) hipLaunchKernelGGL((gate_res_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, (const float*)acc, gate, ld_gate, d, rpb, nchunk, (float*)dacc, dgate, ld_dgate, dbias);
+  if (acc_dtype == MMDIT_BF16 && dacc_dtype == MMDIT_BF16) hipLaunchKernelGGL((gate_res_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, dy, (const bf16_t*)acc, gate, ld_gate, d, rpb, nchunk, (bf16_t*)dacc, dgate, ld_dgate, dbias, ld_dbias);
+  else if (acc_dtype == MMDIT_F32 && dacc_dtype == MMDIT_F32) hipLaunchKernelGGL((gate_res_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, (const float*)acc, gate, ld_gate, d, rpb, nchunk, (float*)dacc, dgate, ld_dgate, dbias, ld_dbias);
   else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }

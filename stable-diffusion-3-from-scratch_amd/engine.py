@@ -232,11 +232,13 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
     g = NS(mlp_x=NS(), mlp_c=NS() if both else None)
     # every atomically-accumulated small gradient of the block comes from ONE zeroed arena (one memset launch)
     hx = sv.gu_x.shape[1]
-    shapes = [tuple(sv.mod.shape), (d,), (hx,), (64,), (64,), (64,), (64,), (d,)] + ([(d,), (sv.gu_c.shape[1],)] if both else [])
+    nb = 2 if both else 1
+    shapes = [tuple(sv.mod.shape), (nb * d,), (hx,), (64,), (64,), (64,), (64,), (d,), (B, nb * d)] + ([(sv.gu_c.shape[1],)] if both else [])
     zs = _zeros_views(shapes, dev)
-    dmod, g.mlp_x.bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c, g.by = zs[:8]
+    dmod, bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c, g.by, bpart = zs[:9]   # bpart: per-batch partial rows of the down-proj bias grads
+    g.mlp_x.bdown = bdown[:d]
     if both:
-        g.mlp_c.bdown, g.mlp_c.bup = zs[8], zs[9]
+        g.mlp_c.bdown, g.mlp_c.bup = bdown[d:], zs[9]
     dms = _mod_views(dmod, d, w.last)
     pending = []   # deferred weight-gradient GEMMs: (setter, descriptor)
 
@@ -244,11 +246,12 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
         pending.append((lambda o, ns=ns, name=name: setattr(ns, name, o), _wg(dY, Xa)))
 
     # ---- MLP: gated residual -> down-proj -> activation -> up-proj -> adaLN
-    dacc_x = ops.gate_residual_bwd(dX2, sv.acc_mx, ms.gate2x, N, dms.gate2x, g.mlp_x.bdown, m.T)
+    dacc_x = ops.gate_residual_bwd(dX2, sv.acc_mx, ms.gate2x, N, dms.gate2x, bpart[:, :d], m.T)
     probs = [dict(A=dacc_x, B=w.mlp_x.Wdown, b_kmajor=True, out_dtype=m.T)]
     if both:
-        dacc_c = ops.gate_residual_bwd(dC2, sv.acc_mc, ms.gate2c, Mt, dms.gate2c, g.mlp_c.bdown, m.T)
+        dacc_c = ops.gate_residual_bwd(dC2, sv.acc_mc, ms.gate2c, Mt, dms.gate2c, bpart[:, d:], m.T)
         probs.append(dict(A=dacc_c, B=w.mlp_c.Wdown, b_kmajor=True, out_dtype=m.T))
+    ops.colsum(bpart, bdown)   # finish both bias gradients: sum the per-batch partial rows
     dh = _group(m, probs)
     defer(g.mlp_x, "Wdown", dacc_x, sv.h_x)
     dgu_x = ops.mlp_act_bwd(dh[0], sv.gu_x, w.mlp_x.hidden, g.mlp_x.bup, w.mlp_x.gelu)

@@ -214,10 +214,12 @@ def silu_bwd(dy, pre, out_dtype, dbias):
 
 
 def gate_residual_bwd(dy, acc, gate, rows_per_batch, dgate, dbias, out_dtype):
+    """dbias: None, a (d,) vector, or a (batch, d) view of per-batch partial rows (column-sum it afterwards)."""
     rows, d = dy.shape
     dacc = torch.empty((rows, d), dtype=out_dtype, device=dy.device)
+    ld_dbias = dbias.stride(0) if (dbias is not None and dbias.dim() == 2) else 0
     check(_lib.lib().mmdit_gate_residual_bwd(_p(_c(dy)), _p(acc), _dt(acc), _p(gate), gate.stride(0), rows, d, rows_per_batch,
-                                             _p(dacc), _dt(dacc), _p(dgate), dgate.stride(0), _p(dbias), _s()), "mmdit_gate_residual_bwd")
+                                             _p(dacc), _dt(dacc), _p(dgate), dgate.stride(0), _p(dbias), ld_dbias, _s()), "mmdit_gate_residual_bwd")
     return dacc
 
 
