@@ -82,6 +82,11 @@ int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
  * precision, act, accumulate, aux dtype) share one grid, e.g. the image and the text stream of a block
  * (Attention.py:130-135 issues them as separate Linears) or all weight-gradient GEMMs of a block. */
 int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream);
+/* Which kernel mmdit_gemm_grouped would launch for these problems (no launch): 64 = register-staged kernel (gemm.hip);
+ * otherwise the LDS-DMA kernel (gemm_dma.hip) with tile configuration (value & 15): 0 = 128x128, 1 = 256x128,
+ * 2 = 256x256, plus 16 if the stream-K decomposition is used.  Negative = the MMDIT_ERR_* the launch would return.
+ * Lets profilers / benchmarks attribute timings to the exact kernel symbol. */
+int mmdit_gemm_plan(const mmdit_gemm_args* args, int count);
 
 /* dtype conversion of n elements (bf16 shadow copies of the fp32 master weights; the
  * reference gets these from torch.autocast, model_trainer.py:416). n%8==0 not required. */

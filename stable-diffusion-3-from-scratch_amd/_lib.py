@@ -8,7 +8,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmdit_hip.so")
+LIB_PATH = os.environ.get("MMDIT_LIB") or os.path.join(_HERE, "libmmdit_hip.so")   # MMDIT_LIB: A/B a scratch build
 HEADER_PATH = os.path.join(_HERE, "..", "include", "mmdit_hip.h")
 
 F32, BF16 = 0, 1
@@ -42,6 +42,7 @@ _SIGNATURES = {
     "mmdit_build_arch": ([], ctypes.c_char_p),
     "mmdit_gemm": ([ctypes.POINTER(GemmArgs), _vp], _i),
     "mmdit_gemm_grouped": ([ctypes.POINTER(GemmArgs), _i, _vp], _i),
+    "mmdit_gemm_plan": ([ctypes.POINTER(GemmArgs), _i], _i),
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),

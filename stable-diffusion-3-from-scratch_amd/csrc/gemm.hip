@@ -265,7 +265,7 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
   return c256 < c128 ? CFG_256x256 : CFG_128x128;
 }
 
-extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) {
+static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only) {
   MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
   const mmdit_gemm_args* a0 = &args[0];
   GroupParams gp;
@@ -288,6 +288,8 @@ extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_
     if (a->K % BK != 0) dma = false;
     if (a->a_kmajor && a->M < 8) dma = false;
     if (a->b_kmajor && a->N < 8) dma = false;
+    // the DMA kernel addresses an operand as a wave-uniform 64-bit base + a 32-bit per-lane byte offset
+    if ((int64_t)(a->a_kmajor ? a->K : a->M) * a->lda * 2 >= (1ll << 32) || (int64_t)(a->b_kmajor ? a->K : a->N) * a->ldb * 2 >= (1ll << 32)) dma = false;
   }
   int bm = BM, bn = BN, cfg = CFG_128x128;
   // stream-K for the weight gradients (k-major A): fp32 C must be pre-zeroed by the caller (a0->stream_k)
@@ -317,7 +319,7 @@ extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_
   gp.persistent = !no_persist;
   if (aux_dt < 0) aux_dt = a0->c_dtype;
   gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = split_k;
-  static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation: 1 = no DMA in the main loop, 2 = no LDS reads / MFMA
+  static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation bits: 1 = no DMA in the main loop, 2 = no LDS reads / MFMA, 4 = no cross-tile prefetch, 8 = no epilogue
   gp.debug = debug_env ? atoi(debug_env) : 0;
   static const char* epi_env = getenv("MMDIT_GEMM_EPI");
   gp.epi_direct = epi_env ? (atoi(epi_env) == 0) : 0;
@@ -327,12 +329,17 @@ extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_
     MMDIT_CHECK_ARG(dma && a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE && !a0->accumulate && split_k <= 64);
     for (int i = 0; i < count; i++) MMDIT_CHECK_ARG(!args[i].aux && !args[i].gate);
   }
+  if (plan_only) return dma ? (cfg | (stream_k ? 16 : 0)) : 64;   // see mmdit_gemm_plan
   hipStream_t s = (hipStream_t)stream;
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a0, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_SPLIT && a0->a_dtype == MMDIT_F32 && a0->b_dtype == MMDIT_F32) return dispatch_out<float, float, true>(a0, aux_dt, gp, s);
   return MMDIT_ERR_DTYPE;
 }
+
+extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) { return gemm_grouped_impl(args, count, stream, false); }
+
+extern "C" int mmdit_gemm_plan(const mmdit_gemm_args* args, int count) { return gemm_grouped_impl(args, count, nullptr, true); }
 
 extern "C" int mmdit_gemm(const mmdit_gemm_args* a, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(a);

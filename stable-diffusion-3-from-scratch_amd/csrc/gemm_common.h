@@ -30,11 +30,13 @@ struct GroupParams {
 //    groups' rows, so that one group of B panels (raster*BN rows of the weight) stays L2-resident while the
 //    A row panels stream past it once.
 __device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int work, int& tm, int& tn, int& sk) {
-  int b = work;
-  sk = b % gp.split_k;
-  b /= gp.split_k;
-  const int T = gp.total_tiles, q = T / NXCD, r = T % NXCD, xcd = b % NXCD, j = b / NXCD;
-  int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  // work index -> contiguous range per XCD; inside it the split-K slice is the SLOW index (k-chunk-major): with
+  // split_k = 8 every XCD owns one K-chunk of ALL tiles, so each operand panel is fetched from HBM once per chunk
+  // instead of once per tile (weight gradients: 3.0 GB -> ~0.8 GB per launch).
+  const int T = gp.total_tiles, W = T * gp.split_k, q = W / NXCD, r = W % NXCD, xcd = work % NXCD, j = work / NXCD;
+  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  sk = lin / T;
+  int t = lin - sk * T;
   int pi = 0;
 #pragma unroll 1
   for (int i = 1; i < gp.count; i++) pi = (t >= gp.p[i].tile_start) ? i : pi;

@@ -1,50 +1,65 @@
 // LDS-DMA MFMA GEMM kernels for gfx950 (bf16 operands, K % 64 == 0): the fast path of mmdit_gemm*.
 //
-// Operands go HBM/L2 -> LDS directly with global_load_lds (16 B per lane): no VGPR staging, no ds_write
-// traffic (the register-staged kernel in gemm.hip spends ~830 LDS-pipe cycles per K-tile pair on
-// ds_write_b128 against 1024 MFMA cycles).  The LDS image of a DMA is lane-linear (wave-uniform base +
-// lane*16), so tiles are unpadded and the bank-conflict swizzle is applied to the per-lane SOURCE address
-// and mirrored in the fragment reads:
-//   row-major tile [R][64] bf16 (128 B rows):    16-B piece p of row r   lives at slot p ^ ((r>>1)&7)
-//   k-major  tile [64][R] bf16 (2R-byte k-rows): 16-B piece p of k-row k lives at slot p ^ ((k&3)<<2)
+// Operands go HBM/L2 -> LDS directly with global_load_lds (16 B per lane): no VGPR staging, no ds_write traffic.
+// The LDS image of a DMA is lane-linear (wave-uniform base + lane*16), so tiles are unpadded and the
+// bank-conflict swizzle is applied to the per-lane SOURCE address and mirrored in the fragment reads:
+//   row-major half-tile [R][32] bf16 (64 B rows):    16-B piece p of row r   lives at slot p ^ ((r>>2)&3)
+//   k-major  half-tile [32][R] bf16 (2R-byte k-rows): 16-B piece p of k-row k lives at slot p ^ ((k&3)<<2)
 // (ds_read_b128 fragments of the first and ds_read_b64_tr_b16 fragments of the second are then conflict-free.)
 // Rows beyond M / N are clamped to valid addresses (their results are never stored).
 //
+// Pipeline.  A workgroup consumes a STREAM of 32-wide K "halves" that runs across its output tiles (persistent
+// tile loop, or stream-K segments).  The halves live in a 4-slot LDS ring; the DMA cursor runs 3 halves ahead of
+// the MFMAs.  One LDS-DMA piece costs its wave ~60-180 issue cycles, so the pieces of half g+3 are spread
+// BETWEEN the MFMA rows of half g (issued in a burst they serialise with the MFMAs: measured 81 us of DMA +
+// 130 us of MFMA = 219 us for the w12 GEMM).  Per half: s_waitcnt vmcnt(<pieces of the younger halves>) + one
+// s_barrier.  Fragment reads are software-pipelined in registers (B double-buffered, A reloaded behind its
+// last MFMA) and get counted lgkmcnt waits.  The epilogue of a tile is deferred until the first half of the
+// next tile has landed, so its stores drain under the following MFMAs; it stages C through a wave-private,
+// XOR-swizzled 4-KiB LDS block that is not part of the ring (no barrier around it).
+//
 // Tile configurations (threads = 64 * WM * WN, each wave owns an (MI*32) x (NJ*32) sub-tile):
-//   128x128: 4 waves 2x2, 2x2 accumulators, 64 KB LDS (2 workgroups / CU)
-//   256x128: 8 waves 4x2, 2x2 accumulators, 96 KB LDS
-//   256x256: 8 waves 2x4, 4x2 accumulators, 128 KB LDS  -- half the L2->CU bytes per FLOP of 128x128
-// Two LDS stages; the DMA of K-tile k+1 is in flight while K-tile k is multiplied.
+//   128x128: 4 waves 2x2, 2x2 accumulators,  80 KB LDS (2 workgroups / CU)
+//   256x128: 8 waves 4x2, 2x2 accumulators, 128 KB LDS
+//   256x256: 8 waves 2x4, 4x2 accumulators, 160 KB LDS  -- half the L2->CU bytes per FLOP of 128x128
 #include "gemm_common.h"
 
 using namespace gemm;
 
 namespace {
 
-template <bool KM, int R, int NW>
-__device__ __forceinline__ void dma_tile(const bf16_t* base, int64_t ld, int row0, int k0, int rows, char* tile, int wave, int lane) {
-  constexpr int NCH = R / 8;            // 1-KiB chunks per tile
-  constexpr int PPR = R / 8;            // 16-B pieces per k-row of a k-major tile
-#pragma unroll
-  for (int i = 0; i < NCH / NW; i++) {
-    const int c = wave * (NCH / NW) + i;
-    const bf16_t* src;
-    if (!KM) {
-      const int r = 8 * c + (lane >> 3), slot = lane & 7, piece = slot ^ ((r >> 1) & 7);
-      src = base + (int64_t)min(row0 + r, rows - 1) * ld + k0 + piece * 8;
-    } else {
-      const int k = c * (64 / PPR) + lane / PPR, slot = lane % PPR, piece = slot ^ ((k & 3) << 2);
-      src = base + (int64_t)(k0 + k) * ld + min(row0 + piece * 8, rows - 8);
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, LDS_PTR(void, tile + c * 1024), 16, 0, 0);
+constexpr int BKH = 32;              // K extent of one ring slot (half of the 64-wide K-tile the host plans in)
+constexpr int RING = 4;              // slots; DMA distance = RING - 1 halves
+constexpr int EP32_WAVE_BYTES = 4096;
+
+// byte offset (from the operand's half-tile base pointer) of the 16 B this lane sources for 1-KiB piece c
+template <bool KM, int R>
+__device__ __forceinline__ uint32_t piece_voff(int c, int lane, int64_t ld, int row0, int rows) {
+  if (!KM) {
+    const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);   // (r>>2)&3 == (lane>>4)&3
+    return (uint32_t)((int64_t)min(row0 + r, rows - 1) * ld * 2 + piece * 16);
+  } else {
+    constexpr int PPR = R / 8;       // 16-B pieces per k-row
+    const int k = c * (64 / PPR) + lane / PPR, slot = lane % PPR, piece = slot ^ ((k & 3) << 2);
+    return (uint32_t)((int64_t)k * ld * 2 + (int64_t)min(row0 + piece * 8, rows - 8) * 2);
   }
 }
 
+// Issued as inline asm on purpose: the compiler's waitcnt pass treats the global_load_lds builtin as a FLAT access
+// that is pending on both counters and then degrades every LDS-read wait of the main loop to lgkmcnt(0); hidden from
+// it, the fragment reads get counted waits.  Completion is tracked by hand (s_waitcnt vmcnt + s_barrier in half_sync).
+__device__ __forceinline__ void glds16(uint32_t voff, const char* sbase_, uint32_t lds_dst_) {
+  const uint64_t a = (uint64_t)(uintptr_t)sbase_;   // wave-uniform by construction; make that explicit for the "s" operands
+  const char* sbase = (const char*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a));
+  const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
 template <bool KM, int R>
-__device__ __forceinline__ bf16x8 load_frag_sw(const char* tile, int r0, int ks, int lane) {
+__device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int r0, int ks, int lane) {
   if (!KM) {
     const int r = r0 + (lane & 31), kp = ks * 2 + (lane >> 5);
-    return *LDS_PTR(const bf16x8, tile + r * 128 + ((kp ^ ((r >> 1) & 7)) << 4));
+    return *LDS_PTR(const bf16x8, tile + r * 64 + ((kp ^ ((r >> 2) & 3)) << 4));
   } else {
     const int kr = ks * 16 + (lane >> 5) * 8 + ((lane & 15) >> 2);
     const int bcol = (r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
@@ -55,127 +70,316 @@ __device__ __forceinline__ bf16x8 load_frag_sw(const char* tile, int r0, int ks,
   }
 }
 
-// one (tile, K-range) segment: accumulate K-tiles [kt0, kt1) of output tile (tm, tn) of problem p
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM>
-__device__ __forceinline__ void mainloop(const Problem& p, const GroupParams& gp, int m0, int n0, int kt0, int kt1, f32x16 (&acc)[MI][NJ],
-                                         char* smem, int wave, int lane, int wm, int wn, bool prefetched = false) {
-  constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
-  constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
-  const bf16_t* A = (const bf16_t*)p.A;
-  const bf16_t* B = (const bf16_t*)p.B;
-  const int M = p.M, N = p.N;
-  const int64_t lda = p.lda, ldb = p.ldb;
-  if (kt0 < kt1 && !prefetched) {   // prefetched: the previous tile of this persistent workgroup already issued K-tile kt0 into stage 0
-    dma_tile<A_KM, TBM, NW>(A, lda, m0, kt0 * BK, M, smem, wave, lane);
-    dma_tile<B_KM, TBN, NW>(B, ldb, n0, kt0 * BK, N, smem + A_BYTES, wave, lane);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = kt0; kt < kt1; kt++) {
-    const int cur = (kt - kt0) & 1;
-    char* nxt = smem + (cur ^ 1) * STAGE;
-    if (kt + 1 < kt1 && !(gp.debug & 1)) {
-      dma_tile<A_KM, TBM, NW>(A, lda, m0, (kt + 1) * BK, M, nxt, wave, lane);
-      dma_tile<B_KM, TBN, NW>(B, ldb, n0, (kt + 1) * BK, N, nxt + A_BYTES, wave, lane);
+// Epilogue (see gemm_common.h for the arithmetic).  acc[i][j] holds a C^T fragment (lane = output row); each
+// 32x32 block goes through the wave's 4-KiB staging block (16-B chunk c of row r at chunk c ^ (r&7): conflict-free
+// ds_write_b128 / ds_read_b128) and leaves as 8 rows x 128 B (fp32) / 64 B (bf16) per wave instruction.
+template <typename TC, typename TAUX, int MI, int NJ>
+__device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
+                                           int lane, int sk, char* stage, bool atomic_out) {
+  TC* C = (TC*)p.C;
+  TAUX* AUX = (TAUX*)p.aux;
+  const bool first = sk == 0;
+  const float* bias = first ? p.bias : nullptr;
+  const float* gate = p.gate;
+  const float* res = first ? p.residual : nullptr;
+  const int wr = lane & 31, wc = lane >> 5;          // write side: row, 16-B chunk parity
+  const int rr = lane >> 3, rc = lane & 7;           // read side: row within the 8-row pass, 16-B chunk
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *LDS_PTR(f32x4, stage + wr * 128 + (((2 * g + wc) ^ (wr & 7)) << 4)) =
+            (f32x4){acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+      const int col = n0 + wn * (NJ * 32) + j * 32 + rc * 4;
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias && col < p.N) ld4(bias + col, b4);
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = m0 + wm * (MI * 32) + i * 32 + r;
+        if (row >= p.M || col >= p.N) continue;
+        float v[4] = {t[0] + b4[0], t[1] + b4[1], t[2] + b4[2], t[3] + b4[3]};
+        if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
+        if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        if (res) {
+          float r4[4];
+          ld4(res + (int64_t)row * p.ld_res + col, r4);
+          if (gate) {
+            float g4[4];
+            ld4(gate + (int64_t)(row / p.rows_per_batch) * p.ld_gate + col, g4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = r4[e] + g4[e] * v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += r4[e];
+          }
+        }
+        TC* cp = C + (int64_t)row * p.ldc + col;
+        if constexpr (sizeof(TC) == 4) {
+          if (gp.split_k > 1 || atomic_out) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) atomicAdd((float*)cp + e, v[e]);
+            continue;
+          }
+        }
+        if (gp.accumulate) {
+          float c4v[4];
+          ld4(cp, c4v);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += c4v[e];
+        }
+        st4(cp, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
     }
-    const char* ta = smem + cur * STAGE;
-    const char* tb = ta + A_BYTES;
-    if (!(gp.debug & 2))
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ks++) {
-      bf16x8 a[MI], b[NJ];
-#pragma unroll
-      for (int i = 0; i < MI; i++) a[i] = load_frag_sw<A_KM, TBM>(ta, wm * (MI * 32) + i * 32, ks, lane);
-#pragma unroll
-      for (int j = 0; j < NJ; j++) b[j] = load_frag_sw<B_KM, TBN>(tb, wn * (NJ * 32) + j * 32, ks, lane);
-      // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m
-#pragma unroll
-      for (int i = 0; i < MI; i++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // also releases the operand LDS for the epilogue / the next segment
   }
+}
+
+// one unit of work of a workgroup: K halves [h0, h1) of output tile (tm, tn) of problem p
+struct Item {
+  int pi;   // problem index (kept as an index so that every access stays a scalar kernarg load)
+  int tm, tn, h0, h1, sk;
+  int pos;
+  bool valid;
+};
+
+__device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end) {
+  Item it;
+  it.pos = pos;
+  it.valid = pos < end;
+  it.pi = 0;
+  it.tm = it.tn = it.h0 = it.h1 = it.sk = 0;
+  if (!it.valid) return it;
+  if (gp.stream_k) {
+    // stream-K: the (tile, K-tile) units of all problems are split evenly over the resident workgroups; a workgroup
+    // walks its contiguous unit range [pos, end) segment by segment and adds each partial tile atomically into the
+    // pre-zeroed fp32 C.  Used for the weight gradients: few output tiles, very long reductions.
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < gp.count; i++) pi = (pos >= gp.p[i].unit_start) ? i : pi;
+    const Problem& p = gp.p[pi];
+    const int local = pos - p.unit_start, t = local / p.nk, k0 = local - t * p.nk, k1 = min(p.nk, k0 + (end - pos));
+    it.pi = pi;
+    it.tm = t / p.tiles_n;
+    it.tn = t - it.tm * p.tiles_n;
+    it.h0 = 2 * k0;
+    it.h1 = 2 * k1;
+    it.sk = k0 == 0 ? 0 : 1;
+  } else {
+    int sk;
+    const Problem& p = locate_tile(gp, pos, it.tm, it.tn, sk);
+    const int nk_all = p.K / BK, per = (nk_all + gp.split_k - 1) / gp.split_k;
+    const int kt0 = sk * per, kt1 = max(kt0, min(nk_all, kt0 + per));
+    it.pi = (int)(&p - &gp.p[0]);
+    it.h0 = 2 * kt0;
+    it.h1 = 2 * kt1;
+    it.sk = sk;
+  }
+  return it;
+}
+
+__device__ __forceinline__ int next_pos(const GroupParams& gp, const Item& it) {
+  return gp.stream_k ? it.pos + (it.h1 - it.h0) / 2 : it.pos + (int)gridDim.x;
 }
 
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) {
-  constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32;
+  constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
+  constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB;      // bytes of one ring slot
+  constexpr int PA = TBM / 16 / NW, PB = TBN / 16 / NW, PP = PA + PB;   // 1-KiB DMA pieces per wave and half
+  constexpr int DSTRIDE = (2 * MI) / PP > 0 ? (2 * MI) / PP : 1;       // MFMA rows between two pieces
+  static_assert(PA >= 1 && PB >= 1 && PP <= 2 * MI && PP <= 4, "piece schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  f32x16 acc[MI][NJ];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  char* stage = smem + RING * H + wave * EP32_WAVE_BYTES;
 
+  int pos, end;
   if (gp.stream_k) {
-    // stream-K: the (tile, K-tile) units of all problems are split evenly over the resident workgroups; a
-    // workgroup walks its contiguous unit range segment by segment and adds each partial tile atomically into
-    // the pre-zeroed fp32 C.  Used for the weight gradients: few output tiles, very long reductions.
     const long long U = gp.total_units, G = gridDim.x;
-    int u = (int)(blockIdx.x * U / G);
-    const int u_end = (int)((blockIdx.x + 1) * U / G);
-    while (u < u_end) {
-      int pi = 0;
-#pragma unroll 1
-      for (int i = 1; i < gp.count; i++) pi = (u >= gp.p[i].unit_start) ? i : pi;
-      const Problem& p = gp.p[pi];
-      const int local = u - p.unit_start, t = local / p.nk, k0 = local - t * p.nk, k1 = min(p.nk, k0 + (u_end - u));
-      const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-#pragma unroll
-      for (int i = 0; i < MI; i++)
-#pragma unroll
-        for (int j = 0; j < NJ; j++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-      mainloop<WM, WN, MI, NJ, A_KM, B_KM>(p, gp, tm * TBM, tn * TBN, k0, k1, acc, smem, wave, lane, wm, wn);
-      epilogue<TC, TAUX, MI, NJ>(acc, p, gp, tm * TBM, tn * TBN, wm, wn, lane, k0 == 0 ? 0 : 1, smem + wave * EP_WAVE_BYTES, true);
-      __syncthreads();   // epilogue staging reads done before the next segment's DMA overwrites the LDS
-      u += k1 - k0;
-    }
-    return;
+    pos = (int)(blockIdx.x * U / G);
+    end = (int)((blockIdx.x + 1) * U / G);
+  } else {
+    pos = blockIdx.x;
+    end = gp.total_tiles * gp.split_k;
   }
 
-  // Persistent tile loop: a resident workgroup walks tiles blockIdx.x, +gridDim.x, ...  The first K-tile of the
-  // NEXT tile is DMA'd into stage 0 before the epilogue of the current one (cross-tile prefetch), so the prologue
-  // latency hides under the C stores; the epilogue stages C through stage 1.
-  constexpr int STAGE = (TBM + TBN) * 128, NW = WM * WN;
-  const int total = gp.total_tiles * gp.split_k;
-  bool pref = false;
-  for (int work = blockIdx.x; work < total; work += gridDim.x) {
-    int tm, tn, sk;
-    const Problem& p = locate_tile(gp, work, tm, tn, sk);
-    const int m0 = tm * TBM, n0 = tn * TBN;
+  // ---- DMA cursor: (item, half) the next issued half belongs to --------------------------------------------
+  Item cit = item_at(gp, pos, end);
+  while (cit.valid && cit.h0 >= cit.h1) cit = item_at(gp, next_pos(gp, cit), end);
+  int ch = cit.h0;
+  uint32_t va[PA], vb[PB];
+  const char* sa = nullptr;
+  const char* sb = nullptr;
+  int64_t stepa = 0, stepb = 0;
+  auto cursor_setup = [&]() {
+    const Problem& q = gp.p[cit.pi];
+#pragma unroll
+    for (int i = 0; i < PA; i++) va[i] = piece_voff<A_KM, TBM>(wave * PA + i, lane, q.lda, cit.tm * TBM, q.M);
+#pragma unroll
+    for (int i = 0; i < PB; i++) vb[i] = piece_voff<B_KM, TBN>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
+    stepa = A_KM ? (int64_t)BKH * q.lda * 2 : BKH * 2;
+    stepb = B_KM ? (int64_t)BKH * q.ldb * 2 : BKH * 2;
+    sa = (const char*)q.A + ch * stepa;
+    sb = (const char*)q.B + ch * stepb;
+  };
+  // after the last half of the stream the cursor stays where it is: the steady-state loop keeps issuing (it re-reads
+  // that half into a free slot) so that the loop body is branch-free and exactly PP pieces are issued per half
+  auto cursor_advance = [&]() {
+    if (!cit.valid) return;
+    if (ch + 1 < cit.h1) {
+      ch++;
+      sa += stepa;
+      sb += stepb;
+      return;
+    }
+    Item nx = cit;
+    do nx = item_at(gp, next_pos(gp, nx), end); while (nx.valid && nx.h0 >= nx.h1);
+    if (nx.valid) {
+      cit = nx;
+      ch = cit.h0;
+      cursor_setup();
+    } else {
+      cit.valid = false;
+    }
+  };
+  auto issue_piece = [&](int q, int slot) {   // q: compile-time piece index of the cursor's half
+    const uint32_t dst = lds0 + slot * H;
+    if (q < PA) glds16(va[q], sa, dst + (wave * PA + q) * 1024);
+    else glds16(vb[q - PA], sb, dst + HA + (wave * PB + (q - PA)) * 1024);
+  };
+
+  f32x16 acc[MI][NJ];
+  auto zero_acc = [&]() {
 #pragma unroll
     for (int i = 0; i < MI; i++)
 #pragma unroll
       for (int j = 0; j < NJ; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
-    const int nk_all = p.K / BK, per = (nk_all + gp.split_k - 1) / gp.split_k;
-    const int kt0 = sk * per, kt1 = min(nk_all, kt0 + per);
-    mainloop<WM, WN, MI, NJ, A_KM, B_KM>(p, gp, m0, n0, kt0, kt1, acc, smem, wave, lane, wm, wn, pref);
-    pref = false;
-    const int nwork = work + gridDim.x;
-    if (nwork < total && !(gp.debug & 4)) {
-      int tm2, tn2, sk2;
-      const Problem& q = locate_tile(gp, nwork, tm2, tn2, sk2);
-      const int nk2 = q.K / BK, per2 = (nk2 + gp.split_k - 1) / gp.split_k, k02 = sk2 * per2;
-      if (k02 < min(nk2, k02 + per2)) {
-        dma_tile<A_KM, TBM, NW>((const bf16_t*)q.A, q.lda, tm2 * TBM, k02 * BK, q.M, smem, wave, lane);
-        dma_tile<B_KM, TBN, NW>((const bf16_t*)q.B, q.ldb, tn2 * TBN, k02 * BK, q.N, smem + TBM * 128, wave, lane);
-        pref = true;
+  };
+  auto run_epilogue = [&](const Item& it) {   // reads the accumulators only (the zeroing that follows is unconditional code)
+    if (!(gp.debug & 8)) epilogue32<TC, TAUX, MI, NJ>(acc, gp.p[it.pi], gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, gp.stream_k != 0);
+    else if (acc[0][0][0] == 12345.678f) ((float*)gp.p[it.pi].C)[0] = 0.f;   // ablation: keep the accumulators live
+  };
+
+  const bool any = cit.valid;   // false: this workgroup only has empty split-K slices (or nothing)
+  int issued = 0, done = 0;
+  if (any) {
+    cursor_setup();
+#pragma unroll 1
+    for (int s = 0; s < RING - 1; s++) {
+#pragma unroll
+      for (int q = 0; q < PP; q++) issue_piece(q, issued & (RING - 1));
+      issued++;
+      cursor_advance();
+    }
+  }
+
+  // Fragment registers are carried from half to half: the last k-step of a half already reads the first fragments
+  // of the NEXT half (which half_sync made visible one half early), so no half starts with an exposed LDS burst.
+  // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m
+  bf16x8 a[MI], b[2][NJ];
+  // one K half: multiply slot done&3 while the PP pieces of the cursor's half go into slot issued&3 (= (done-1)&3,
+  // which every wave left before the barrier of half_sync).  No data-dependent branch inside.
+  auto half_body = [&]() {
+    const int dslot = issued & (RING - 1);
+    const char* ta = smem + (done & (RING - 1)) * H;
+    const char* tb = ta + HA;
+    const char* na = smem + ((done + 1) & (RING - 1)) * H;   // (after the last half of the stream: read, never used)
+    const char* nb = na + HA;
+#pragma unroll
+    for (int ks = 0; ks < BKH / 16; ks++) {
+      const int c = ks & 1, nx = c ^ 1;
+      const bool last = ks + 1 == BKH / 16;
+      // B fragments are double-buffered, each A fragment is reloaded right after the last MFMA that reads it; the
+      // order is pinned so every ds_read has MFMAs of cover and gets a counted lgkmcnt wait.
+#pragma unroll
+      for (int j = 0; j < NJ; j++) b[nx][j] = load_frag_h<B_KM, TBN>(last ? nb : tb, wn * (NJ * 32) + j * 32, last ? 0 : ks + 1, lane);
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
+        a[i] = load_frag_h<A_KM, TBM>(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1, lane);
+        const int q = ks * MI + i;   // compile-time after unrolling
+        if (q % DSTRIDE == 0 && q / DSTRIDE < PP) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(q / DSTRIDE, dslot);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    issued++;
+    cursor_advance();
+    done++;
+  };
+  auto half_body_nocompute = [&]() {   // ablation (MMDIT_GEMM_DEBUG & 2): DMA stream only
+#pragma unroll
+    for (int q = 0; q < PP; q++) issue_piece(q, issued & (RING - 1));
+    issued++;
+    cursor_advance();
+    done++;
+  };
+  auto half_sync = [&]() {
+    // exactly RING-1 halves are in flight here (done .. done+2): halves done and done+1 have landed once only the PP
+    // pieces of half done+2 may still be outstanding (loads retire in order; stores only make the wait conservative)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left half done-1, whose slot the DMA below refills
+  };
+
+  Item item = item_at(gp, pos, end), prev = item;
+  bool pending = false;
+  const bool compute = !(gp.debug & 2);
+  while (item.valid) {
+    const int n = item.h1 - item.h0;
+    if (n > 0) half_sync();
+    // the previous tile's epilogue is deferred to here: its stores drain under the MFMAs that follow
+    if (pending) run_epilogue(prev);
+    zero_acc();
+    if (n > 0) {
+      if (compute) {
+        // the fragments of a tile's first half: carried over from the previous tile, except at the start of the stream
+        if (done == 0) {
+          const char* ta = smem;
+#pragma unroll
+          for (int j = 0; j < NJ; j++) b[0][j] = load_frag_h<B_KM, TBN>(ta + HA, wn * (NJ * 32) + j * 32, 0, lane);
+#pragma unroll
+          for (int i = 0; i < MI; i++) a[i] = load_frag_h<A_KM, TBM>(ta, wm * (MI * 32) + i * 32, 0, lane);
+        }
+        half_body();
+#pragma unroll 1
+        for (int u = 1; u < n; u++) {
+          half_sync();
+          half_body();
+        }
+      } else {
+#pragma unroll 1
+        for (int u = 0; u < n; u++) {
+          if (u) half_sync();
+          half_body_nocompute();
+        }
       }
     }
-    if (gp.epi_direct) epilogue_direct<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk);
-    else epilogue<TC, TAUX, MI, NJ>(acc, p, gp, m0, n0, wm, wn, lane, sk, smem + STAGE + wave * EP_WAVE_BYTES);
-    __syncthreads();   // stage 1 (epilogue staging) is free again before the next tile's second K-tile lands in it
+    pending = true;   // (an empty split-K slice still contributes its epilogue terms)
+    prev = item;
+    item = item_at(gp, next_pos(gp, item), end);
   }
+  if (pending) run_epilogue(prev);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (unused) DMA pieces must land before the LDS is released
 }
 
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
 int launch_cfg(const GroupParams& gp, hipStream_t s) {
-  constexpr int stage = (WM * MI * 32 + WN * NJ * 32) * 128, ep = WM * WN * EP_WAVE_BYTES;
-  constexpr int smem = 2 * stage + (ep > stage ? ep - stage : 0);   // the epilogue stages C behind stage 0 (which may hold a prefetched K-tile)
+  constexpr int smem = RING * (WM * MI * 32 + WN * NJ * 32) * 64 + WM * WN * EP32_WAVE_BYTES;
   auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
@@ -183,7 +387,7 @@ int launch_cfg(const GroupParams& gp, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  // stream-K: one resident workgroup per slot (256 CUs x workgroups that fit per CU by LDS)
+  // one resident workgroup per slot (256 CUs x workgroups that fit per CU by LDS)
   const int slots = 256 * (smem <= 80 * 1024 ? 2 : 1);
   const int work = gp.total_tiles * gp.split_k;
   const int grid = gp.stream_k ? slots : (gp.persistent && work > slots ? slots : work);

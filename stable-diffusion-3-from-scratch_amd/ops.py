@@ -83,9 +83,21 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     return out
 
 
-def _variant(a, out):
-    layout = "nt" if not (a.a_kmajor or a.b_kmajor) else ("dgrad" if not a.a_kmajor else "wgrad")
-    return f"gemm_{layout}_{'bf16' if a.precision == PREC_BF16 else 'split'}_c{_dt(out)}"
+_CFG = {0: "2,2,2,2", 1: "4,2,2,2", 2: "2,4,4,2"}
+
+
+def _variant(arr, n, outs):
+    """Name of the kernel symbol (template instantiation) mmdit_gemm_grouped launches for these problems."""
+    a = arr[0]
+    plan = _lib.lib().mmdit_gemm_plan(arr, n)
+    tc = "f" if _dt(outs[0]) == F32 else "t"
+    aux = [arr[i].aux_dtype for i in range(n) if arr[i].aux]
+    ta = ("f" if aux[0] == F32 else "t") if aux else tc
+    km = f"{int(bool(a.a_kmajor))},{int(bool(a.b_kmajor))}"
+    if plan == 64:
+        ab = "t,t" if a.precision == PREC_BF16 else "f,f"
+        return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
+    return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "")
 
 
 def gemm_grouped(problems):
@@ -99,7 +111,7 @@ def gemm_grouped(problems):
         e0.record()
         check(_lib.lib().mmdit_gemm_grouped(arr, n, _s()), "mmdit_gemm_grouped")
         e1.record()
-        PROFILE.append((_variant(arr[0], outs[0]), sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
+        PROFILE.append((_variant(arr, n, outs), sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
         return outs
     check(_lib.lib().mmdit_gemm_grouped(arr, n, _s()), "mmdit_gemm_grouped")
     return outs
