@@ -315,10 +315,37 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     if (stream_k) MMDIT_CHECK_ARG(!a->aux && !a->gate && a->stream_k);
   }
   gp.stream_k = stream_k; gp.total_units = units;
+  // K-decomposition for the weight gradients (few output tiles, very long reductions; a0->stream_k = "C is pre-zeroed fp32,
+  // decompose along K as you like").  Default "tail": R full rounds of one-tile-per-workgroup over the whole K -- the 32
+  // workgroups of an XCD then walk K together and share operand panels through its L2 (stream-K's contiguous unit ranges
+  // never do: measured 3.8x operand over-fetch, HBM-bound) -- and only the T % slots leftover tiles are cut S ways along K.
+  // MMDIT_GEMM_KDEC=streamk selects the stream-K schedule instead.
+  static const char* kdec_env = getenv("MMDIT_GEMM_KDEC");
+  static const bool kdec_streamk = kdec_env && kdec_env[0] == 's';
+  int full_tiles = split_k > 1 ? 0 : tiles, tail_split = split_k;
+  bool tail_mode = false;
+  if (stream_k && !kdec_streamk) {
+    gp.stream_k = 0;
+    tail_mode = true;
+    const int G = 256 * (cfg == CFG_128x128 ? 2 : 1), r = tiles % G;
+    int nk_min = 1 << 30;
+    for (int i = 0; i < count; i++) nk_min = gp.p[i].nk < nk_min ? gp.p[i].nk : nk_min;
+    full_tiles = tiles - r;
+    tail_split = 1;
+    if (r) {
+      double best = 1e30;
+      for (int S = 1; S <= 64 && S * 2 <= nk_min; S++) {
+        // rounds of full-K tile time, plus the atomic adds of the r*S partial tiles (measured ~0.6 us of whole-GPU time
+        // per 256x256 fp32 partial = 0.0028 rounds)
+        const double c = (double)((r * S + G - 1) / G) / S + (S > 1 ? 0.0028 * r * S : 0.0);
+        if (c < best) { best = c; tail_split = S; }
+      }
+    }
+  }
   static const bool no_persist = getenv("MMDIT_GEMM_NO_PERSIST") != nullptr;
   gp.persistent = !no_persist;
   if (aux_dt < 0) aux_dt = a0->c_dtype;
-  gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = split_k;
+  gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = tail_split; gp.full_tiles = full_tiles;
   static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation bits: 1 = no DMA in the main loop, 2 = no LDS reads / MFMA, 4 = no cross-tile prefetch, 8 = no epilogue
   gp.debug = debug_env ? atoi(debug_env) : 0;
   static const char* epi_env = getenv("MMDIT_GEMM_EPI");
@@ -329,7 +356,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     MMDIT_CHECK_ARG(dma && a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE && !a0->accumulate && split_k <= 64);
     for (int i = 0; i < count; i++) MMDIT_CHECK_ARG(!args[i].aux && !args[i].gate);
   }
-  if (plan_only) return dma ? (cfg | (stream_k ? 16 : 0)) : 64;   // see mmdit_gemm_plan
+  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0)) : 64;   // see mmdit_gemm_plan
   hipStream_t s = (hipStream_t)stream;
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a0, aux_dt, gp, s);

@@ -20,6 +20,8 @@ struct Problem {
 struct GroupParams {
   Problem p[MAXG];
   int count, total_tiles, act, accumulate, split_k, raster, debug, epi_direct;
+  int full_tiles;   // tiles [0, full_tiles) are multiplied over their whole K by one workgroup; tiles [full_tiles, total_tiles) are cut
+                    // split_k ways along K (partials added atomically into a pre-zeroed fp32 C)
   int stream_k, total_units, persistent;   // stream-K: every workgroup gets an equal share of the (tile, K-tile) units
 };
 
@@ -29,14 +31,29 @@ struct GroupParams {
 //  * Rasterization inside a problem: tiles are walked in column groups of gp.raster n-tiles, m fastest between
 //    groups' rows, so that one group of B panels (raster*BN rows of the weight) stays L2-resident while the
 //    A row panels stream past it once.
+// work items of a launch: the unsplit tiles first, then (tile, K-slice) pairs of the split tail
+__device__ __host__ __forceinline__ int total_work(const GroupParams& gp) { return gp.full_tiles + (gp.total_tiles - gp.full_tiles) * gp.split_k; }
+__device__ __forceinline__ bool is_split_work(const GroupParams& gp, int work) { return work >= gp.full_tiles && gp.split_k > 1; }
+
+// work index -> contiguous range per XCD of a sequence of W items (workgroup b runs on XCD b % 8; full_tiles is a multiple of 8
+// whenever a split tail follows it, so the same holds for the tail's local index)
+__device__ __forceinline__ int xcd_chunk(int w, int W) {
+  const int q = W / NXCD, r = W % NXCD, xcd = w % NXCD, j = w / NXCD;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+}
+
 __device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int work, int& tm, int& tn, int& sk) {
-  // work index -> contiguous range per XCD; inside it the split-K slice is the SLOW index (k-chunk-major): with
-  // split_k = 8 every XCD owns one K-chunk of ALL tiles, so each operand panel is fetched from HBM once per chunk
-  // instead of once per tile (weight gradients: 3.0 GB -> ~0.8 GB per launch).
-  const int T = gp.total_tiles, W = T * gp.split_k, q = W / NXCD, r = W % NXCD, xcd = work % NXCD, j = work / NXCD;
-  const int lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-  sk = lin / T;
-  int t = lin - sk * T;
+  // Inside the split tail the K-slice is the SLOW index (k-chunk-major): an XCD owns (mostly) one K-slice of ALL tail
+  // tiles, so each operand panel of that slice is fetched once into its L2 instead of once per tile.
+  int t;
+  if (work < gp.full_tiles) {
+    sk = 0;
+    t = xcd_chunk(work, gp.full_tiles);
+  } else {
+    const int Tt = gp.total_tiles - gp.full_tiles, lin = xcd_chunk(work - gp.full_tiles, Tt * gp.split_k);
+    sk = lin / Tt;
+    t = gp.full_tiles + lin - sk * Tt;
+  }
   int pi = 0;
 #pragma unroll 1
   for (int i = 1; i < gp.count; i++) pi = (t >= gp.p[i].tile_start) ? i : pi;

@@ -16,12 +16,12 @@
 // s_barrier.  Fragment reads are software-pipelined in registers (B double-buffered, A reloaded behind its
 // last MFMA) and get counted lgkmcnt waits.  The epilogue of a tile is deferred until the first half of the
 // next tile has landed, so its stores drain under the following MFMAs; it stages C through a wave-private,
-// XOR-swizzled 4-KiB LDS block that is not part of the ring (no barrier around it).
+// XOR-swizzled 4-KiB block of the ring slot that is free at that point (one extra barrier per tile).
 //
 // Tile configurations (threads = 64 * WM * WN, each wave owns an (MI*32) x (NJ*32) sub-tile):
-//   128x128: 4 waves 2x2, 2x2 accumulators,  80 KB LDS (2 workgroups / CU)
+//   128x128: 4 waves 2x2, 2x2 accumulators,  64 KB LDS (2 workgroups / CU)
 //   256x128: 8 waves 4x2, 2x2 accumulators, 128 KB LDS
-//   256x256: 8 waves 2x4, 4x2 accumulators, 160 KB LDS  -- half the L2->CU bytes per FLOP of 128x128
+//   256x256: 8 waves 2x4, 4x2 accumulators, 128 KB LDS  -- half the L2->CU bytes per FLOP of 128x128
 #include "gemm_common.h"
 
 using namespace gemm;
@@ -29,7 +29,11 @@ using namespace gemm;
 namespace {
 
 constexpr int BKH = 32;              // K extent of one ring slot (half of the 64-wide K-tile the host plans in)
-constexpr int RING = 4;              // slots; DMA distance = RING - 1 halves
+#ifndef MMDIT_GEMM_RING
+#define MMDIT_GEMM_RING 4
+#endif
+constexpr int RING = MMDIT_GEMM_RING;   // slots; DMA distance = RING - 1 halves.  5 slots (all 160 KB for the 256x256 tile) measured equal to 4:
+                                       // the LDS-DMA path saturates near 46 GB/s per CU, it is not latency-bound
 constexpr int EP32_WAVE_BYTES = 4096;
 
 // byte offset (from the operand's half-tile base pointer) of the 16 B this lane sources for 1-KiB piece c
@@ -123,7 +127,7 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
         }
         TC* cp = C + (int64_t)row * p.ldc + col;
         if constexpr (sizeof(TC) == 4) {
-          if (gp.split_k > 1 || atomic_out) {
+          if (atomic_out) {
 #pragma unroll
             for (int e = 0; e < 4; e++) atomicAdd((float*)cp + e, v[e]);
             continue;
@@ -146,6 +150,7 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
 struct Item {
   int pi;   // problem index (kept as an index so that every access stays a scalar kernarg load)
   int tm, tn, h0, h1, sk;
+  bool atomic;   // partial tile: added atomically into the pre-zeroed fp32 C
   int pos;
   bool valid;
 };
@@ -156,6 +161,7 @@ __device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end)
   it.valid = pos < end;
   it.pi = 0;
   it.tm = it.tn = it.h0 = it.h1 = it.sk = 0;
+  it.atomic = false;
   if (!it.valid) return it;
   if (gp.stream_k) {
     // stream-K: the (tile, K-tile) units of all problems are split evenly over the resident workgroups; a workgroup
@@ -172,15 +178,18 @@ __device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end)
     it.h0 = 2 * k0;
     it.h1 = 2 * k1;
     it.sk = k0 == 0 ? 0 : 1;
+    it.atomic = true;
   } else {
     int sk;
     const Problem& p = locate_tile(gp, pos, it.tm, it.tn, sk);
-    const int nk_all = p.K / BK, per = (nk_all + gp.split_k - 1) / gp.split_k;
+    const int S = is_split_work(gp, pos) ? gp.split_k : 1;
+    const int nk_all = p.K / BK, per = (nk_all + S - 1) / S;
     const int kt0 = sk * per, kt1 = max(kt0, min(nk_all, kt0 + per));
     it.pi = (int)(&p - &gp.p[0]);
     it.h0 = 2 * kt0;
     it.h1 = 2 * kt1;
     it.sk = sk;
+    it.atomic = S > 1;
   }
   return it;
 }
@@ -200,7 +209,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
-  char* stage = smem + RING * H + wave * EP32_WAVE_BYTES;
+  // epilogue staging: the ring slot that is free between the barrier of half_sync and the next DMA issue (when a slot
+  // is large enough for all waves), else a dedicated region behind the ring
+  constexpr bool STAGE_IN_RING = NW * EP32_WAVE_BYTES <= H;
 
   int pos, end;
   if (gp.stream_k) {
@@ -209,7 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     end = (int)((blockIdx.x + 1) * U / G);
   } else {
     pos = blockIdx.x;
-    end = gp.total_tiles * gp.split_k;
+    end = total_work(gp);
   }
 
   // ---- DMA cursor: (item, half) the next issued half belongs to --------------------------------------------
@@ -266,20 +277,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
   };
+  int cslot = 0, dslot = 0;   // ring slots of the half being multiplied / of the half being issued
+  auto bump = [](int s) { return s + 1 == RING ? 0 : s + 1; };
   auto run_epilogue = [&](const Item& it) {   // reads the accumulators only (the zeroing that follows is unconditional code)
-    if (!(gp.debug & 8)) epilogue32<TC, TAUX, MI, NJ>(acc, gp.p[it.pi], gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, gp.stream_k != 0);
+    char* stage = smem + (STAGE_IN_RING ? dslot * H : RING * H) + wave * EP32_WAVE_BYTES;   // dslot: free until the next issue
+    if (!(gp.debug & 8)) epilogue32<TC, TAUX, MI, NJ>(acc, gp.p[it.pi], gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, it.atomic);
     else if (acc[0][0][0] == 12345.678f) ((float*)gp.p[it.pi].C)[0] = 0.f;   // ablation: keep the accumulators live
   };
 
   const bool any = cit.valid;   // false: this workgroup only has empty split-K slices (or nothing)
-  int issued = 0, done = 0;
   if (any) {
     cursor_setup();
 #pragma unroll 1
     for (int s = 0; s < RING - 1; s++) {
 #pragma unroll
-      for (int q = 0; q < PP; q++) issue_piece(q, issued & (RING - 1));
-      issued++;
+      for (int q = 0; q < PP; q++) issue_piece(q, dslot);
+      dslot = bump(dslot);
       cursor_advance();
     }
   }
@@ -291,10 +304,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   // one K half: multiply slot done&3 while the PP pieces of the cursor's half go into slot issued&3 (= (done-1)&3,
   // which every wave left before the barrier of half_sync).  No data-dependent branch inside.
   auto half_body = [&]() {
-    const int dslot = issued & (RING - 1);
-    const char* ta = smem + (done & (RING - 1)) * H;
+    const int nslot = bump(cslot);
+    const char* ta = smem + cslot * H;
     const char* tb = ta + HA;
-    const char* na = smem + ((done + 1) & (RING - 1)) * H;   // (after the last half of the stream: read, never used)
+    const char* na = smem + nslot * H;   // (after the last half of the stream: read, never used)
     const char* nb = na + HA;
 #pragma unroll
     for (int ks = 0; ks < BKH / 16; ks++) {
@@ -318,37 +331,43 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    issued++;
+    dslot = bump(dslot);
+    cslot = nslot;
     cursor_advance();
-    done++;
   };
   auto half_body_nocompute = [&]() {   // ablation (MMDIT_GEMM_DEBUG & 2): DMA stream only
 #pragma unroll
-    for (int q = 0; q < PP; q++) issue_piece(q, issued & (RING - 1));
-    issued++;
+    for (int q = 0; q < PP; q++) issue_piece(q, dslot);
+    dslot = bump(dslot);
+    cslot = bump(cslot);
     cursor_advance();
-    done++;
   };
   auto half_sync = [&]() {
-    // exactly RING-1 halves are in flight here (done .. done+2): halves done and done+1 have landed once only the PP
-    // pieces of half done+2 may still be outstanding (loads retire in order; stores only make the wait conservative)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PP) : "memory");
+    // exactly RING-1 halves are in flight here: the current half and the next one have landed once only the pieces of
+    // the RING-3 youngest halves may still be outstanding (loads retire in order; stores only make the wait conservative)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * PP) : "memory");
     __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left half done-1, whose slot the DMA below refills
   };
 
   Item item = item_at(gp, pos, end), prev = item;
   bool pending = false;
   const bool compute = !(gp.debug & 2);
+  bool first = true;
   while (item.valid) {
     const int n = item.h1 - item.h0;
     if (n > 0) half_sync();
+    else if (STAGE_IN_RING) __builtin_amdgcn_s_barrier();
     // the previous tile's epilogue is deferred to here: its stores drain under the MFMAs that follow
-    if (pending) run_epilogue(prev);
+    if (pending) {
+      run_epilogue(prev);
+      if (STAGE_IN_RING) __builtin_amdgcn_s_barrier();   // staging reads done before the DMA below refills that slot
+    }
     zero_acc();
     if (n > 0) {
       if (compute) {
         // the fragments of a tile's first half: carried over from the previous tile, except at the start of the stream
-        if (done == 0) {
+        if (first) {
+          first = false;
           const char* ta = smem;
 #pragma unroll
           for (int j = 0; j < NJ; j++) b[0][j] = load_frag_h<B_KM, TBN>(ta + HA, wn * (NJ * 32) + j * 32, 0, lane);
@@ -373,13 +392,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     prev = item;
     item = item_at(gp, next_pos(gp, item), end);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (unused) DMA pieces must land before the LDS is reused / released
+  if (STAGE_IN_RING) __builtin_amdgcn_s_barrier();   // every wave has left the last half (its slot is the staging slot)
   if (pending) run_epilogue(prev);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (unused) DMA pieces must land before the LDS is released
 }
 
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
 int launch_cfg(const GroupParams& gp, hipStream_t s) {
-  constexpr int smem = RING * (WM * MI * 32 + WN * NJ * 32) * 64 + WM * WN * EP32_WAVE_BYTES;
+  constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64;
+  constexpr int smem = RING * slot + (WM * WN * EP32_WAVE_BYTES <= slot ? 0 : WM * WN * EP32_WAVE_BYTES);
   auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
@@ -389,7 +410,7 @@ int launch_cfg(const GroupParams& gp, hipStream_t s) {
   }
   // one resident workgroup per slot (256 CUs x workgroups that fit per CU by LDS)
   const int slots = 256 * (smem <= 80 * 1024 ? 2 : 1);
-  const int work = gp.total_tiles * gp.split_k;
+  const int work = total_work(gp);
   const int grid = gp.stream_k ? slots : (gp.persistent && work > slots ? slots : work);
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);
   return mmdit_launch_status();

@@ -97,7 +97,7 @@ def _variant(arr, n, outs):
     if plan == 64:
         ab = "t,t" if a.precision == PREC_BF16 else "f,f"
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
-    return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "")
+    return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "")
 
 
 def gemm_grouped(problems):
