@@ -29,6 +29,22 @@ TRAIN_GFLOP_PER_IMG = 293.3   # 3 x 97.78 GFLOP forward (GEMM + 
 PEAK_BF16 = 2.5e15            # dense MFMA bf16 peak per MI355X (MI355X_MICROARCH.md)
 
 
+def pmc_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC passes (profiles/*_pmc_summary.json, newest round):
+    (2*FETCH_SIZE + WRITE_SIZE) KiB as MI355X_MICROARCH.md prescribes for gfx950; collected by tools/pmc_collect.sh
+    in separate rocprofv3 --pmc runs of this same bench (counters cannot be read inside the timed run).  None if absent."""
+    import glob
+    name = kernel.split("+")[0]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if name in d:
+            return d[name]["hbm_bytes_per_launch"], d[name]["mfma_util"], os.path.relpath(f, ROOT)
+    return None, None, None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """fwd + bwd + clip + AdamW of the oracle on MMDiT-B, batch 8, host cores only."""
     import torch
@@ -139,7 +155,8 @@ def main():
         tot_f = sum(s[1] for s in stats.values())
         dom = max(stats.items(), key=lambda kv: kv[1][2])
         roofline = {"bound": "mfma", "kernel": dom[0], "achieved": round(dom[1][1] / dom[1][2] / 1e12, 1), "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                    "frac": round(dom[1][1] / dom[1][2] / PEAK_BF16, 4), "traffic": None,
+                    "frac": round(dom[1][1] / dom[1][2] / PEAK_BF16, 4), "traffic": pmc_traffic(dom[0])[0],
+                    "traffic_unit": "bytes/launch (L2<->fabric, 2*FETCH_SIZE+WRITE_SIZE)", "traffic_source": pmc_traffic(dom[0])[2], "mfma_util_pmc": pmc_traffic(dom[0])[1],
                     "avg_launch_us": round(dom[1][2] / dom[1][0] * 1e6, 2), "launches_per_step": dom[1][0] // 3,
                     "all_gemm": {"achieved": round(tot_f / tot_t / 1e12, 1), "frac": round(tot_f / tot_t / PEAK_BF16, 4),
                                  "ms_per_step": round(tot_t / 3 * 1e3, 3), "gflop_per_step": round(tot_f / 3 / 1e9, 1)},

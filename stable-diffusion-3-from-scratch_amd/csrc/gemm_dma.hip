@@ -92,19 +92,32 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
   for (int i = 0; i < MI; i++) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
+      const int col = n0 + wn * (NJ * 32) + j * 32 + rc * 4;
+      const int row0 = m0 + wm * (MI * 32) + i * 32 + rr;
+      // the residual rows of all four passes are requested before the staging round trip, so that the block
+      // pays one memory latency instead of four load -> wait -> store chains
+      float r4[4][4];   // (the gate rows are a few KB shared by 256 output rows each: L1/L2-hot, loaded in place)
+      if (res) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+          const int row = row0 + it * 8;
+          if (row < p.M && col < p.N) {
+            ld4(res + (int64_t)row * p.ld_res + col, r4[it]);
+          }
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; g++)
         *LDS_PTR(f32x4, stage + wr * 128 + (((2 * g + wc) ^ (wr & 7)) << 4)) =
             (f32x4){acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
-      const int col = n0 + wn * (NJ * 32) + j * 32 + rc * 4;
       float b4[4] = {0.f, 0.f, 0.f, 0.f};
       if (bias && col < p.N) ld4(bias + col, b4);
 #pragma unroll
       for (int it = 0; it < 4; it++) {
         const int r = it * 8 + rr;
         const f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
-        const int row = m0 + wm * (MI * 32) + i * 32 + r;
+        const int row = row0 + it * 8;
         if (row >= p.M || col >= p.N) continue;
         float v[4] = {t[0] + b4[0], t[1] + b4[1], t[2] + b4[2], t[3] + b4[3]};
         if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
@@ -113,16 +126,14 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
           for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
         }
         if (res) {
-          float r4[4];
-          ld4(res + (int64_t)row * p.ld_res + col, r4);
           if (gate) {
             float g4[4];
             ld4(gate + (int64_t)(row / p.rows_per_batch) * p.ld_gate + col, g4);
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = r4[e] + g4[e] * v[e];
+            for (int e = 0; e < 4; e++) v[e] = r4[it][e] + g4[e] * v[e];
           } else {
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += r4[e];
+            for (int e = 0; e < 4; e++) v[e] += r4[it][e];
           }
         }
         TC* cp = C + (int64_t)row * p.ldc + col;
@@ -143,6 +154,53 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
     }
+  }
+}
+
+// bf16 output without residual / gate / aux (QKV, up-projection, every dgrad): bias and activation are applied in the
+// accumulator layout, the block pair (i, j = 0..NJ-1... two 32-column blocks) is converted to bf16 FIRST and staged as a
+// 32-row x 64-column bf16 block (4 KiB, 16-B chunk c of row r at chunk c ^ (r&7)), so a wave store instruction writes
+// 8 rows x 128 B (full lines, 16 B per lane): half the LDS bytes and half the store instructions of the fp32 staging.
+template <int MI, int NJ>
+__device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
+                                              int lane, char* stage) {
+  static_assert(NJ == 2, "wave sub-tile must be 64 columns wide");
+  bf16_t* C = (bf16_t*)p.C;
+  const float* bias = p.bias;
+  const int wr = lane & 31, wc = lane >> 5;          // write side: row, 8-B half of the 16-B chunk
+  const int rr = lane >> 3, rc = lane & 7;           // read side: row within the 8-row pass, 16-B chunk (8 columns)
+  const int colw = n0 + wn * 64;                     // first column of this wave
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float v[4] = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+        if (bias) {
+          const int c = colw + j * 32 + 8 * g + 4 * wc;
+          float b4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (c < p.N) ld4(bias + c, b4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b4[e];
+        }
+        if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *LDS_PTR(u32x2, stage + wr * 128 + (((j * 4 + g) ^ (wr & 7)) << 4) + wc * 8) = pk;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+    const int col = colw + rc * 8;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+      const int row = m0 + wm * (MI * 32) + i * 32 + r;
+      if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
   }
 }
 
@@ -281,7 +339,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   auto bump = [](int s) { return s + 1 == RING ? 0 : s + 1; };
   auto run_epilogue = [&](const Item& it) {   // reads the accumulators only (the zeroing that follows is unconditional code)
     char* stage = smem + (STAGE_IN_RING ? dslot * H : RING * H) + wave * EP32_WAVE_BYTES;   // dslot: free until the next issue
-    if (!(gp.debug & 8)) epilogue32<TC, TAUX, MI, NJ>(acc, gp.p[it.pi], gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, it.atomic);
+    if (!(gp.debug & 8)) {
+      const Problem& q = gp.p[it.pi];
+      bool fast = false;
+      if constexpr (sizeof(TC) == 2 && NJ == 2)
+        fast = !q.aux && !q.residual && !q.gate && !gp.accumulate && !it.atomic && (q.N & 7) == 0 && (q.ldc & 7) == 0 && ((uintptr_t)q.C & 15) == 0 && !(gp.debug & 64);
+      if (fast) epilogue_bf16<MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, stage);
+      else epilogue32<TC, TAUX, MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, it.atomic);
+    }
     else if (acc[0][0][0] == 12345.678f) ((float*)gp.p[it.pi].C)[0] = 0.f;   // ablation: keep the accumulators live
   };
 
