@@ -85,7 +85,8 @@ class model_trainer:
                  load_ema_file=None, optimFile=None, schedulerFile=None, scalerFile=None, use_amp=True, wandb_name=None,
                  wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
-                 data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False):
+                 data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False,
+                 fused_unscale_clip=True):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
@@ -120,6 +121,7 @@ class model_trainer:
             if hasattr(self.model, "grad_reducer"):
                 self.model.grad_reducer = red
 
+        self.fused_unscale_clip = bool(fused_unscale_clip)
         fused = bool(fused_optimizer and self.device.type == "cuda")
         self.optim = torch.optim.AdamW(self.model.parameters(), lr=lr, eps=1e-8, weight_decay=0.01, betas=(0.9, 0.999), fused=fused)
         self.scheduler = get_scheduler(self.optim, num_warmup_steps=warmup_steps, num_training_steps=totalSteps, use_lr_scheduler=use_lr_scheduler)
@@ -177,11 +179,33 @@ class model_trainer:
             self.reducer.finish()
         return loss.detach()
 
+    def _unscale_and_clip(self, max_norm=1.0):
+        """GradScaler.unscale_(optim) + clip_grad_norm_(params, max_norm) with ONE pass over the gradients instead of two
+        (model_trainer.py:463-470 of the reference calls them back to back).  The loss scale is a power of two, so
+        g * (inv_scale * clip_coef) is bit-identical to (g * inv_scale) * clip_coef, and ||g * inv_scale|| = inv_scale * ||g||;
+        an inf/nan gradient makes the norm non-finite, which is exactly unscale_'s found_inf.  The scaler is told that the
+        gradients are unscaled (the same bookkeeping unscale_ does), so step()/update() behave as in the reference."""
+        from torch.amp.grad_scaler import OptState
+        sc = self.grad_scaler
+        st = sc._per_optimizer_states[id(self.optim)]
+        if st["stage"] is not OptState.READY:
+            raise RuntimeError("unscale_() has already been called on this optimizer since the last update().")
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads, 2.0)), 2.0)     # norm of the SCALED gradients
+        inv_scale = sc._scale.double().reciprocal().float()
+        coef = inv_scale * torch.clamp(max_norm / (total * inv_scale + 1e-6), max=1.0)
+        torch._foreach_mul_(grads, coef)
+        st["found_inf_per_device"] = {total.device: (~torch.isfinite(total)).to(torch.float32)}
+        st["stage"] = OptState.UNSCALED
+
     def optimizer_step(self, step):
-        if self.grad_scaler is not None:
-            self.grad_scaler.unscale_(self.optim)
-        if self.use_amp:
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
+        if self.grad_scaler is not None and self.use_amp and self.grad_scaler.is_enabled() and self.fused_unscale_clip:
+            self._unscale_and_clip(1.0)
+        else:
+            if self.grad_scaler is not None:
+                self.grad_scaler.unscale_(self.optim)
+            if self.use_amp:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), 1.0)
         if self.grad_scaler is not None:
             self.grad_scaler.step(self.optim)
         else:

@@ -307,3 +307,47 @@ def test_trainer_step_and_reducer_path_single_rank():
     assert np.allclose(l0, l1, rtol=1e-5)
     for a, b in zip(p0, p1):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+
+
+def test_fused_unscale_clip_matches_two_pass_path():
+    """The one-pass unscale+clip (trainer default) must leave the gradients and the scaler bookkeeping of
+    GradScaler.unscale_ followed by clip_grad_norm_ (the reference's sequence, model_trainer.py:463-470) on the same
+    scaled gradients -- finite case (clipping active and inactive) and inf case."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+
+    def make(fused):
+        torch.manual_seed(0)
+        net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                         device=torch.device("cuda:0"), positional_encoding="RoPE2d", **CONFIGS["micro"])
+        net.load_state_dict(make_state_dict(0, **CONFIGS["micro"]))
+        return model_trainer(net, batchSize=4, accumulation_steps=1, totalSteps=10, lr=1e-3, ema_update_freq=1, ema_decay=0.9, warmup_steps=0,
+                             use_lr_scheduler=False, device=torch.device("cuda:0"), saveDir="/tmp/_t", numSaveSteps=100, max_res=128,
+                             device_rng=True, use_ema=False, fused_unscale_clip=fused)
+
+    for mag, poison in ((1e-4, False), (3.0, False), (1.0, True)):      # below the clip threshold / above it / one inf
+        out = []
+        for fused in (True, False):
+            tr = make(fused)
+            g = torch.Generator(device="cuda").manual_seed(5)
+            scale = float(tr.grad_scaler.get_scale()) if tr.grad_scaler._scale is not None else 65536.0
+            tr.grad_scaler.scale(torch.ones((), device="cuda"))          # lazily creates the scale tensor
+            scale = float(tr.grad_scaler.get_scale())
+            for i, q in enumerate(tr.model.parameters()):
+                q.grad = torch.randn(q.shape, generator=g, device="cuda") * mag * scale
+                if poison and i == 3:
+                    q.grad.view(-1)[0] = float("inf")
+            if fused:
+                tr._unscale_and_clip(1.0)
+            else:
+                tr.grad_scaler.unscale_(tr.optim)
+                torch.nn.utils.clip_grad_norm_(tr.model.parameters(), 1.0)
+            st = tr.grad_scaler._per_optimizer_states[id(tr.optim)]
+            found = sum(float(x) for x in st["found_inf_per_device"].values())
+            out.append(([q.grad.clone() for q in tr.model.parameters()], found, st["stage"]))
+        (ga, fa, sa), (gb, fb, sb) = out
+        assert fa == fb == (1.0 if poison else 0.0) and sa == sb
+        if not poison:
+            for a, b in zip(ga, gb):
+                assert torch.allclose(a, b, rtol=2e-6, atol=0.0)
