@@ -270,77 +270,82 @@ __global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const TI* __restr
   }
 }
 
+// Backward: a workgroup has 24 * heads threads = one qkv row (thread = (part, head, 8-element chunk): no per-element index
+// divisions, the q/k norm weights stay in registers) and walks rows blockIdx.x, + gridDim.x, ... two at a time; the grid is
+// small (2 workgroups per CU) because every workgroup ends with 128 global atomics on the same two cache lines.
 template <typename TG, typename TI, typename TO>
-__global__ __launch_bounds__(256) void qk_norm_rope_bwd_kernel(const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
-                                                               const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
-                                                               const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                               int64_t total, int tokens, int heads, int s_total, int tok0,
-                                                               TO* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk) {
+__global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
+                                                                const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                                int rows, int tokens, int heads, int s_total, int tok0,
+                                                                TO* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk) {
   __shared__ float sdw[2][64];
-  if (threadIdx.x < 128) sdw[threadIdx.x >> 6][threadIdx.x & 63] = 0.f;
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) sdw[i >> 6][i & 63] = 0.f;
   __syncthreads();
-  float aq[8], ak[8];
+  const int hc = threadIdx.x % (8 * heads), part = threadIdx.x / (8 * heads), head = hc >> 3, chunk = hc & 7;
+  const TG* gbase = part == 0 ? dQ : part == 1 ? dK : dV;
+  float w[8], aw[8];
 #pragma unroll
-  for (int e = 0; e < 8; e++) { aq[e] = 0.f; ak[e] = 0.f; }
-  const int chunk = threadIdx.x & 7;  // constant per thread: 256 and gridDim*256 are multiples of 8
-  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
-    int64_t hv = gid >> 3;
-    const int head = (int)(hv % heads); hv /= heads;
-    const int part = (int)(hv % 3);
-    const int64_t row = hv / 3;
-    const int n = (int)(row % tokens);
-    const int64_t b = row / tokens;
-    const TG* src = (part == 0 ? dQ : part == 1 ? dK : dV) + ((b * heads + head) * (int64_t)s_total + tok0 + n) * 64 + chunk * 8;
-    float dz[8];
-    ld8(src, dz);
-    if (part < 2) {
-      float x[8], w[8];
-      ld8(qkv + gid * 8, x);
-      ld8((part == 0 ? wq : wk) + chunk * 8, w);
-      float ss = 0.f;
+  for (int e = 0; e < 8; e++) { w[e] = 0.f; aw[e] = 0.f; }
+  if (part < 2) ld8((part == 0 ? wq : wk) + chunk * 8, w);
+  const int rstride = gridDim.x;
+  for (int row0 = blockIdx.x; row0 < rows; row0 += 2 * rstride) {
+    float dz[2][8], x[2][8], cs[2][8], sn[2][8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) ss += x[e] * x[e];
-      const float rinv = rsqrtf(group8_sum(ss) * (1.f / 64.f) + RMS_EPS);
-      if (rcos) {
-        float c[8], s[8];
-        ld8(rcos + (int64_t)n * 64 + chunk * 8, c);
-        ld8(rsin + (int64_t)n * 64 + chunk * 8, s);
-#pragma unroll
-        for (int p = 0; p < 4; p++) {
-          float da = dz[2 * p], db = dz[2 * p + 1];
-          dz[2 * p] = da * c[2 * p] + db * s[2 * p + 1];
-          dz[2 * p + 1] = db * c[2 * p + 1] - da * s[2 * p];
+    for (int k = 0; k < 2; k++) {
+      const int row = row0 + k * rstride;
+      if (row < rows) {
+        const int n = row % tokens, b = row / tokens;
+        ld8(gbase + (((int64_t)b * heads + head) * s_total + tok0 + n) * 64 + chunk * 8, dz[k]);
+        if (part < 2) {
+          ld8(qkv + (((int64_t)row * 3 + part) * heads + head) * 64 + chunk * 8, x[k]);
+          if (rcos) {
+            ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[k]);
+            ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[k]);
+          }
         }
       }
-      float dot = 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; e++) {
-        float xh = x[e] * rinv;
-        float dwv = dz[e] * xh;
-        if (part == 0) aq[e] += dwv; else ak[e] += dwv;
-        dz[e] *= w[e];                 // d(xhat)
-        dot += dz[e] * xh;
-        x[e] = xh;
-      }
-      dot = group8_sum(dot) * (1.f / 64.f);
-#pragma unroll
-      for (int e = 0; e < 8; e++) dz[e] = rinv * (dz[e] - x[e] * dot);
     }
-    st8(dqkv + gid * 8, dz);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int row = row0 + k * rstride;
+      if (row >= rows) break;
+      if (part < 2) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) ss += x[k][e] * x[k][e];
+        const float rinv = rsqrtf(group8_sum(ss) * (1.f / 64.f) + RMS_EPS);
+        if (rcos) {
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            float da = dz[k][2 * p], db = dz[k][2 * p + 1];
+            dz[k][2 * p] = da * cs[k][2 * p] + db * sn[k][2 * p + 1];
+            dz[k][2 * p + 1] = db * cs[k][2 * p + 1] - da * sn[k][2 * p];
+          }
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+          float xh = x[k][e] * rinv;
+          aw[e] += dz[k][e] * xh;
+          dz[k][e] *= w[e];                 // d(xhat)
+          dot += dz[k][e] * xh;
+          x[k][e] = xh;
+        }
+        dot = group8_sum(dot) * (1.f / 64.f);
+#pragma unroll
+        for (int e = 0; e < 8; e++) dz[k][e] = rinv * (dz[k][e] - x[k][e] * dot);
+      }
+      st8(dqkv + (((int64_t)row * 3 + part) * heads + head) * 64 + chunk * 8, dz[k]);
+    }
   }
-  // lanes with equal (lane & 7) hold the same weight columns: reduce over the wave, then LDS, then global
+  // weight gradients: sum over rows (done) and heads: LDS atomics per (part, column), then 128 global atomics per workgroup
+  if (part < 2) {
 #pragma unroll
-  for (int e = 0; e < 8; e++) {
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) { aq[e] += __shfl_xor(aq[e], o, 64); ak[e] += __shfl_xor(ak[e], o, 64); }
-  }
-  if ((threadIdx.x & 63) < 8) {
-#pragma unroll
-    for (int e = 0; e < 8; e++) { atomicAdd(&sdw[0][chunk * 8 + e], aq[e]); atomicAdd(&sdw[1][chunk * 8 + e], ak[e]); }
+    for (int e = 0; e < 8; e++) atomicAdd(&sdw[part][chunk * 8 + e], aw[e]);
   }
   __syncthreads();
-  if (threadIdx.x < 64) atomicAdd(dwq + threadIdx.x, sdw[0][threadIdx.x]);
-  else if (threadIdx.x < 128) atomicAdd(dwk + threadIdx.x - 64, sdw[1][threadIdx.x - 64]);
+  for (int i = threadIdx.x; i < 128; i += blockDim.x) atomicAdd((i < 64 ? dwq : dwk) + (i & 63), sdw[i >> 6][i & 63]);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -392,57 +397,85 @@ __device__ __forceinline__ void colsum_flush(float (&acc)[8], float* sbuf /*[256
   __syncthreads();
 }
 
+constexpr int MB_RCH = 128;
+// activation backward: a workgroup covers 256 columns x MB_RCH rows (32 column groups of 8 x 8 row lanes, two rows in flight
+// per thread); the bias-gradient column sums cost one atomic per column and workgroup.  grid = (hidden / 256, rows / MB_RCH)
 template <typename T, bool GELU>
 __global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ gu, T* __restrict__ dgu,
                                                           int rows, int hidden, float* __restrict__ dbias) {
-  __shared__ float sbuf[1024];
-  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
-  const int c = blockIdx.x * 1024 + tx * 8;
+  __shared__ float sbuf[8 * 256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + tx * 8;
   const bool act = c < hidden;
   const int64_t ldi = GELU ? hidden : 2 * (int64_t)hidden;
   float sg[8], su[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { sg[e] = 0.f; su[e] = 0.f; }
-  const int rend = min(rows, (int)(blockIdx.y + 1) * CO_RCH);
+  const int rend = min(rows, (int)(blockIdx.y + 1) * MB_RCH);
   if (act) {
-    for (int r = blockIdx.y * CO_RCH + ty; r < rend; r += 2) {
-      float d[8], g[8], og[8];
-      ld8(dh + (int64_t)r * hidden + c, d);
-      ld8(gu + r * ldi + c, g);
-      if constexpr (GELU) {
+    for (int r0 = blockIdx.y * MB_RCH + ty; r0 < rend; r0 += 16) {
+      float d[2][8], g[2][8], u[2][8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) { og[e] = d[e] * gelu_grad_f(g[e]); sg[e] += og[e]; }
-        st8(dgu + r * ldi + c, og);
-      } else {
-        float u[8], ou[8];
-        ld8(gu + r * ldi + hidden + c, u);
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-          float sig = sigmoid_f(g[e]);
-          og[e] = d[e] * u[e] * sig * (1.f + g[e] * (1.f - sig));
-          ou[e] = d[e] * g[e] * sig;
-          sg[e] += og[e]; su[e] += ou[e];
+      for (int k = 0; k < 2; k++) {
+        const int r = r0 + 8 * k;
+        if (r < rend) {
+          ld8(dh + (int64_t)r * hidden + c, d[k]);
+          ld8(gu + r * ldi + c, g[k]);
+          if constexpr (!GELU) ld8(gu + r * ldi + hidden + c, u[k]);
         }
-        st8(dgu + r * ldi + c, og);
-        st8(dgu + r * ldi + hidden + c, ou);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int r = r0 + 8 * k;
+        if (r >= rend) break;
+        float og[8], ou[8];
+        if constexpr (GELU) {
+#pragma unroll
+          for (int e = 0; e < 8; e++) { og[e] = d[k][e] * gelu_grad_f(g[k][e]); sg[e] += og[e]; }
+          st8(dgu + r * ldi + c, og);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; e++) {
+            float sig = sigmoid_f(g[k][e]);
+            og[e] = d[k][e] * u[k][e] * sig * (1.f + g[k][e] * (1.f - sig));
+            ou[e] = d[k][e] * g[k][e] * sig;
+            sg[e] += og[e]; su[e] += ou[e];
+          }
+          st8(dgu + r * ldi + c, og);
+          st8(dgu + r * ldi + hidden + c, ou);
+        }
       }
     }
   }
   if (dbias) {
-    colsum_flush(sg, sbuf, dbias, c, hidden);
-    if constexpr (!GELU) colsum_flush(su, sbuf, dbias + hidden, c, hidden);
+    const int col = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+    for (int which = 0; which < (GELU ? 1 : 2); which++) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) sbuf[ty * 256 + tx * 8 + e] = which == 0 ? sg[e] : su[e];
+      __syncthreads();
+      if (col < hidden) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; r++) s += sbuf[r * 256 + threadIdx.x];
+        atomicAdd(dbias + which * hidden + col, s);
+      }
+      __syncthreads();
+    }
   }
 }
 
-constexpr int GR_RCH = 16;
-// dacc = dy * gate[b]; dgate[b] += sum dy*acc; dbias += sum dacc.  grid = (slabs, batch * chunks)
+constexpr int GR_RCH = 64;
+// dacc = dy * gate[b]; dgate[b] += sum dy*acc; dbias += sum dacc.  grid = (d / 256 column slabs, batch * row chunks).
+// A workgroup covers 256 columns x GR_RCH rows: 32 column groups of 8 x 8 row lanes, two rows in flight per thread; the
+// row lanes are combined through LDS and every column costs ONE atomic per workgroup (atomics are the expensive part).
 template <typename TA, typename TO>
 __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const float* __restrict__ dy, const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate,
                                                            int d, int rpb, int nchunk, TO* __restrict__ dacc,
                                                            float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias) {
-  __shared__ float sbuf[1024];
-  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
-  const int c = blockIdx.x * 1024 + tx * 8;
+  __shared__ float sbuf[8 * 256];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + tx * 8;
   const bool act = c < d;
   const int b = blockIdx.y / nchunk, chunk = blockIdx.y % nchunk;
   float g[8], sgate[8], sb[8];
@@ -451,18 +484,43 @@ __global__ __launch_bounds__(256) void gate_res_bwd_kernel(const float* __restri
   if (act) {
     ld8(gate + (int64_t)b * ld_gate + c, g);
     const int rend = min(rpb, (chunk + 1) * GR_RCH);
-    for (int rl = chunk * GR_RCH + ty; rl < rend; rl += 2) {
-      const int64_t row = (int64_t)b * rpb + rl;
-      float dv[8], av[8], o[8];
-      ld8(dy + row * d + c, dv);
-      ld8(acc + row * d + c, av);
+    for (int rl = chunk * GR_RCH + ty; rl < rend; rl += 16) {
+      const int64_t row0 = (int64_t)b * rpb + rl, row1 = row0 + 8;
+      const bool two = rl + 8 < rend;
+      float dv0[8], av0[8], dv1[8], av1[8], o[8];
+      ld8(dy + row0 * d + c, dv0);
+      ld8(acc + row0 * d + c, av0);
+      if (two) {
+        ld8(dy + row1 * d + c, dv1);
+        ld8(acc + row1 * d + c, av1);
+      }
 #pragma unroll
-      for (int e = 0; e < 8; e++) { o[e] = dv[e] * g[e]; sgate[e] += dv[e] * av[e]; sb[e] += o[e]; }
-      st8(dacc + row * d + c, o);
+      for (int e = 0; e < 8; e++) { o[e] = dv0[e] * g[e]; sgate[e] += dv0[e] * av0[e]; sb[e] += o[e]; }
+      st8(dacc + row0 * d + c, o);
+      if (two) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { o[e] = dv1[e] * g[e]; sgate[e] += dv1[e] * av1[e]; sb[e] += o[e]; }
+        st8(dacc + row1 * d + c, o);
+      }
     }
   }
-  colsum_flush(sgate, sbuf, dgate + (int64_t)b * ld_dgate, c, d);
-  if (dbias) colsum_flush(sb, sbuf, dbias + (int64_t)b * ld_dbias, c, d);   // ld_dbias > 0: per-batch partial rows (low contention)
+  // combine the 8 row lanes through LDS: thread t owns column slab_base + t
+  const int col = blockIdx.x * 256 + threadIdx.x;
+#pragma unroll
+  for (int which = 0; which < 2; which++) {
+    float* dst = which == 0 ? dgate + (int64_t)b * ld_dgate : (dbias ? dbias + (int64_t)b * ld_dbias : nullptr);
+    if (!dst) break;   // uniform
+#pragma unroll
+    for (int e = 0; e < 8; e++) sbuf[ty * 256 + tx * 8 + e] = which == 0 ? sgate[e] : sb[e];
+    __syncthreads();
+    if (col < d) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 8; r++) s += sbuf[r * 256 + threadIdx.x];
+      atomicAdd(dst + col, s);
+    }
+    __syncthreads();
+  }
 }
 
 template <typename T>
@@ -662,9 +720,10 @@ extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void
   MMDIT_CHECK_ARG(dQ && dK && dV && qkv && wq && wk && dqkv && dwq && dwk && batch > 0 && tokens > 0 && heads > 0 && tok0 >= 0 && tok0 + tokens <= s_total);
   MMDIT_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr));
   hipStream_t s = (hipStream_t)stream;
-  const int64_t total = (int64_t)batch * tokens * 3 * heads * 8;
-  dim3 grid(grid_cap(total, 256 * 32));   // few, long-running blocks: every block ends with 128 atomics on the same two cache lines
-#define QKB(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<TG, TI, TO>), grid, dim3(256), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, total, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk)
+  MMDIT_CHECK_ARG(heads >= 1 && 24 * heads <= 1024);   // one row per workgroup of 24*heads threads
+  const int rows = batch * tokens;
+  dim3 grid(rows < 512 ? rows : 512);
+#define QKB(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<TG, TI, TO>), grid, dim3(24 * heads), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, rows, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk)
   if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_BF16 && dqkv_dtype == MMDIT_BF16) QKB(bf16_t, bf16_t, bf16_t);
   else if (dq_dtype == MMDIT_F32 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(float, float, float);
   else if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(bf16_t, float, float);
@@ -686,7 +745,7 @@ static int mlp_act_fwd(const void* gu, void* h, int dtype, int rows, int hidden,
 template <bool GELU>
 static int mlp_act_bwd(const void* dh, const void* gu, void* dgu, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(dh && gu && dgu && rows > 0 && hidden > 0 && hidden % 8 == 0);
-  dim3 grid((hidden + 1023) / 1024, (rows + CO_RCH - 1) / CO_RCH);
+  dim3 grid((hidden + 255) / 256, (rows + MB_RCH - 1) / MB_RCH);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MMDIT_BF16) hipLaunchKernelGGL((mlp_act_bwd_kernel<bf16_t, GELU>), grid, dim3(256), 0, s, (const bf16_t*)dh, (const bf16_t*)gu, (bf16_t*)dgu, rows, hidden, dbias);
   else if (dtype == MMDIT_F32) hipLaunchKernelGGL((mlp_act_bwd_kernel<float, GELU>), grid, dim3(256), 0, s, (const float*)dh, (const float*)gu, (float*)dgu, rows, hidden, dbias);
@@ -714,7 +773,7 @@ extern "C" int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc
   MMDIT_CHECK_ARG(dy && acc && gate && dacc && dgate && rows > 0 && d % 8 == 0 && rpb > 0 && rows % rpb == 0 && ld_gate % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   const int nchunk = (rpb + GR_RCH - 1) / GR_RCH;
-  dim3 grid((d + 1023) / 1024, (rows / rpb) * nchunk);
+  dim3 grid((d + 255) / 256, (rows / rpb) * nchunk);
   if (acc_dtype == MMDIT_BF16 && dacc_dtype == MMDIT_BF16) hipLaunchKernelGGL((gate_res_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, dy, (const bf16_t*)acc, gate, ld_gate, d, rpb, nchunk, (bf16_t*)dacc, dgate, ld_dgate, dbias, ld_dbias);
   else if (acc_dtype == MMDIT_F32 && dacc_dtype == MMDIT_F32) hipLaunchKernelGGL((gate_res_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, (const float*)acc, gate, ld_gate, d, rpb, nchunk, (float*)dacc, dgate, ld_dgate, dbias, ld_dbias);
   else return MMDIT_ERR_DTYPE;
