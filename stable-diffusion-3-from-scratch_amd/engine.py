@@ -111,7 +111,7 @@ def _zeros_views(shapes, dev):
     """One zero-filled fp32 arena (one memset launch) carved into views of the given shapes."""
     sizes = [int(torch.Size(s).numel()) for s in shapes]
     pad = [(n + 3) // 4 * 4 for n in sizes]           # keep every view 16-byte aligned
-    flat = torch.zeros(sum(pad), dtype=F32, device=dev)
+    flat = ops.zeros(sum(pad), dev)                   # (a slice of the pass-wide zero pool on a GPU)
     out, off = [], 0
     for s, n, p in zip(shapes, sizes, pad):
         out.append(flat[off:off + n].view(s))
@@ -168,7 +168,7 @@ def mlp_core_fwd(m, w, x_act):
 
 def mlp_core_bwd(m, w, dacc, x_act, gu, h, dev):
     dh = _dgrad(m, dacc, w.Wdown, m.T)
-    dbup = torch.zeros(gu.shape[1], dtype=F32, device=dev)
+    dbup = ops.zeros(gu.shape[1], dev)
     dgu = ops.mlp_act_bwd(dh, gu, w.hidden, dbup, w.gelu)
     dx = _dgrad(m, dgu, w.Wup, m.T)
     ds = [_wg(dacc, h), _wg(dgu, x_act)]
@@ -362,6 +362,8 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     B, N, Mt, H, d = sv.dims
     _, Cin, Hh, Ww = sv.img
     dev = dv.device
+    if dev.type == "cuda":
+        ops.zero_pool_begin(dev)
     g = NS()
     pending = []
 
@@ -369,11 +371,11 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
         pending.append((lambda o, name=name: setattr(g, name, o), _wg(dY, Xa)))
 
     dZ = ops.patchify(dv.contiguous(), m.T)
-    g.bout = torch.zeros(W.Wout.shape[0], dtype=F32, device=dev)
+    g.bout = ops.zeros(W.Wout.shape[0], dev)
     ops.colsum(dZ, g.bout)
     dlnf = _dgrad(m, dZ, W.Wout, m.T)
     defer("Wout", dZ, sv.lnf)
-    dmodo = torch.zeros_like(sv.modo)
+    dmodo = ops.zeros(sv.modo.shape, dev) if sv.modo.dtype == F32 else torch.zeros_like(sv.modo)
     dX = ops.ln_modulate_bwd(dlnf, sv.Xf, sv.muf, sv.rsf, sv.modo[:, d:], None, N, dmodo[:, d:], dmodo[:, :d])
     dmodo_a = m.act(dmodo)
     dy_acc = _dgrad(m, dmodo_a, W.Wmod_out, F32, **({"split_k": 4} if m.fast else {}))
@@ -388,7 +390,7 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
             on_grads(_grad_tensors(g.blocks[i]), _wg_streams.get(dev))
 
     # patch embedding
-    g.bpe = torch.zeros(d, dtype=F32, device=dev)
+    g.bpe = ops.zeros(d, dev)
     ops.colsum(dX, g.bpe)
     dX_a = m.act(dX)
     dX0 = _dgrad(m, dX_a, W.Wpe, m.T)

@@ -17,6 +17,47 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16}
 PROFILE = None
 
 
+class _ZeroPool:
+    """Zero-initialised fp32 scratch for one backward pass (atomic accumulation targets: split-K / bias / norm-weight
+    gradients).  The demand of a pass is learned from the previous one, so that from the second step on ONE memset serves
+    every request of the pass (~200 tiny fill launches per step otherwise).  Slices stay valid for as long as they are
+    referenced: every pass gets a fresh buffer."""
+
+    def __init__(self):
+        self.buf, self.off, self.cap, self.need = None, 0, 0, 0
+
+    def begin(self, device):
+        self.cap = max(self.cap, self.need)
+        self.need, self.off = 0, 0
+        self.buf = torch.zeros(self.cap, dtype=torch.float32, device=device) if self.cap else None
+
+    def take(self, numel, device):
+        n = (numel + 3) // 4 * 4            # keep every slice 16-byte aligned
+        self.need += n
+        if self.buf is not None and self.buf.device == device and self.off + n <= self.cap:
+            v = self.buf[self.off:self.off + numel]
+            self.off += n
+            return v
+        return torch.zeros(numel, dtype=torch.float32, device=device)
+
+
+_pools = {}
+
+
+def zero_pool_begin(device):
+    """Call at the start of a backward pass (engine.model_bwd)."""
+    _pools.setdefault(device, _ZeroPool()).begin(device)
+
+
+def zeros(shape, device):
+    """fp32 zeros of `shape`: a slice of the pass's pool on a GPU, plain torch.zeros elsewhere."""
+    shape = tuple(shape) if not isinstance(shape, int) else (shape,)
+    pool = _pools.get(device)
+    if pool is None:
+        return torch.zeros(shape, dtype=torch.float32, device=device)
+    return pool.take(int(torch.Size(shape).numel()), device).view(shape)
+
+
 def _dt(t: torch.Tensor) -> int:
     try:
         return _DT[t.dtype]
@@ -61,7 +102,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
         raise RuntimeError(f"gemm: inner dimensions differ ({K_} vs {Kb})")
     if out is None:
         if split_k > 1 or stream_k:
-            out = torch.zeros((M, N), dtype=torch.float32, device=A.device)   # slices accumulate atomically
+            out = zeros((M, N), A.device)   # slices accumulate atomically
         else:
             out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
     a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), A.stride(0)
@@ -160,8 +201,8 @@ def text_rmsnorm_fwd(x, w1, w2, s1, s2, split, out_dtype):
 
 def text_rmsnorm_bwd(dout1, dout2, x, w1, w2, s1, s2, split):
     batch, tokens, d = x.shape
-    dw1, dw2 = torch.zeros_like(w1), torch.zeros_like(w2)
-    ds1, ds2 = torch.zeros_like(s1), torch.zeros_like(s2)
+    dw1, dw2 = zeros(w1.shape, w1.device), zeros(w2.shape, w2.device)
+    ds1, ds2 = zeros(s1.shape, s1.device), zeros(s2.shape, s2.device)
     check(_lib.lib().mmdit_text_rmsnorm_bwd(_p(_c(dout1)), _p(_c(dout2)), _dt(dout1), _p(x), _dt(x), _p(w1), _p(w2), _p(s1), _p(s2),
                                             batch, tokens, split, d, _p(dw1), _p(dw2), _p(ds1), _p(ds2), _s()), "mmdit_text_rmsnorm_bwd")
     return dw1, dw2, ds1, ds2
@@ -263,6 +304,6 @@ def time_embed_fwd(t, time_scale, denom, out_dtype):
 
 def time_embed_bwd(dout, t, time_scale, denom):
     batch, dim = t.shape[0], denom.shape[0]
-    dts = torch.zeros_like(time_scale)
+    dts = zeros(time_scale.shape, time_scale.device)
     check(_lib.lib().mmdit_time_embed_bwd(_p(_c(dout)), _dt(dout), _p(t), _p(time_scale), _p(denom), batch, dim, _p(dts), _s()), "mmdit_time_embed_bwd")
     return dts
