@@ -107,8 +107,10 @@ def wgrad_join(device):
         torch.cuda.current_stream(device).wait_stream(st)
 
 
-def _zeros_views(shapes, dev):
-    """One zero-filled fp32 arena (one memset launch) carved into views of the given shapes."""
+def _zeros_views(shapes, dev, prefix=None):
+    """One zero-filled fp32 arena (one memset launch) carved into views of the given shapes.
+    prefix=k: also return the flat sub-arena that holds exactly the first k views (a data-parallel reducer averages the
+    parameter gradients of a block in place through it)."""
     sizes = [int(torch.Size(s).numel()) for s in shapes]
     pad = [(n + 3) // 4 * 4 for n in sizes]           # keep every view 16-byte aligned
     flat = ops.zeros(sum(pad), dev)                   # (a slice of the pass-wide zero pool on a GPU)
@@ -116,19 +118,23 @@ def _zeros_views(shapes, dev):
     for s, n, p in zip(shapes, sizes, pad):
         out.append(flat[off:off + n].view(s))
         off += p
+    if prefix is not None:
+        return out, flat[:sum(pad[:prefix])]
     return out
 
 
 def _wgrad_flush(m, pending):
     """pending: list of (setter, descriptor).  Grouped launches (<= 12 problems each), on the side stream."""
+    arena = None
     if not pending:
-        return
+        return arena
     overlap = _WG_OVERLAP and pending[0][1]["A"].is_cuda
     if overlap:
         dev = pending[0][1]["A"].device
         # outputs come from the main stream's pool (one zeroed arena: stream-K adds partial tiles atomically);
         # inputs must outlive the side-stream reads (record_stream below)
-        for (_, d), o in zip(pending, _zeros_views([(d["A"].shape[1], d["B"].shape[1]) for _, d in pending], dev)):
+        outs, arena = _zeros_views([(d["A"].shape[1], d["B"].shape[1]) for _, d in pending], dev, prefix=len(pending))
+        for (_, d), o in zip(pending, outs):
             d["out"] = o
         side = wgrad_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -147,6 +153,7 @@ def _wgrad_flush(m, pending):
         for _, d in pending:
             d["A"].record_stream(side)
             d["B"].record_stream(side)
+    return arena   # the flat buffer that holds every output of this flush (None: outputs were allocated one by one)
 
 
 class _NullCtx:
@@ -242,12 +249,15 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
     # every atomically-accumulated small gradient of the block comes from ONE zeroed arena (one memset launch)
     hx = sv.gu_x.shape[1]
     nb = 2 if both else 1
-    shapes = [tuple(sv.mod.shape), (nb * d,), (hx,), (64,), (64,), (64,), (64,), (d,), (B, nb * d)] + ([(sv.gu_c.shape[1],)] if both else [])
-    zs = _zeros_views(shapes, dev)
-    dmod, bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c, g.by, bpart = zs[:9]   # bpart: per-batch partial rows of the down-proj bias grads
+    # parameter gradients first (they form one flat sub-arena a reducer can average in place), scratch after them
+    shapes = [(nb * d,), (hx,), (64,), (64,), (64,), (64,), (d,)] + ([(sv.gu_c.shape[1],)] if both else []) + [tuple(sv.mod.shape), (B, nb * d)]
+    npar = len(shapes) - 2
+    zs, small_arena = _zeros_views(shapes, dev, prefix=npar)
+    bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c, g.by = zs[:7]
+    dmod, bpart = zs[npar], zs[npar + 1]   # bpart: per-batch partial rows of the down-proj bias grads
     g.mlp_x.bdown = bdown[:d]
     if both:
-        g.mlp_c.bdown, g.mlp_c.bup = bdown[d:], zs[9]
+        g.mlp_c.bdown, g.mlp_c.bup = bdown[d:], zs[7]
     dms = _mod_views(dmod, d, w.last)
     pending = []   # deferred weight-gradient GEMMs: (setter, descriptor)
 
@@ -304,7 +314,9 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
     dy_acc = _dgrad(m, dpre, w.Wy, F32, residual=dy_acc)
     defer(g, "Wy", dpre, sv.y)
 
-    _wgrad_flush(m, pending)   # all weight gradients of the block in one grouped launch
+    wg_arena = _wgrad_flush(m, pending)   # all weight gradients of the block in one grouped launch
+    # every parameter gradient of the block lives in one of these two flat buffers (None: not the case, e.g. overlap off)
+    g.arenas = [wg_arena, small_arena] if wg_arena is not None else None
     return dX, dC, dy_acc, g
 
 
@@ -355,6 +367,17 @@ def _grad_tensors(g):
     return out
 
 
+def _set_grad_tensors(g, new, pos=0):
+    """Replace the tensors of g (same traversal order as _grad_tensors) by `new`; returns the next position."""
+    for k, v in list(vars(g).items()):
+        if isinstance(v, NS):
+            pos = _set_grad_tensors(v, new, pos)
+        elif torch.is_tensor(v):
+            setattr(g, k, new[pos])
+            pos += 1
+    return pos
+
+
 def model_bwd(m, W, sv, dv, rope, on_grads=None):
     """Returns grads: NS with top-level packed-weight grads and .blocks = [block grads].
     on_grads(list_of_tensors) is called as soon as a group of parameter gradients is final (block by
@@ -387,7 +410,10 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
         dX, dC, dy_acc, g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, dy_acc, sv.dims, rope)
         sv.blocks[i] = None  # free saved activations as we go
         if on_grads is not None:
-            on_grads(_grad_tensors(g.blocks[i]), _wg_streams.get(dev))
+            # the reducer may hand back views of its flat bucket (zero copy-back): use them as this block's gradients
+            repl = on_grads(_grad_tensors(g.blocks[i]), _wg_streams.get(dev), g.blocks[i].arenas)
+            if repl is not None:
+                _set_grad_tensors(g.blocks[i], repl)
 
     # patch embedding
     g.bpe = ops.zeros(d, dev)
@@ -414,6 +440,10 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     g.time_scale = ops.time_embed_bwd(dpe, sv.t, W.time_scale, W.denom)
     _wgrad_flush(m, pending)
     if on_grads is not None:
-        on_grads([v for v in vars(g).values() if torch.is_tensor(v)], _wg_streams.get(dev))
+        keys = [k for k, v in vars(g).items() if torch.is_tensor(v)]
+        repl = on_grads([getattr(g, k) for k in keys], _wg_streams.get(dev))
+        if repl is not None:
+            for k, t in zip(keys, repl):
+                setattr(g, k, t)
     wgrad_join(dev)
     return g

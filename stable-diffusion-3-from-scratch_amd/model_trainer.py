@@ -166,7 +166,11 @@ class model_trainer:
             batch_x_0, batch_txt, batch_txt_pooled = self.data_source()
             t_vals, n_pooled, n_gemma, n_bert = self._sample_conditioning(batch_x_0.shape[0])
             batch_x_t, epsilon_t = self.model.noise_batch(batch_x_0, t_vals)
-        self.reducer.skip = not final
+        # Hook path (post-accumulate hooks see the ACCUMULATED gradient): reduce on the final micro-step only (DDP no_sync).
+        # Engine path (the backward schedule hands over each micro-step's own gradients): every micro-step is averaged,
+        # which sums to the same mean and is what plain DDP does on every backward (reference model_trainer.py:467).
+        engine_path = getattr(self.model, "grad_reducer", None) is self.reducer and self.reducer.enabled
+        self.reducer.skip = (not final) and not engine_path
         v_pred = self.model(batch_x_t.detach(), t_vals, batch_txt, batch_txt_pooled, n_pooled, n_gemma, n_bert)
         labels = epsilon_t - batch_x_0.to(epsilon_t.device)
         loss = nn.MSELoss(reduction="none")(v_pred, labels.detach().to(v_pred.dtype)).flatten(1, -1).mean()
@@ -175,7 +179,7 @@ class model_trainer:
             self.grad_scaler.scale(loss).backward()
         else:
             loss.backward()
-        if final:
+        if final or engine_path:
             self.reducer.finish()
         return loss.detach()
 

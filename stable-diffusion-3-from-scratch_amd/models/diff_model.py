@@ -40,7 +40,7 @@ class _MMDiTFn(torch.autograd.Function):
         net, m = ctx.net, ctx.m
         W = net.weights(m)
         red = net.grad_reducer
-        g = engine.model_bwd(m, W, ctx.sv, dv, ctx.rope, on_grads=red.add if red is not None else None)
+        g = engine.model_bwd(m, W, ctx.sv, dv, ctx.rope, on_grads=red.add_bucket if red is not None else None)
         ctx.sv = None
         out = {}
         net.scatter_grads(g, out)

@@ -24,6 +24,7 @@ class GradReducer:
         self._inflight = []      # (flat, tensors, work)
         self._after = None
         self.skip = False        # True on non-final gradient-accumulation micro-steps (no_sync semantics)
+        self._views_wanted = False
 
     def _side(self, device):
         if self._stream is None:
@@ -31,6 +32,53 @@ class GradReducer:
         return self._stream
 
     # ---- called by the engine (or the hook fallback) as gradients become final -----------------
+    def _reduce_in_place(self, arenas):
+        """All-reduce flat buffers where they are (no gather, no copy-back)."""
+        if arenas[0].is_cuda:
+            side = self._side(arenas[0].device)
+            side.wait_stream(torch.cuda.current_stream())
+            if self._after is not None:
+                side.wait_stream(self._after)
+            ctx = torch.cuda.stream(side)
+        else:
+            ctx = _null()
+        nccl = dist.get_backend(self.group) == "nccl"
+        with ctx:
+            for a in arenas:
+                work = dist.all_reduce(a, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._inflight.append((a, None, work, not nccl))
+        # no record_stream: the buffers are released on the main stream, which has waited for this stream in finish()
+
+    def add_bucket(self, tensors, after=None, arenas=None):
+        """Engine path (zero copy-back): `tensors` become ONE bucket right away; returns replacement tensors -- views of
+        the flat bucket, same shapes and order -- that hold the averaged gradients once finish() has run.  The caller
+        uses them in place of `tensors` (which are not written back), so the ~400 per-parameter copy-back launches of
+        the generic path and a second pass over the gradients disappear.  With `arenas` (flat buffers that ARE the storage
+        of `tensors`) even the gather copy goes away.  Returns None when the caller keeps using `tensors`."""
+        if after is not None:
+            self._after = after
+        if not self.enabled or self.skip:
+            return None
+        tensors = [t for t in tensors if t is not None]
+        if not tensors:
+            return None
+        self.flush()                      # keep the launch order of anything queued through add()
+        if arenas:
+            # the producer guarantees that `tensors` are exactly the contents of these flat buffers (engine.block_bwd):
+            # average them where they are -- no gather copy, no replacement
+            self._reduce_in_place(arenas)
+            return None
+        self._pending, self._pending_bytes = tensors, 1
+        self._views_wanted = True
+        self.flush()
+        flat = self._inflight[-1][0]
+        views, off = [], 0
+        for t in tensors:
+            n = t.numel()
+            views.append(flat[off:off + n].view(t.shape))
+            off += n
+        return views
+
     def add(self, tensors, after=None):
         """tensors: gradients that are final once the current stream (and `after`, the stream that produced
         the weight gradients, if given) reach this point."""
@@ -69,7 +117,9 @@ class GradReducer:
         else:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             div = True
-        self._inflight.append((flat, tensors, work, div))
+        # (flat, tensors to copy back into | None when the caller took views of flat, work, divide-after)
+        self._inflight.append((flat, None if self._views_wanted else tensors, work, div))
+        self._views_wanted = False
 
     # ---- called by the trainer after backward(), before clip / optimizer step --------------------
     def finish(self):
@@ -83,11 +133,13 @@ class GradReducer:
                 work.wait()
                 if div:
                     flat.div_(self.world)
-                off = 0
-                for t in tensors:
-                    n = t.numel()
-                    t.copy_(flat[off:off + n].view_as(t))
-                    off += n
+                if tensors is not None:
+                    outs, off = [], 0
+                    for t in tensors:
+                        n = t.numel()
+                        outs.append(flat[off:off + n].view_as(t))
+                        off += n
+                    torch._foreach_copy_(tensors, outs)
         self._inflight = []
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)

@@ -103,3 +103,56 @@ def test_two_rank_gloo_matches_single_process(accum):
         assert (a == b).all(), "ranks diverged"
     for a, r in zip(res[0], _reference(world, accum)):
         assert torch.allclose(torch.from_numpy(a), r, atol=1e-6)
+
+
+def _bucket_worker(rank, world, port, q):
+    """Engine path: add_bucket() hands back views of the flat bucket that hold the averaged gradients after finish();
+    with gradient accumulation every micro-step is averaged and the views are accumulated like ordinary gradients."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sd3_amd  # noqa: F401
+    from sd3_amd.reducer import GradReducer
+    red = GradReducer()
+    acc = None
+    for micro in range(2):
+        g = torch.Generator().manual_seed(10 * micro + rank)
+        grads = [torch.randn(5, 7, generator=g), None, torch.randn(11, generator=g), torch.randn(3, 4, 2, generator=g)]
+        views = red.add_bucket(grads)
+        more = red.add_bucket([torch.full((6,), float(rank + micro))])      # a second bucket in flight
+        arena = torch.arange(10, dtype=torch.float32) * (rank + 1)          # gradients that already live in one flat buffer:
+        inplace = [arena[:4].view(2, 2), arena[4:]]                        # averaged where they are, nothing handed back
+        assert red.add_bucket(inplace, arenas=[arena]) is None
+        red.finish()
+        assert torch.allclose(arena, torch.arange(10, dtype=torch.float32) * 1.5) and torch.equal(inplace[1], arena[4:])
+        assert len(views) == 3 and [v.shape for v in views] == [grads[0].shape, grads[2].shape, grads[3].shape]
+        cur = views + more
+        acc = cur if acc is None else [a + c for a, c in zip(acc, cur)]
+    q.put((rank, [a.numpy().copy() for a in acc]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_bucket_views():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = None
+    for micro in range(2):
+        per_rank = []
+        for rank in range(world):
+            g = torch.Generator().manual_seed(10 * micro + rank)
+            per_rank.append([torch.randn(5, 7, generator=g), torch.randn(11, generator=g), torch.randn(3, 4, 2, generator=g),
+                             torch.full((6,), float(rank + micro))])
+        mean = [sum(ts) / world for ts in zip(*per_rank)]
+        want = mean if want is None else [w + m for w, m in zip(want, mean)]
+    for rank in range(world):
+        for a, w in zip(res[rank], want):
+            assert torch.allclose(torch.from_numpy(a), w, atol=1e-6)
