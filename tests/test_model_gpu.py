@@ -420,3 +420,36 @@ def test_full_size_properties_mmdit_b_batch64():
     r = rel(vf, v64)
     print(f"[full size] fast (bf16) vs parity output, batch 64: rel-L2 = {r:.3e}")
     assert r < 2e-2
+
+
+def test_gpu_resident_ema_matches_reference_cpu_loop():
+    """update_ema on the GPU-resident average == the reference's per-parameter CPU loop (model_trainer.py:537-541);
+    sync_ema_to_cpu() brings `ema_model_cpu` (what the checkpoint stores) up to date."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+
+    def make(on_gpu):
+        torch.manual_seed(0)
+        net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                         device=torch.device("cuda:0"), positional_encoding="RoPE2d", **CONFIGS["micro"])
+        net.load_state_dict(make_state_dict(0, **CONFIGS["micro"]))
+        return model_trainer(net, batchSize=4, accumulation_steps=1, totalSteps=10, lr=1e-3, ema_update_freq=1, ema_decay=0.9, warmup_steps=0,
+                             use_lr_scheduler=False, device=torch.device("cuda:0"), saveDir="/tmp/_t", numSaveSteps=100, max_res=128,
+                             device_rng=True, use_ema=True, ema_on_gpu=on_gpu)
+
+    res = []
+    for on_gpu in (True, False):
+        tr = make(on_gpu)
+        assert (tr._ema_gpu is not None) == on_gpu
+        g = torch.Generator(device="cuda").manual_seed(9)
+        for _ in range(3):
+            with torch.no_grad():
+                for p in tr.model.parameters():
+                    if p.requires_grad:
+                        p.add_(torch.randn(p.shape, generator=g, device="cuda") * 0.01)
+            tr.update_ema()
+        res.append({k: v.clone() for k, v in tr.sync_ema_to_cpu().state_dict().items()})
+    for k in res[0]:
+        assert torch.allclose(res[0][k], res[1][k], rtol=1e-6, atol=1e-8), k
+    assert any(not torch.equal(res[0][k], make_state_dict(0, **CONFIGS["micro"])[k]) for k in res[0])
