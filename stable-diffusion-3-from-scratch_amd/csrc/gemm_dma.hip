@@ -56,7 +56,8 @@ __device__ __forceinline__ void glds16(uint32_t voff, const char* sbase_, uint32
   const uint64_t a = (uint64_t)(uintptr_t)sbase_;   // wave-uniform by construction; make that explicit for the "s" operands
   const char* sbase = (const char*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a));
   const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+  // s_nop 4: the SGPR base may come straight from v_readfirstlane (VALU-written SGPR -> VMEM address needs 5 wait states)
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
 template <bool KM, int R>
