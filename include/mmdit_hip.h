@@ -197,6 +197,30 @@ int mmdit_unpatchify(const void* tokens, int tok_dtype, int batch, int ch, int H
 int mmdit_time_embed_fwd(const float* t, const float* time_scale, const float* denom, int batch, int dim, void* out, int out_dtype, mmdit_stream_t stream);
 int mmdit_time_embed_bwd(const void* dout, int dout_dtype, const float* t, const float* time_scale, const float* denom, int batch, int dim, float* dtime_scale, mmdit_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * FLUX VAE (diffusers AutoencoderKL) building blocks.  Call sites in the reference:
+ * helpers/VAE_T5_CLIP.py:176-182 and helpers/VAE_T5_CLIP_inference.py:25-43 (encode), models/diff_model.py:467-477 (decode).
+ * Activations are NHWC bf16 with channel counts that are multiples of 8; a 3x3 convolution is
+ * mmdit_vae_im2col3x3 + mmdit_gemm with the weight re-laid as [Cout][kh][kw][Cin].
+ * ------------------------------------------------------------------------- */
+/* NCHW (fp32 | bf16) -> NHWC bf16, channels zero-padded to C_padded; value = (x + shift) * scale
+ * (decode entry: (z - shift_factor) / scaling_factor, diff_model.py:467). */
+int mmdit_vae_nchw_to_nhwc(const void* src, int src_dtype, int batch, int C, int H, int W, int C_padded, float scale, float shift,
+                           void* dst_bf16, mmdit_stream_t stream);
+/* NHWC fp32 (row pitch ld >= C) -> NCHW fp32, clamped to [lo, hi] (.sample.clamp(-1, 1), diff_model.py:467-477). */
+int mmdit_vae_nhwc_to_nchw(const float* src, int batch, int C, int H, int W, int ld, float lo, float hi, float* dst, mmdit_stream_t stream);
+/* im2col of a 3x3 convolution: dst[(b,yo,xo), (kh*3+kw)*C + c].  mode 0: stride 1, padding 1 (nn.Conv2d(…, 3, padding=1));
+ * mode 1: stride 2 after padding (0,1,0,1) (diffusers Downsample2D, padding=0); mode 2: nearest x2 upsampling then
+ * stride 1, padding 1 (diffusers Upsample2D) -- output (2H, 2W), the upsampled tensor is never materialised. */
+int mmdit_vae_im2col3x3(const void* src_bf16, int batch, int H, int W, int C, int mode, void* dst_bf16, mmdit_stream_t stream);
+/* GroupNorm(groups, C, eps, affine) over NHWC x (fp32 | bf16), optional SiLU, bf16 out (ResnetBlock2D norm1/norm2,
+ * Attention.group_norm, conv_norm_out).  sums_zeroed: batch*groups*2 fp32 scratch, zero on entry. */
+int mmdit_vae_groupnorm(const void* x, int x_dtype, const float* gamma, const float* beta, int batch, int HW, int C, int groups, float eps, int silu,
+                        float* sums_zeroed, void* y_bf16, mmdit_stream_t stream);
+/* y = softmax(scale * x) over the first `cols` entries of each row (pitch ld, padding written as 0), fp32 -> bf16
+ * (single-head mid-block attention, attention_processor.py). */
+int mmdit_vae_softmax_rows(const float* x, int rows, int cols, int ld, float scale, void* y_bf16, mmdit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

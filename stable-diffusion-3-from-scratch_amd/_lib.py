@@ -59,6 +59,11 @@ _SIGNATURES = {
     "mmdit_silu_bwd": ([_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "mmdit_gate_residual_bwd": ([_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp], _i),
     "mmdit_colsum": ([_vp, _i, _i, _i, _i64, _vp, _vp], _i),
+    "mmdit_vae_nchw_to_nhwc": ([_vp, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_float, _vp, _vp], _i),
+    "mmdit_vae_nhwc_to_nchw": ([_vp, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_float, _vp, _vp], _i),
+    "mmdit_vae_im2col3x3": ([_vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
+    "mmdit_vae_groupnorm": ([_vp, _i, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp], _i),
+    "mmdit_vae_softmax_rows": ([_vp, _i, _i, _i, ctypes.c_float, _vp, _vp], _i),
     "mmdit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
     "mmdit_unpatchify": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
     "mmdit_time_embed_fwd": ([_vp, _vp, _vp, _i, _i, _vp, _i, _vp], _i),

@@ -307,3 +307,47 @@ def time_embed_bwd(dout, t, time_scale, denom):
     dts = zeros(time_scale.shape, time_scale.device)
     check(_lib.lib().mmdit_time_embed_bwd(_p(_c(dout)), _dt(dout), _p(t), _p(time_scale), _p(denom), batch, dim, _p(dts), _s()), "mmdit_time_embed_bwd")
     return dts
+
+
+# ---------------------------------------------------------------------------------------------
+# FLUX VAE building blocks (csrc/vae.hip); activations NHWC bf16
+# ---------------------------------------------------------------------------------------------
+def vae_nchw_to_nhwc(x, c_padded, scale=1.0, shift=0.0):
+    B, C, H, W = x.shape
+    out = torch.empty((B, H, W, c_padded), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmdit_vae_nchw_to_nhwc(_p(_c(x)), _dt(x), B, C, H, W, c_padded, float(scale), float(shift), _p(out), _s()), "mmdit_vae_nchw_to_nhwc")
+    return out
+
+
+def vae_nhwc_to_nchw(x2d, B, C, H, W, lo=-float("inf"), hi=float("inf")):
+    """x2d: fp32 (B*H*W, ld) rows = pixels; returns fp32 (B, C, H, W) of the first C columns, clamped."""
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x2d.device)
+    check(_lib.lib().mmdit_vae_nhwc_to_nchw(_p(_c(x2d)), B, C, H, W, x2d.shape[1], float(lo), float(hi), _p(out), _s()), "mmdit_vae_nhwc_to_nchw")
+    return out
+
+
+def vae_im2col3x3(x, mode=0):
+    """x: bf16 (B, H, W, C) -> bf16 (B*Ho*Wo, 9*C); mode 0 same / 1 stride-2 downsample / 2 nearest-x2 upsample then conv."""
+    B, H, W, C = x.shape
+    Ho, Wo = (H // 2, W // 2) if mode == 1 else (2 * H, 2 * W) if mode == 2 else (H, W)
+    out = torch.empty((B * Ho * Wo, 9 * C), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmdit_vae_im2col3x3(_p(_c(x)), B, H, W, C, mode, _p(out), _s()), "mmdit_vae_im2col3x3")
+    return out, Ho, Wo
+
+
+def vae_groupnorm(x, gamma, beta, B, HW, groups, eps, silu):
+    """x: (B*HW, C) fp32 or bf16 -> bf16 (B*HW, C)."""
+    C = x.shape[1]
+    sums = torch.zeros(B * groups * 2, dtype=torch.float32, device=x.device)
+    out = torch.empty((B * HW, C), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmdit_vae_groupnorm(_p(_c(x)), _dt(x), _p(gamma), _p(beta), B, HW, C, groups, float(eps), int(silu), _p(sums), _p(out), _s()), "mmdit_vae_groupnorm")
+    return out
+
+
+def vae_softmax_rows(x, scale, cols=None):
+    """softmax over the first `cols` columns of every row of x (fp32); the remaining (padding) columns come out as 0."""
+    rows, ld = x.shape
+    cols = ld if cols is None else cols
+    out = torch.empty((rows, ld), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmdit_vae_softmax_rows(_p(_c(x)), rows, cols, ld, float(scale), _p(out), _s()), "mmdit_vae_softmax_rows")
+    return out

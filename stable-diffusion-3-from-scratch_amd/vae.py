@@ -1,0 +1,250 @@
+"""FLUX.1-schnell VAE (`diffusers.AutoencoderKL`) on the MI355X kernels -- inference only, as the reference
+uses it: frozen, bf16, `encode(x).latent_dist.sample()` on the data side (helpers/VAE_T5_CLIP.py:176-182,
+helpers/VAE_T5_CLIP_inference.py:25-43) and `decode(z).sample` in the sampler (models/diff_model.py:467-477).
+
+Mirror of the diffusers interface that those call sites touch: `.config.{latent_channels, scaling_factor, shift_factor}`,
+`.dtype`, `.encode(x).latent_dist.sample()/.mode()`, `.decode(z).sample`, parameters under diffusers' state_dict keys
+(a real `diffusion_pytorch_model.safetensors` loads with `load_state_dict`).  Every convolution is
+im2col (csrc/vae.hip) + the MFMA GEMM (bf16 operands, fp32 accumulate), GroupNorm+SiLU one fused two-pass kernel, the
+mid-block attention GEMM + row softmax + GEMM.  No CPU / PyTorch-math fallback.  First correct path: not yet tuned
+(im2col is materialised; the implicit-GEMM operand gather is the next step)."""
+import math
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+class _Conv(nn.Module):
+    """nn.Conv2d parameter holder (weight (Cout, Cin, k, k), bias) + the packed bf16 GEMM operand [Cout_p][k*k*Cin_p]."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
+        self.bias = nn.Parameter(torch.empty(cout))
+        self.cin, self.cout, self.k = cin, cout, k
+        self._packed = None
+
+    def packed(self):
+        key = (self.weight._version, self.bias._version, self.weight.device)
+        if self._packed is None or self._packed[0] != key:
+            cin_p, cout_p = _pad8(self.cin), _pad8(self.cout)
+            w = torch.zeros((cout_p, self.k, self.k, cin_p), dtype=F32, device=self.weight.device)
+            w[:self.cout, :, :, :self.cin] = self.weight.detach().permute(0, 2, 3, 1)
+            b = torch.zeros(cout_p, dtype=F32, device=self.weight.device)
+            b[:self.cout] = self.bias.detach()
+            self._packed = (key, w.reshape(cout_p, -1).to(BF16).contiguous(), b)
+        return self._packed[1], self._packed[2]
+
+
+class _Norm(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c))
+        self.bias = nn.Parameter(torch.empty(c))
+
+
+class _Linear(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(c, c))
+        self.bias = nn.Parameter(torch.empty(c))
+
+
+class _Resnet(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.norm1, self.conv1 = _Norm(cin), _Conv(cin, cout, 3)
+        self.norm2, self.conv2 = _Norm(cout), _Conv(cout, cout, 3)
+        if cin != cout:
+            self.conv_shortcut = _Conv(cin, cout, 1)
+
+
+class _Attn(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.group_norm = _Norm(c)
+        self.to_q, self.to_k, self.to_v = _Linear(c), _Linear(c), _Linear(c)
+        self.to_out = nn.ModuleList([_Linear(c)])
+
+
+class _Mid(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.attentions = nn.ModuleList([_Attn(c)])
+        self.resnets = nn.ModuleList([_Resnet(c, c), _Resnet(c, c)])
+
+
+class _Sampler(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = _Conv(c, c, 3)
+
+
+class _Down(nn.Module):
+    def __init__(self, cin, cout, n, down):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(cin if j == 0 else cout, cout) for j in range(n)])
+        if down:
+            self.downsamplers = nn.ModuleList([_Sampler(cout)])
+
+
+class _Up(nn.Module):
+    def __init__(self, cin, cout, n, up):
+        super().__init__()
+        self.resnets = nn.ModuleList([_Resnet(cin if j == 0 else cout, cout) for j in range(n)])
+        if up:
+            self.upsamplers = nn.ModuleList([_Sampler(cout)])
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        ch = cfg.block_out_channels
+        self.conv_in = _Conv(cfg.in_channels, ch[0], 3)
+        self.down_blocks = nn.ModuleList([_Down(ch[max(i - 1, 0)], c, cfg.layers_per_block, i != len(ch) - 1) for i, c in enumerate(ch)])
+        self.mid_block = _Mid(ch[-1])
+        self.conv_norm_out = _Norm(ch[-1])
+        self.conv_out = _Conv(ch[-1], 2 * cfg.latent_channels, 3)
+
+
+class _Decoder(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        rev = list(reversed(cfg.block_out_channels))
+        self.conv_in = _Conv(cfg.latent_channels, rev[0], 3)
+        self.mid_block = _Mid(rev[0])
+        self.up_blocks = nn.ModuleList([_Up(rev[max(i - 1, 0)], c, cfg.layers_per_block + 1, i != len(rev) - 1) for i, c in enumerate(rev)])
+        self.conv_norm_out = _Norm(rev[-1])
+        self.conv_out = _Conv(rev[-1], cfg.out_channels, 3)
+
+
+class _Act:
+    """An activation on the device: fp32 rows (B*H*W, C) = NHWC pixels, plus its geometry."""
+
+    def __init__(self, x, B, H, W):
+        self.x, self.B, self.H, self.W = x, B, H, W
+
+
+class DiagonalGaussianDistribution:
+    """diffusers' class of the same name: moments (B, 2*latent, h, w) -> mean, clamped logvar; sample(), mode()."""
+
+    def __init__(self, moments):
+        self.mean, logvar = moments.chunk(2, dim=1)
+        self.logvar = logvar.clamp(-30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None):
+        return self.mean + self.std * torch.randn(self.mean.shape, generator=generator, device=self.mean.device, dtype=self.mean.dtype)
+
+    def mode(self):
+        return self.mean
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, in_channels=3, out_channels=3, latent_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 norm_num_groups=32, scaling_factor=0.3611, shift_factor=0.1159, device="cuda"):
+        super().__init__()
+        self.config = SimpleNamespace(in_channels=in_channels, out_channels=out_channels, latent_channels=latent_channels,
+                                      block_out_channels=tuple(block_out_channels), layers_per_block=layers_per_block,
+                                      norm_num_groups=norm_num_groups, scaling_factor=scaling_factor, shift_factor=shift_factor,
+                                      use_quant_conv=False, use_post_quant_conv=False, force_upcast=True)
+        self.encoder = _Encoder(self.config)
+        self.decoder = _Decoder(self.config)
+        self.eps = 1e-6
+        self.to(device)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @property
+    def dtype(self):
+        return BF16     # what the reference casts the VAE to (VAE_T5_CLIP_inference.py:32); the sampler feeds `output.to(VAE.dtype)`
+
+    # ---- building blocks ----------------------------------------------------------------------
+    def _gn(self, a, norm, silu):
+        return ops.vae_groupnorm(a.x, norm.weight, norm.bias, a.B, a.H * a.W, self.config.norm_num_groups, self.eps, silu)
+
+    def _conv3(self, xb, a, conv, mode=0, residual=None):
+        """xb: bf16 (B*H*W, Cin_p) NHWC rows.  Returns _Act with fp32 (B*Ho*Wo, Cout_p)."""
+        w, b = conv.packed()
+        cols, Ho, Wo = ops.vae_im2col3x3(xb.view(a.B, a.H, a.W, xb.shape[1]), mode)
+        y = ops.gemm(cols, w, bias=b, residual=residual, out_dtype=F32)
+        return _Act(y, a.B, Ho, Wo)
+
+    def _resnet(self, a, r):
+        h = self._conv3(self._gn(a, r.norm1, True), a, r.conv1)
+        sc = a.x
+        if hasattr(r, "conv_shortcut"):
+            w, b = r.conv_shortcut.packed()
+            sc = ops.gemm(ops.cast(a.x, BF16), w, bias=b, out_dtype=F32)
+        return self._conv3(self._gn(h, r.norm2, True), h, r.conv2, residual=sc)
+
+    def _attn(self, a, at):
+        B, HW, C = a.B, a.H * a.W, a.x.shape[1]
+        h = self._gn(a, at.group_norm, False)
+        wb = lambda l: (l.weight.detach().to(BF16), l.bias.detach())
+        (wq, bq), (wk, bk), (wv, bv), (wo, bo) = wb(at.to_q), wb(at.to_k), wb(at.to_v), wb(at.to_out[0])
+        q = ops.gemm(h, wq, bias=bq, out_dtype=BF16)
+        k = ops.gemm(h, wk, bias=bk, out_dtype=BF16)
+        v = ops.gemm(h, wv, bias=bv, out_dtype=BF16)
+        o = torch.empty((B * HW, C), dtype=BF16, device=h.device)
+        HWp = _pad8(HW)         # GEMM operands need 16-byte rows: keys / values are zero-padded to a multiple of 8 tokens
+        kp, vp = torch.zeros((HWp, C), dtype=BF16, device=h.device), torch.zeros((HWp, C), dtype=BF16, device=h.device)
+        for i in range(B):      # one head of width C: plain GEMMs per image
+            kp[:HW].copy_(k[i * HW:(i + 1) * HW])
+            vp[:HW].copy_(v[i * HW:(i + 1) * HW])
+            s = ops.gemm(q[i * HW:(i + 1) * HW], kp, out_dtype=F32)                 # (HW, HWp)
+            p = ops.vae_softmax_rows(s, 1.0 / math.sqrt(C), cols=HW)               # padding columns = 0
+            ops.gemm(p, vp, b_kmajor=True, out=o[i * HW:(i + 1) * HW])
+        return _Act(ops.gemm(o, wo, bias=bo, residual=a.x, out_dtype=F32), a.B, a.H, a.W)
+
+    def _mid(self, a, m):
+        a = self._resnet(a, m.resnets[0])
+        a = self._attn(a, m.attentions[0])
+        return self._resnet(a, m.resnets[1])
+
+    # ---- public interface -----------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x):
+        """x: (B, 3, H, W) image in [-1, 1] (any float dtype), H and W multiples of 8."""
+        if not x.is_cuda:
+            raise RuntimeError("the VAE runs on the HIP kernels only (no CPU fallback)")
+        B, C, H, W = x.shape
+        e = self.encoder
+        xb = ops.vae_nchw_to_nhwc(x.contiguous() if x.dtype in (F32, BF16) else x.float().contiguous(), _pad8(C))
+        a = self._conv3(xb.view(B * H * W, -1), _Act(None, B, H, W), e.conv_in)
+        for blk in e.down_blocks:
+            for r in blk.resnets:
+                a = self._resnet(a, r)
+            if hasattr(blk, "downsamplers"):
+                a = self._conv3(ops.cast(a.x, BF16), a, blk.downsamplers[0].conv, mode=1)
+        a = self._mid(a, e.mid_block)
+        a = self._conv3(self._gn(a, e.conv_norm_out, True), a, e.conv_out)
+        moments = ops.vae_nhwc_to_nchw(a.x, B, 2 * self.config.latent_channels, a.H, a.W)
+        return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(moments))
+
+    @torch.no_grad()
+    def decode(self, z):
+        """z: (B, latent, h, w) in VAE space (the caller applied (z - shift_factor) / scaling_factor)."""
+        if not z.is_cuda:
+            raise RuntimeError("the VAE runs on the HIP kernels only (no CPU fallback)")
+        B, C, H, W = z.shape
+        d = self.decoder
+        zb = ops.vae_nchw_to_nhwc(z.contiguous() if z.dtype in (F32, BF16) else z.float().contiguous(), _pad8(C))
+        a = self._conv3(zb.view(B * H * W, -1), _Act(None, B, H, W), d.conv_in)
+        a = self._mid(a, d.mid_block)
+        for blk in d.up_blocks:
+            for r in blk.resnets:
+                a = self._resnet(a, r)
+            if hasattr(blk, "upsamplers"):
+                a = self._conv3(ops.cast(a.x, BF16), a, blk.upsamplers[0].conv, mode=2)
+        a = self._conv3(self._gn(a, d.conv_norm_out, True), a, d.conv_out)
+        return SimpleNamespace(sample=ops.vae_nhwc_to_nchw(a.x, B, self.config.out_channels, a.H, a.W))
