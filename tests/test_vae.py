@@ -97,3 +97,46 @@ def test_vae_kernels_vs_torch():
     assert rel(got.float(), ref) < 5e-3
     s = torch.randn(37, 100, generator=g) * 3
     assert rel(ops.vae_softmax_rows(s.cuda(), 0.25).float(), torch.softmax(s * 0.25, -1)) < 5e-3
+
+
+@pytest.mark.gpu
+def test_sampler_with_hip_vae_decode():
+    """diff_model.sample_imgs end to end with the HIP VAE in place of the stand-in: the decoded image must equal the
+    oracle VAE decode of the latent the same sampler produces with an identity VAE (diff_model.py:467-477:
+    decode((z - shift) / scale).sample.clamp(-1, 1))."""
+    import sd3_amd  # noqa: F401
+    from oracle.weights import make_inputs, make_state_dict
+    from sd3_amd.helpers.VAE_inference import VAE_inference
+    from sd3_amd.models.diff_model import diff_model
+    cfgm = dict(dim=128, num_heads=2, num_blocks=3)
+    net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                     device=torch.device("cuda:0"), positional_encoding="RoPE2d", **cfgm)
+    net.load_state_dict(make_state_dict(0, **cfgm))
+    net.set_precision("parity")
+    _, th, tp = make_inputs(40, 1, 16, 16, text_scale=30.0)
+    vsd = V.make_state_dict(3)
+
+    class _Text:
+        def text_to_embedding(self, text):
+            return th.clone(), tp.clone()
+
+    class _Identity:
+        config, dtype = V.VAEConfig(), torch.float32
+
+        def decode(self, z):
+            class D:
+                sample = z * 1e-3      # keeps the sampler's clamp(-1, 1) inactive
+            return D
+
+    holder = VAE_inference(torch.device("cuda:0"), vsd)
+    holder.text_encoder = _Text()
+    net.text_encoders = holder
+    img = net.sample_imgs(1, 3, ["x"], cfg_scale=2.0, width=128, height=128, sampler="euler", generator=torch.Generator().manual_seed(7))
+    holder.VAE = _Identity()            # same sampler, latent passed through: (z - shift) / scale
+    lat = net.sample_imgs(1, 3, ["x"], cfg_scale=2.0, width=128, height=128, sampler="euler", generator=torch.Generator().manual_seed(7))
+    del net.text_encoders
+    want = V.decode(lat.float().cpu() * 1e3, vsd).clamp(-1, 1)
+    assert img.shape == (1, 3, 128, 128) and float(img.abs().max()) <= 1.0
+    r = rel(img, want)
+    print(f"[vae] sampler + HIP decode vs oracle decode rel-L2 = {r:.3e}")
+    assert r < 3e-2
