@@ -170,7 +170,8 @@ int mmdit_swiglu_bwd(const void* dh, const void* gu, void* dgu, int dtype, int r
 int mmdit_gelu_fwd(const void* u, void* h, int dtype, int rows, int hidden, mmdit_stream_t stream);
 int mmdit_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t stream);
 /* d(pre) = dy * silu'(pre): y_proj's SiLU (Transformer_Block_Dual.py:25-28). dbias accumulates column sums. */
-int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, mmdit_stream_t stream);
+int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, int rows_per_bias,
+                   mmdit_stream_t stream);   /* rows_per_bias > 0: dbias is (rows / rows_per_bias, cols), one row per group of rows (stacked blocks) */
 
 /* Backward of  Y = X + gate[b,:] * acc  (Transformer_Block_Dual.py:64-66,70-76):
  * dacc = dy * gate[b,:] (dtype dacc_dtype); dgate[b,:] += sum_rows dy*acc; dbias[b*ld_dbias + :] += sum_rows dacc (optional;

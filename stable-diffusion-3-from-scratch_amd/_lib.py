@@ -56,7 +56,7 @@ _SIGNATURES = {
     "mmdit_swiglu_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "mmdit_gelu_fwd": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "mmdit_gelu_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
-    "mmdit_silu_bwd": ([_vp, _i, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
+    "mmdit_silu_bwd": ([_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp], _i),
     "mmdit_gate_residual_bwd": ([_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp], _i),
     "mmdit_colsum": ([_vp, _i, _i, _i, _i64, _vp, _vp], _i),
     "mmdit_vae_nchw_to_nhwc": ([_vp, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_float, _vp, _vp], _i),

@@ -543,17 +543,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   colsum_flush(s, sbuf, out, c, cols);
 }
 
-// y_proj SiLU backward on a small (rows = batch, cols = d) matrix: 64 columns x 4 row lanes per block, the row lanes are
-// combined through LDS and the column owner adds into dbias (one writer per column: no atomics)
+// y_proj SiLU backward on small (rows, cols) matrices: 64 columns x 4 row lanes per block, the row lanes are combined
+// through LDS and the column owner adds into dbias (one writer per column: no atomics).  blockIdx.y = row group: rows
+// [g * rpg, (g+1) * rpg) feed dbias row g (the y_proj matrices of all transformer blocks stacked: one launch for all).
 template <typename TG, typename TO>
-__global__ __launch_bounds__(256) void silu_bwd_kernel(const TG* __restrict__ dy, const float* __restrict__ pre, TO* __restrict__ dpre, int rows, int cols, float* __restrict__ dbias) {
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const TG* __restrict__ dy, const float* __restrict__ pre, TO* __restrict__ dpre, int rpg, int cols, float* __restrict__ dbias) {
   __shared__ float sb[4][64];
   const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
+  const int r0 = blockIdx.y * rpg;
   float s = 0.f;
   if (c < cols) {
 #pragma unroll 4
-    for (int r = rl; r < rows; r += 4) {
+    for (int r = r0 + rl; r < r0 + rpg; r += 4) {
       const int64_t i = (int64_t)r * cols + c;
       const float p = pre[i], sig = sigmoid_f(p);
       const float g = io<TG>::ld(dy + i) * sig * (1.f + p * (1.f - sig));
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const TG* __restrict__ dy
   }
   sb[rl][cl] = s;
   __syncthreads();
-  if (rl == 0 && c < cols && dbias) dbias[c] += sb[0][cl] + sb[1][cl] + sb[2][cl] + sb[3][cl];
+  if (rl == 0 && c < cols && dbias) dbias[(int64_t)blockIdx.y * cols + c] += sb[0][cl] + sb[1][cl] + sb[2][cl] + sb[3][cl];
 }
 
 template <typename TI, typename TO>
@@ -764,13 +766,16 @@ extern "C" int mmdit_swiglu_bwd(const void* dh, const void* gu, void* dgu, int d
 extern "C" int mmdit_gelu_fwd(const void* u, void* h, int dtype, int rows, int hidden, mmdit_stream_t st) { return mlp_act_fwd<true>(u, h, dtype, rows, hidden, st); }
 extern "C" int mmdit_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t st) { return mlp_act_bwd<true>(dh, u, du, dtype, rows, hidden, dbias, st); }
 
-extern "C" int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, mmdit_stream_t stream) {
+extern "C" int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, int rows_per_bias,
+                              mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(dy && pre && dpre && rows > 0 && cols > 0);
+  const int rpg = rows_per_bias > 0 ? rows_per_bias : rows;
+  MMDIT_CHECK_ARG(rows % rpg == 0);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((cols + 63) / 64);
-  if (dy_dtype == MMDIT_BF16 && dpre_dtype == MMDIT_BF16) hipLaunchKernelGGL((silu_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, pre, (bf16_t*)dpre, rows, cols, dbias);
-  else if (dy_dtype == MMDIT_F32 && dpre_dtype == MMDIT_F32) hipLaunchKernelGGL((silu_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)dy, pre, (float*)dpre, rows, cols, dbias);
-  else if (dy_dtype == MMDIT_F32 && dpre_dtype == MMDIT_BF16) hipLaunchKernelGGL((silu_bwd_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)dy, pre, (bf16_t*)dpre, rows, cols, dbias);
+  dim3 grid((cols + 63) / 64, rows / rpg);
+  if (dy_dtype == MMDIT_BF16 && dpre_dtype == MMDIT_BF16) hipLaunchKernelGGL((silu_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dy, pre, (bf16_t*)dpre, rpg, cols, dbias);
+  else if (dy_dtype == MMDIT_F32 && dpre_dtype == MMDIT_F32) hipLaunchKernelGGL((silu_bwd_kernel<float, float>), grid, dim3(256), 0, s, (const float*)dy, pre, (float*)dpre, rpg, cols, dbias);
+  else if (dy_dtype == MMDIT_F32 && dpre_dtype == MMDIT_BF16) hipLaunchKernelGGL((silu_bwd_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)dy, pre, (bf16_t*)dpre, rpg, cols, dbias);
   else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }

@@ -187,15 +187,38 @@ def mlp_core_bwd(m, w, dacc, x_act, gu, h, dev):
 # ----------------------------------------------------------------------------------------------
 # Transformer_Block_Dual
 # ----------------------------------------------------------------------------------------------
-def block_fwd(m, w, X, C, y, dims, rope):
-    """X (B*N,d) fp32, C (B*M,d) fp32, y (B,d) in m.T.  Returns X2, C2, saved."""
+def cond_fwd_all(m, blocks, y):
+    """y' = SiLU(W_y y + b) and the adaLN modulation vectors of ALL transformer blocks in two grouped launches: they only
+    depend on the conditioning vector y (Transformer_Block_Dual.py:56-60), and as 2 x n_blocks separate M = batch GEMMs
+    they are pure launch latency on the critical path (~55 us per block).  Returns [(pre, yp, mod)] per block; pre / yp of
+    all blocks are row-stacked in one buffer each (cond_bwd_all runs one SiLU-backward launch over the stack)."""
+    B, d = y.shape
+    nb, dev = len(blocks), y.device
+    pre_all = torch.empty((nb * B, d), dtype=F32, device=dev)
+    yp_all = torch.empty((nb * B, d), dtype=m.T, device=dev)
+    pres = [pre_all[i * B:(i + 1) * B] for i in range(nb)]
+    yps = [yp_all[i * B:(i + 1) * B] for i in range(nb)]
+    mods = []
+    for i0 in range(0, nb, 12):
+        sl = range(i0, min(nb, i0 + 12))
+        _group(m, [dict(A=y, B=blocks[i].Wy, bias=blocks[i].by, act=ACT_SILU, aux=pres[i], out=yps[i]) for i in sl])
+        mods += _group(m, [dict(A=yps[i], B=blocks[i].Wmod, out_dtype=F32) for i in sl])
+    return [(pres[i], yps[i], mods[i]) for i in range(nb)], pre_all
+
+
+def block_fwd(m, w, X, C, y, dims, rope, cond=None):
+    """X (B*N,d) fp32, C (B*M,d) fp32, y (B,d) in m.T.  cond: this block's (pre, yp, mod) from cond_fwd_all.
+    Returns X2, C2, saved."""
     B, N, Mt, H, d = dims
     S, dev = N + Mt, X.device
     both = not w.last
     sv = NS(X=X, C=C, y=y)
-    sv.pre = torch.empty((B, d), dtype=F32, device=dev)
-    sv.yp = _gemm(m, y, w.Wy, bias=w.by, act=ACT_SILU, aux=sv.pre, out_dtype=m.T)
-    sv.mod = _gemm(m, sv.yp, w.Wmod, out_dtype=F32)
+    if cond is not None:
+        sv.pre, sv.yp, sv.mod = cond
+    else:
+        sv.pre = torch.empty((B, d), dtype=F32, device=dev)
+        sv.yp = _gemm(m, y, w.Wy, bias=w.by, act=ACT_SILU, aux=sv.pre, out_dtype=m.T)
+        sv.mod = _gemm(m, sv.yp, w.Wmod, out_dtype=F32)
     ms = _mod_views(sv.mod, d, w.last)
 
     sv.ln1x, sv.mu1x, sv.rs1x = ops.ln_modulate_fwd(X, ms.scale1x, ms.shift1x, N, m.T)
@@ -238,9 +261,11 @@ def block_fwd(m, w, X, C, y, dims, rope):
     return X2, C2, sv
 
 
-def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
+def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
     """dX2 (B*N,d) fp32, dC2 (B*M,d) fp32 or None, dy_acc (B,d) fp32 or None.
-    Returns dX, dC, dy_acc', grads (NS keyed like the packed weights)."""
+    Returns dX, dC, dy_acc', grads (NS keyed like the packed weights).
+    defer_cond: leave the backward of y' = SiLU(W_y y + b) to cond_bwd_all (one launch set for all blocks): the third
+    return value is then this block's modulation gradient in the activation dtype, and grads has no Wy / by."""
     B, N, Mt, H, d = dims
     S, dev = N + Mt, dX2.device
     both = not w.last
@@ -250,14 +275,17 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
     hx = sv.gu_x.shape[1]
     nb = 2 if both else 1
     # parameter gradients first (they form one flat sub-arena a reducer can average in place), scratch after them
-    shapes = [(nb * d,), (hx,), (64,), (64,), (64,), (64,), (d,)] + ([(sv.gu_c.shape[1],)] if both else []) + [tuple(sv.mod.shape), (B, nb * d)]
-    npar = len(shapes) - 2
+    shapes = [(nb * d,), (hx,), (64,), (64,), (64,), (64,)] + ([(sv.gu_c.shape[1],)] if both else []) + ([] if defer_cond else [(d,)])
+    npar = len(shapes)
+    shapes += [tuple(sv.mod.shape), (B, nb * d)]
     zs, small_arena = _zeros_views(shapes, dev, prefix=npar)
-    bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c, g.by = zs[:7]
+    bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c = zs[:6]
+    if not defer_cond:
+        g.by = zs[npar - 1]
     dmod, bpart = zs[npar], zs[npar + 1]   # bpart: per-batch partial rows of the down-proj bias grads
     g.mlp_x.bdown = bdown[:d]
     if both:
-        g.mlp_c.bdown, g.mlp_c.bup = bdown[d:], zs[7]
+        g.mlp_c.bdown, g.mlp_c.bup = bdown[d:], zs[6]
     dms = _mod_views(dmod, d, w.last)
     pending = []   # deferred weight-gradient GEMMs: (setter, descriptor)
 
@@ -308,11 +336,14 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope):
 
     # ---- modulation vectors and y_proj
     dmod_a = m.act(dmod)
-    dyp = _dgrad(m, dmod_a, w.Wmod, F32, **({"split_k": 16} if m.fast else {}))   # M = batch: 6 tiles, K = 12 d
     defer(g, "Wmod", dmod_a, sv.yp)
-    dpre = ops.silu_bwd(dyp, sv.pre, m.T, g.by)
-    dy_acc = _dgrad(m, dpre, w.Wy, F32, residual=dy_acc)
-    defer(g, "Wy", dpre, sv.y)
+    if defer_cond:
+        dy_acc = dmod_a
+    else:
+        dyp = _dgrad(m, dmod_a, w.Wmod, F32, **({"split_k": 16} if m.fast else {}))   # M = batch: 6 tiles, K = 12 d
+        dpre = ops.silu_bwd(dyp, sv.pre, m.T, g.by)
+        dy_acc = _dgrad(m, dpre, w.Wy, F32, residual=dy_acc)
+        defer(g, "Wy", dpre, sv.y)
 
     wg_arena = _wgrad_flush(m, pending)   # all weight gradients of the block in one grouped launch
     # every parameter gradient of the block lives in one of these two flat buffers (None: not the case, e.g. overlap off)
@@ -345,8 +376,9 @@ def model_fwd(m, W, x_t, t, c, c_pooled, rope):
     X = _gemm(m, sv.X0, W.Wpe, bias=W.bpe, out_dtype=F32)
 
     sv.blocks = []
-    for wb in W.blocks:
-        X, C, bs = block_fwd(m, wb, X, C, sv.y, dims, rope)
+    conds, sv.pre_all = cond_fwd_all(m, W.blocks, sv.y)
+    for wb, cond in zip(W.blocks, conds):
+        X, C, bs = block_fwd(m, wb, X, C, sv.y, dims, rope, cond)
         sv.blocks.append(bs)
 
     sv.Xf = X
@@ -405,15 +437,35 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     defer("Wmod_out", dmodo_a, sv.y)
 
     dC = None
-    g.blocks = [None] * len(W.blocks)
-    for i in range(len(W.blocks) - 1, -1, -1):
-        dX, dC, dy_acc, g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, dy_acc, sv.dims, rope)
+    nblk = len(W.blocks)
+    g.blocks = [None] * nblk
+    dmods = [None] * nblk
+    for i in range(nblk - 1, -1, -1):
+        dX, dC, dmods[i], g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, None, sv.dims, rope, defer_cond=True)
         sv.blocks[i] = None  # free saved activations as we go
         if on_grads is not None:
             # the reducer may hand back views of its flat bucket (zero copy-back): use them as this block's gradients
             repl = on_grads(_grad_tensors(g.blocks[i]), _wg_streams.get(dev), g.blocks[i].arenas)
             if repl is not None:
                 _set_grad_tensors(g.blocks[i], repl)
+
+    # conditioning path of all blocks at once (see cond_fwd_all): d(mod) -> d(y') -> SiLU backward -> d(y)
+    dyp_all = ops.zeros((nblk * B, d), dev)
+    by_all = ops.zeros((nblk, d), dev)
+    for i0 in range(0, nblk, 12):
+        _group(m, [dict(A=dmods[i], B=W.blocks[i].Wmod, b_kmajor=True, out=dyp_all[i * B:(i + 1) * B], **({"split_k": 4} if m.fast else {}))
+                   for i in range(i0, min(nblk, i0 + 12))])
+    dpre_all = ops.silu_bwd(dyp_all, sv.pre_all, m.T, by_all, rows_per_bias=B)
+    dyc = torch.empty((nblk + 1, B, d), dtype=F32, device=dev)
+    dyc[nblk].copy_(dy_acc)
+    for i0 in range(0, nblk, 12):
+        _group(m, [dict(A=dpre_all[i * B:(i + 1) * B], B=W.blocks[i].Wy, b_kmajor=True, out=dyc[i]) for i in range(i0, min(nblk, i0 + 12))])
+    dy_acc = dyc.sum(0)
+    late = []   # (block index, name): block gradients produced here, after that block's gradients were handed to on_grads
+    for i in range(nblk):
+        g.blocks[i].by = by_all[i]
+        pending.append((lambda o, i=i: setattr(g.blocks[i], "Wy", o), _wg(dpre_all[i * B:(i + 1) * B], sv.y)))
+        late += [(i, "by"), (i, "Wy")]
 
     # patch embedding
     g.bpe = ops.zeros(d, dev)
@@ -441,9 +493,11 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     _wgrad_flush(m, pending)
     if on_grads is not None:
         keys = [k for k, v in vars(g).items() if torch.is_tensor(v)]
-        repl = on_grads([getattr(g, k) for k in keys], _wg_streams.get(dev))
+        repl = on_grads([getattr(g, k) for k in keys] + [getattr(g.blocks[i], n) for i, n in late], _wg_streams.get(dev))
         if repl is not None:
             for k, t in zip(keys, repl):
                 setattr(g, k, t)
+            for (i, n), t in zip(late, repl[len(keys):]):
+                setattr(g.blocks[i], n, t)
     wgrad_join(dev)
     return g

@@ -259,10 +259,11 @@ def mlp_act_bwd(dh, gu, hidden, dbias, gelu=False):
     return dgu
 
 
-def silu_bwd(dy, pre, out_dtype, dbias):
+def silu_bwd(dy, pre, out_dtype, dbias, rows_per_bias=0):
+    """rows_per_bias > 0: dbias is (rows / rows_per_bias, cols): one bias-gradient row per group of rows (stacked blocks)."""
     rows, cols = pre.shape
     dpre = torch.empty((rows, cols), dtype=out_dtype, device=pre.device)
-    check(_lib.lib().mmdit_silu_bwd(_p(_c(dy)), _dt(dy), _p(pre), _p(dpre), _dt(dpre), rows, cols, _p(dbias), _s()), "mmdit_silu_bwd")
+    check(_lib.lib().mmdit_silu_bwd(_p(_c(dy)), _dt(dy), _p(pre), _p(dpre), _dt(dpre), rows, cols, _p(dbias), int(rows_per_bias), _s()), "mmdit_silu_bwd")
     return dpre
 
 
