@@ -88,6 +88,14 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python __graft_entry__.py build` "
                 "(hipcc --offload-arch=gfx950).  There is no PyTorch/CPU fallback for the MMDiT hot path.")
+        try:
+            # The library must share PyTorch's HIP runtime instance and device context: initialise torch's first when a GPU
+            # is present (loading this library before torch has touched the GPU left its launches with hipErrorNoDevice).
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (argtypes, restype) in _SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError -> symbol missing: fail loudly
