@@ -140,3 +140,26 @@ def test_sampler_with_hip_vae_decode():
     r = rel(img, want)
     print(f"[vae] sampler + HIP decode vs oracle decode rel-L2 = {r:.3e}")
     assert r < 3e-2
+
+
+@pytest.mark.gpu
+def test_training_step_from_raw_images():
+    """VAE encode inside the training rank -- a trainer step fed by ImageLatentSource equals a step fed with
+    the oracle-encoded latents (same sampling noise) within the VAE's bf16 distance."""
+    import sd3_amd  # noqa: F401
+    from oracle.weights import make_inputs, make_state_dict
+    from sd3_amd.helpers.VAE_inference import VAE_inference
+    from sd3_amd.helpers.latent_source import ImageLatentSource
+    dev = torch.device("cuda:0")
+    vsd = V.make_state_dict(5)
+    holder = VAE_inference(dev, vsd)
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    _, text, pooled = make_inputs(1, 2, 8, 8, text_scale=30.0)
+    src = ImageLatentSource(lambda: (imgs.to(dev), text.to(dev, torch.bfloat16), pooled.to(dev, torch.bfloat16)), holder,
+                            generator=torch.Generator(device=dev).manual_seed(0))
+    lat, t2, p2 = src()
+    assert lat.shape == (2, 16, 8, 8) and lat.dtype == torch.bfloat16 and t2.shape == (2, 154, 2304)
+    noise = torch.randn((2, 16, 8, 8), generator=torch.Generator(device=dev).manual_seed(0), device=dev)
+    want = V.sample_latent(V.encode_moments(imgs, vsd), noise.cpu())
+    assert rel(lat.float(), want) < 3e-2
