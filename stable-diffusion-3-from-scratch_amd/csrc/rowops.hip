@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void text_rms_bwd_kernel(const TG* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; e++) accw[it][e] = 0.f;
   }
-  for (int m = blockIdx.x * 64 + wave; m < min(rows, (int)(blockIdx.x + 1) * 64); m += 4) {
+  for (int m = blockIdx.x * 16 + wave; m < min(rows, (int)(blockIdx.x + 1) * 16); m += 4) {   // 16 rows per workgroup: enough workgroups to fill the chip
     const TI* xr = x + ((int64_t)(m / cnt) * tokens + off + m % cnt) * d;
     float v[NIT][4];
     float q = 0.f;
@@ -208,12 +208,23 @@ __global__ __launch_bounds__(256) void text_rms_bwd_kernel(const TG* __restrict_
       }
     }
   }
+  // the four waves are combined through LDS first: one atomic per column and workgroup (atomics are the expensive part)
+  __shared__ float red[3][NIT * 256];
+  if (wave > 0) {
 #pragma unroll
-  for (int it = 0; it < NIT; it++) {
-    int ch = lane + 64 * it;
-    if (ch < nch) {
+    for (int it = 0; it < NIT; it++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) atomicAdd(dw + ch * 4 + e, accw[it][e]);
+      for (int e = 0; e < 4; e++) red[wave - 1][(lane + 64 * it) * 4 + e] = accw[it][e];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      int ch = lane + 64 * it;
+      if (ch < nch) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) atomicAdd(dw + ch * 4 + e, accw[it][e] + red[0][ch * 4 + e] + red[1][ch * 4 + e] + red[2][ch * 4 + e]);
+      }
     }
   }
   accs = wave_sum(accs);
@@ -698,7 +709,7 @@ extern "C" int mmdit_text_rmsnorm_bwd(const void* dout1, const void* dout2, int 
     const int cnt = half ? tokens - split : split, off = half ? split : 0, rows = batch * cnt;
     const float* w = half ? w2 : w1; const float* sp = half ? s2 : s1; const void* dout = half ? dout2 : dout1;
     float* dw = half ? dw2 : dw1; float* dsp = half ? ds2 : ds1;
-    dim3 grid((rows + 63) / 64);
+    dim3 grid((rows + 15) / 16);
 #define TRB(TI, TG) NIT_SWITCH(nit, hipLaunchKernelGGL((text_rms_bwd_kernel<NIT, TI, TG>), grid, dim3(256), 0, s, (const TG*)dout, (const TI*)x, w, sp, rows, cnt, tokens, off, d, dw, dsp))
     if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_F32) { TRB(float, float); }
     else if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_BF16) { TRB(float, bf16_t); }
