@@ -76,6 +76,12 @@ typedef struct {
   int stream_k;   /* !=0: stream-K decomposition allowed: C is fp32 and PRE-ZEROED, the (tile, K-tile) units of the whole
                      launch are split evenly over the resident workgroups and partial tiles are added atomically (weight
                      gradients: few output tiles, very long reductions).  Ignored when the fast path does not apply. */
+  /* Implicit-GEMM 3x3 convolution on the fast path (FLUX VAE, nn.Conv2d(C, N, 3)): conv_mode != 0 makes A a ZERO-BORDERED
+   * NHWC bf16 tensor (batch, conv_H + 2, conv_W + 2, conv_C) and K = 9 * conv_C ordered (kh, kw, c) -- B is the weight re-laid
+   * as [N][kh][kw][C].  conv_mode 1: stride 1, padding 1, M = batch * conv_H * conv_W.  conv_mode 2: stride 2 after padding
+   * (0,1,0,1) (diffusers Downsample2D), M = batch * (conv_H/2) * (conv_W/2).  Output rows are the output pixels in NHWC
+   * order.  Needs bf16 operands and conv_C % 32 == 0; lda is ignored. */
+  int conv_mode, conv_H, conv_W, conv_C;
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 /* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,
@@ -215,9 +221,13 @@ int mmdit_vae_nhwc_to_nchw(const float* src, int batch, int C, int H, int W, int
  * stride 1, padding 1 (diffusers Upsample2D) -- output (2H, 2W), the upsampled tensor is never materialised. */
 int mmdit_vae_im2col3x3(const void* src_bf16, int batch, int H, int W, int C, int mode, void* dst_bf16, mmdit_stream_t stream);
 /* GroupNorm(groups, C, eps, affine) over NHWC x (fp32 | bf16), optional SiLU, bf16 out (ResnetBlock2D norm1/norm2,
- * Attention.group_norm, conv_norm_out).  sums_zeroed: batch*groups*2 fp32 scratch, zero on entry. */
-int mmdit_vae_groupnorm(const void* x, int x_dtype, const float* gamma, const float* beta, int batch, int HW, int C, int groups, float eps, int silu,
-                        float* sums_zeroed, void* y_bf16, mmdit_stream_t stream);
+ * Attention.group_norm, conv_norm_out).  sums_zeroed: batch*groups*2 fp32 scratch, zero on entry.
+ * pad != 0: y is a zero-bordered (batch, H+2, W+2, C) tensor (borders zeroed by the caller) whose interior is written --
+ * the A operand of the implicit-GEMM convolution (mmdit_gemm_args.conv_mode). */
+int mmdit_vae_groupnorm(const void* x, int x_dtype, const float* gamma, const float* beta, int batch, int H, int W, int C, int groups, float eps, int silu,
+                        float* sums_zeroed, void* y_bf16, int pad, mmdit_stream_t stream);
+/* NHWC (fp32 | bf16) -> interior of a zero-bordered bf16 (batch, uH+2, uW+2, C); upsample = 1: nearest x2 first (Upsample2D). */
+int mmdit_vae_pad_cast(const void* x, int x_dtype, int batch, int H, int W, int C, int upsample, void* y_bf16, mmdit_stream_t stream);
 /* y = softmax(scale * x) over the first `cols` entries of each row (pitch ld, padding written as 0), fp32 -> bf16
  * (single-head mid-block attention, attention_processor.py). */
 int mmdit_vae_softmax_rows(const float* x, int rows, int cols, int ld, float scale, void* y_bf16, mmdit_stream_t stream);

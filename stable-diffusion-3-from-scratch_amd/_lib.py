@@ -33,6 +33,7 @@ class GemmArgs(ctypes.Structure):
         ("precision", _i),
         ("split_k", _i),
         ("stream_k", _i),
+        ("conv_mode", _i), ("conv_H", _i), ("conv_W", _i), ("conv_C", _i),
     ]
 
 
@@ -62,7 +63,8 @@ _SIGNATURES = {
     "mmdit_vae_nchw_to_nhwc": ([_vp, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_float, _vp, _vp], _i),
     "mmdit_vae_nhwc_to_nchw": ([_vp, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_float, _vp, _vp], _i),
     "mmdit_vae_im2col3x3": ([_vp, _i, _i, _i, _i, _i, _vp, _vp], _i),
-    "mmdit_vae_groupnorm": ([_vp, _i, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _vp], _i),
+    "mmdit_vae_groupnorm": ([_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_float, _i, _vp, _vp, _i, _vp], _i),
+    "mmdit_vae_pad_cast": ([_vp, _i, _i, _i, _i, _i, _i, _vp, _vp], _i),
     "mmdit_vae_softmax_rows": ([_vp, _i, _i, _i, ctypes.c_float, _vp, _vp], _i),
     "mmdit_patchify": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
     "mmdit_unpatchify": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),

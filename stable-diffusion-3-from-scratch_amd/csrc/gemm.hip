@@ -275,6 +275,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   static const bool no_dma = getenv("MMDIT_GEMM_NO_DMA") != nullptr;
   static const char* raster_env = getenv("MMDIT_GEMM_RASTER");
   bool dma = !no_dma && a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16;
+  bool conv = false;
   const int split_k = a0->split_k > 1 ? a0->split_k : 1;
   for (int i = 0; i < count; i++) {
     const mmdit_gemm_args* a = &args[i];
@@ -288,9 +289,20 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     if (a->K % BK != 0) dma = false;
     if (a->a_kmajor && a->M < 8) dma = false;
     if (a->b_kmajor && a->N < 8) dma = false;
+    if (a->conv_mode) {
+      // implicit-GEMM convolution: DMA path only (bf16, conv_C % 32 == 0 so that a K half never straddles a tap), plain row-major B
+      MMDIT_CHECK_ARG((a->conv_mode == 1 || a->conv_mode == 2) && !a->a_kmajor && !a->b_kmajor && a->conv_C > 0 && a->conv_C % 32 == 0 && a->K == 9 * a->conv_C && a->K % BK == 0);
+      MMDIT_CHECK_ARG(a->conv_H > 0 && a->conv_W > 0 && (a->conv_mode == 1 || (a->conv_H % 2 == 0 && a->conv_W % 2 == 0)));
+      const int64_t px = a->conv_mode == 1 ? (int64_t)a->conv_H * a->conv_W : (int64_t)(a->conv_H / 2) * (a->conv_W / 2);
+      MMDIT_CHECK_ARG(a->M % px == 0 && split_k == 1 && !a->stream_k && a->a_dtype == MMDIT_BF16 && a->b_dtype == MMDIT_BF16 && a->precision == MMDIT_PREC_BF16);
+      MMDIT_CHECK_ARG((a->M / px) * (int64_t)(a->conv_H + 2) * (a->conv_W + 2) * a->conv_C * 2 < (1ll << 32));
+      conv = true;
+      continue;
+    }
     // the DMA kernel addresses an operand as a wave-uniform 64-bit base + a 32-bit per-lane byte offset
     if ((int64_t)(a->a_kmajor ? a->K : a->M) * a->lda * 2 >= (1ll << 32) || (int64_t)(a->b_kmajor ? a->K : a->N) * a->ldb * 2 >= (1ll << 32)) dma = false;
   }
+  if (conv) MMDIT_CHECK_ARG(dma);   // no register-staged fallback for the implicit-GEMM convolution
   int bm = BM, bn = BN, cfg = CFG_128x128;
   // stream-K for the weight gradients (k-major A): fp32 C must be pre-zeroed by the caller (a0->stream_k)
   static const bool no_sk = getenv("MMDIT_GEMM_NO_STREAMK") != nullptr;
@@ -305,6 +317,8 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ld_gate = a->ld_gate; p.ld_res = a->ld_res; p.ld_aux = a->ld_aux;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.rows_per_batch = a->rows_per_batch > 0 ? a->rows_per_batch : 1;
+    p.conv_mode = a->conv_mode; p.cC = a->conv_C; p.cHp = a->conv_H + 2; p.cWp = a->conv_W + 2;
+    p.cHo = a->conv_mode == 2 ? a->conv_H / 2 : a->conv_H; p.cWo = a->conv_mode == 2 ? a->conv_W / 2 : a->conv_W;
     p.tiles_n = (a->N + bn - 1) / bn;
     p.tiles_m = (a->M + bm - 1) / bm;
     p.tile_start = tiles;

@@ -16,6 +16,9 @@ struct Problem {
   int M, N, K;
   int rows_per_batch, tiles_n, tiles_m, tile_start;
   int nk, unit_start;   // stream-K: K-tiles per output tile, first (tile, K-tile) unit of this problem
+  // implicit-GEMM 3x3 convolution (conv_mode != 0): A is a zero-bordered NHWC bf16 tensor (batch, cHp, cWp, cC); output row
+  // m = (b, yo, xo) reads pixel (s*yo + kh + o, s*xo + kw + o) for K index (kh*3 + kw)*cC + c  (mode 1: s=1, o=0; mode 2: s=2, o=1)
+  int conv_mode, cHo, cWo, cHp, cWp, cC;
 };
 struct GroupParams {
   Problem p[MAXG];

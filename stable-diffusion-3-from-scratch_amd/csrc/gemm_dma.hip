@@ -49,6 +49,16 @@ __device__ __forceinline__ uint32_t piece_voff(int c, int lane, int64_t ld, int 
   }
 }
 
+// implicit-GEMM convolution: byte offset (from the tensor base) of the 16 B this lane sources for piece c of an A half-tile;
+// the tap / channel part of the address is wave-uniform and lives in the cursor's base pointer
+__device__ __forceinline__ uint32_t conv_voff(int c, int lane, const Problem& q, int row0) {
+  const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);
+  const int m = min(row0 + r, q.M - 1), hw = q.cHo * q.cWo;
+  const int b = m / hw, rem = m - b * hw, yo = rem / q.cWo, xo = rem - yo * q.cWo;
+  const int s = q.conv_mode == 2 ? 2 : 1;
+  return (uint32_t)((((int64_t)b * q.cHp + s * yo) * q.cWp + s * xo) * q.cC * 2 + piece * 16);
+}
+
 // Issued as inline asm on purpose: the compiler's waitcnt pass treats the global_load_lds builtin as a FLAT access
 // that is pending on both counters and then degrades every LDS-read wait of the main loop to lgkmcnt(0); hidden from
 // it, the fragment reads get counted waits.  Completion is tracked by hand (s_waitcnt vmcnt + s_barrier in half_sync).
@@ -290,16 +300,31 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   const char* sa = nullptr;
   const char* sb = nullptr;
   int64_t stepa = 0, stepb = 0;
+  int cseg = 0, cseg_len = 0;      // implicit-GEMM convolution: halves left in / per kernel row (3 taps x cC/32 halves are contiguous)
+  int64_t crow_jump = 0;           // extra bytes when the K index moves to the next kernel row
   auto cursor_setup = [&]() {
     const Problem& q = gp.p[cit.pi];
+    if (!A_KM && q.conv_mode) {
 #pragma unroll
-    for (int i = 0; i < PA; i++) va[i] = piece_voff<A_KM, TBM>(wave * PA + i, lane, q.lda, cit.tm * TBM, q.M);
+      for (int i = 0; i < PA; i++) va[i] = conv_voff(wave * PA + i, lane, q, cit.tm * TBM);
+    } else {
+#pragma unroll
+      for (int i = 0; i < PA; i++) va[i] = piece_voff<A_KM, TBM>(wave * PA + i, lane, q.lda, cit.tm * TBM, q.M);
+    }
 #pragma unroll
     for (int i = 0; i < PB; i++) vb[i] = piece_voff<B_KM, TBN>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
     stepa = A_KM ? (int64_t)BKH * q.lda * 2 : BKH * 2;
     stepb = B_KM ? (int64_t)BKH * q.ldb * 2 : BKH * 2;
     sa = (const char*)q.A + ch * stepa;
     sb = (const char*)q.B + ch * stepb;
+    cseg = 0;
+    if (!A_KM && q.conv_mode) {
+      cseg_len = 3 * (q.cC / BKH);
+      const int kh = ch / cseg_len, within = ch - kh * cseg_len, o = q.conv_mode == 2 ? 1 : 0;
+      crow_jump = ((int64_t)q.cWp - 3) * q.cC * 2;
+      sa = (const char*)q.A + (((int64_t)(kh + o) * q.cWp + o) * q.cC) * 2 + (int64_t)within * (BKH * 2);
+      cseg = cseg_len - within;
+    }
   };
   // after the last half of the stream the cursor stays where it is: the steady-state loop keeps issuing (it re-reads
   // that half into a free slot) so that the loop body is branch-free and exactly PP pieces are issued per half
@@ -309,6 +334,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       ch++;
       sa += stepa;
       sb += stepb;
+      if (cseg && --cseg == 0) {   // convolution: next kernel row
+        sa += crow_jump;
+        cseg = cseg_len;
+      }
       return;
     }
     Item nx = cit;

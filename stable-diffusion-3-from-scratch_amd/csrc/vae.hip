@@ -110,10 +110,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const TI* __restrict__ x,
 }
 
 // GroupNorm apply: y = (x - mean_g) * rstd_g * gamma_c + beta_c, optional SiLU, bf16 out.
+// pad != 0: y is a zero-bordered (B, H+2, W+2, C) tensor whose interior is written (operand of the implicit-GEMM convolution)
 template <typename TI>
 __global__ void gn_apply_kernel(const TI* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                int B, int HW, int C, int G, float eps, int silu, bf16_t* __restrict__ y) {
-  const int cg = C / 8, cpg = C / G;
+                                int B, int H, int W, int C, int G, float eps, int silu, int pad, bf16_t* __restrict__ y) {
+  const int cg = C / 8, cpg = C / G, HW = H * W;
   const int64_t total = (int64_t)B * HW * cg;
   const float inv_n = 1.f / ((float)HW * (float)cpg);
   for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * blockDim.x) {
@@ -131,7 +132,31 @@ __global__ void gn_apply_kernel(const TI* __restrict__ x, const float* __restric
       float o = (v[e] - m) * rsqrtf(var + eps) * ga[e] + be[e];
       v[e] = silu ? silu_f(o) : o;
     }
-    st8(y + gid * 8, v);
+    int64_t o = gid * 8;
+    if (pad) {
+      const int64_t pix = gid / cg;
+      const int p = (int)(pix % HW), yy = p / W, xx = p - yy * W;
+      o = (((b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * (int64_t)C) + t * 8;
+    }
+    st8(y + o, v);
+  }
+}
+
+// fp32 | bf16 NHWC (B,H,W,C) -> interior of a zero-bordered bf16 (B, uH+2, uW+2, C), uH = H << up (nearest x2 upsampling when up)
+template <typename TI>
+__global__ void pad_cast_kernel(const TI* __restrict__ x, bf16_t* __restrict__ y, int B, int H, int W, int C, int up) {
+  const int cg = C / 8, Ho = H << up, Wo = W << up;
+  const int64_t total = (int64_t)B * Ho * Wo * cg;
+  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(gid % cg);
+    int64_t r = gid / cg;
+    const int xo = (int)(r % Wo);
+    r /= Wo;
+    const int yo = (int)(r % Ho);
+    const int64_t b = r / Ho;
+    float v[8];
+    ld8(x + (((b * H + (yo >> up)) * W + (xo >> up)) * (int64_t)C) + t * 8, v);
+    st8(y + (((b * (Ho + 2) + yo + 1) * (Wo + 2) + xo + 1) * (int64_t)C) + t * 8, v);
   }
 }
 
@@ -181,19 +206,29 @@ extern "C" int mmdit_vae_im2col3x3(const void* src_bf16, int batch, int H, int W
   return mmdit_launch_status();
 }
 
-extern "C" int mmdit_vae_groupnorm(const void* x, int x_dtype, const float* gamma, const float* beta, int batch, int HW, int C, int groups, float eps, int silu,
-                                   float* sums_zeroed, void* y_bf16, mmdit_stream_t stream) {
-  MMDIT_CHECK_ARG(x && gamma && beta && sums_zeroed && y_bf16 && batch > 0 && HW > 0 && C % 8 == 0 && C / 8 <= 256 && groups > 0 && groups <= 64 && C % groups == 0);
+extern "C" int mmdit_vae_groupnorm(const void* x, int x_dtype, const float* gamma, const float* beta, int batch, int H, int W, int C, int groups, float eps, int silu,
+                                   float* sums_zeroed, void* y_bf16, int pad, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && gamma && beta && sums_zeroed && y_bf16 && batch > 0 && H > 0 && W > 0 && C % 8 == 0 && C / 8 <= 256 && groups > 0 && groups <= 64 && C % groups == 0);
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = 256;
+  const int rpb = 256, HW = H * W;
   dim3 g1((HW + rpb - 1) / rpb, batch), g2(grid_cap((int64_t)batch * HW * (C / 8), 256));
   if (x_dtype == MMDIT_F32) {
     hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, s, (const float*)x, HW, C, groups, rpb, sums_zeroed);
-    hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), 0, s, (const float*)x, sums_zeroed, gamma, beta, batch, HW, C, groups, eps, silu, (bf16_t*)y_bf16);
+    hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), 0, s, (const float*)x, sums_zeroed, gamma, beta, batch, H, W, C, groups, eps, silu, pad, (bf16_t*)y_bf16);
   } else if (x_dtype == MMDIT_BF16) {
     hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), g1, dim3(256), 0, s, (const bf16_t*)x, HW, C, groups, rpb, sums_zeroed);
-    hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), g2, dim3(256), 0, s, (const bf16_t*)x, sums_zeroed, gamma, beta, batch, HW, C, groups, eps, silu, (bf16_t*)y_bf16);
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), g2, dim3(256), 0, s, (const bf16_t*)x, sums_zeroed, gamma, beta, batch, H, W, C, groups, eps, silu, pad, (bf16_t*)y_bf16);
   } else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_vae_pad_cast(const void* x, int x_dtype, int batch, int H, int W, int C, int upsample, void* y_bf16, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && y_bf16 && batch > 0 && H > 0 && W > 0 && C % 8 == 0 && (upsample == 0 || upsample == 1));
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(grid_cap((int64_t)batch * (H << upsample) * (W << upsample) * (C / 8), 256));
+  if (x_dtype == MMDIT_F32) hipLaunchKernelGGL((pad_cast_kernel<float>), grid, dim3(256), 0, s, (const float*)x, (bf16_t*)y_bf16, batch, H, W, C, upsample);
+  else if (x_dtype == MMDIT_BF16) hipLaunchKernelGGL((pad_cast_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y_bf16, batch, H, W, C, upsample);
+  else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }
 

@@ -89,8 +89,14 @@ def torch_dtype(code: int):
 
 # ---------------------------------------------------------------------------------------------
 def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False):
-    if a_kmajor:
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None):
+    """conv = (mode, H, W, C): A is a zero-bordered NHWC bf16 tensor (batch, H+2, W+2, C) -- implicit-GEMM 3x3 convolution."""
+    if conv is not None:
+        mode, cH, cW, cC = conv
+        if A.dim() != 4 or tuple(A.shape[1:]) != (cH + 2, cW + 2, cC) or A.dtype != torch.bfloat16:
+            raise RuntimeError("conv operand must be a zero-bordered bf16 (batch, H+2, W+2, C) tensor")
+        M, K_ = A.shape[0] * (cH * cW if mode == 1 else (cH // 2) * (cW // 2)), 9 * cC
+    elif a_kmajor:
         K_, M = A.shape
     else:
         M, K_ = A.shape
@@ -105,7 +111,9 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
             out = zeros((M, N), A.device)   # slices accumulate atomically
         else:
             out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
-    a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), A.stride(0)
+    a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), (K_ if conv is not None else A.stride(0))
+    if conv is not None:
+        a.conv_mode, a.conv_H, a.conv_W, a.conv_C = conv
     a.B, a.b_dtype, a.b_kmajor, a.ldb = _p(B), _dt(B), int(b_kmajor), B.stride(0)
     a.C, a.c_dtype, a.ldc = _p(out), _dt(out), out.stride(0)
     a.M, a.N, a.K = M, N, K_
@@ -336,13 +344,20 @@ def vae_im2col3x3(x, mode=0):
     return out, Ho, Wo
 
 
-def vae_groupnorm(x, gamma, beta, B, HW, groups, eps, silu):
-    """x: (B*HW, C) fp32 or bf16 -> bf16 (B*HW, C)."""
+def vae_groupnorm(x, gamma, beta, B, H, W, groups, eps, silu, padded_out=None):
+    """x: (B*H*W, C) fp32 or bf16 -> bf16 (B*H*W, C), or into the interior of `padded_out` (B, H+2, W+2, C) with zero borders."""
     C = x.shape[1]
     sums = torch.zeros(B * groups * 2, dtype=torch.float32, device=x.device)
-    out = torch.empty((B * HW, C), dtype=torch.bfloat16, device=x.device)
-    check(_lib.lib().mmdit_vae_groupnorm(_p(_c(x)), _dt(x), _p(gamma), _p(beta), B, HW, C, groups, float(eps), int(silu), _p(sums), _p(out), _s()), "mmdit_vae_groupnorm")
+    out = padded_out if padded_out is not None else torch.empty((B * H * W, C), dtype=torch.bfloat16, device=x.device)
+    check(_lib.lib().mmdit_vae_groupnorm(_p(_c(x)), _dt(x), _p(gamma), _p(beta), B, H, W, C, groups, float(eps), int(silu), _p(sums), _p(out),
+                                         int(padded_out is not None), _s()), "mmdit_vae_groupnorm")
     return out
+
+
+def vae_pad_cast(x, B, H, W, padded_out, upsample=False):
+    """x: (B*H*W, C) fp32 or bf16 -> interior of the zero-bordered bf16 `padded_out` (B, uH+2, uW+2, C); nearest x2 if upsample."""
+    check(_lib.lib().mmdit_vae_pad_cast(_p(_c(x)), _dt(x), B, H, W, x.shape[1], int(upsample), _p(padded_out), _s()), "mmdit_vae_pad_cast")
+    return padded_out
 
 
 def vae_softmax_rows(x, scale, cols=None):

@@ -160,6 +160,7 @@ class AutoencoderKL(nn.Module):
         self.encoder = _Encoder(self.config)
         self.decoder = _Decoder(self.config)
         self.eps = 1e-6
+        self._pad_cache = {}
         self.to(device)
         for p in self.parameters():
             p.requires_grad_(False)
@@ -169,23 +170,46 @@ class AutoencoderKL(nn.Module):
         return BF16     # what the reference casts the VAE to (VAE_T5_CLIP_inference.py:32); the sampler feeds `output.to(VAE.dtype)`
 
     # ---- building blocks ----------------------------------------------------------------------
-    def _gn(self, a, norm, silu):
-        return ops.vae_groupnorm(a.x, norm.weight, norm.bias, a.B, a.H * a.W, self.config.norm_num_groups, self.eps, silu)
+    def _padded(self, B, H, W, C, dev):
+        """Zero-bordered bf16 (B, H+2, W+2, C) operand buffer of the implicit-GEMM convolution.  One buffer per shape is
+        recycled: producers only ever write the interior, so the border stays zero, and producer / consumer alternate on
+        one stream."""
+        key = (B, H, W, C, dev)
+        buf = self._pad_cache.get(key)
+        if buf is None:
+            buf = self._pad_cache[key] = torch.zeros((B, H + 2, W + 2, C), dtype=BF16, device=dev)
+        return buf
 
-    def _conv3(self, xb, a, conv, mode=0, residual=None):
-        """xb: bf16 (B*H*W, Cin_p) NHWC rows.  Returns _Act with fp32 (B*Ho*Wo, Cout_p)."""
+    def _gn(self, a, norm, silu, padded=False):
+        out = self._padded(a.B, a.H, a.W, a.x.shape[1], a.x.device) if padded else None
+        return ops.vae_groupnorm(a.x, norm.weight, norm.bias, a.B, a.H, a.W, self.config.norm_num_groups, self.eps, silu, out)
+
+    def _conv3(self, xin, a, conv, mode=0, residual=None):
+        """3x3 convolution of the activation `a` whose conv operand is `xin`:
+        a zero-bordered bf16 (B, H+2, W+2, Cin) tensor -> implicit GEMM (Cin % 64 == 0: the big layers);
+        bf16 rows (B*H*W, Cin_p) -> materialised im2col + GEMM (conv_in with its 8 / 16 padded channels).
+        mode 0: stride 1 / 1: Downsample2D / 2: Upsample2D (nearest x2 first).  Returns _Act with fp32 (B*Ho*Wo, Cout_p)."""
         w, b = conv.packed()
-        cols, Ho, Wo = ops.vae_im2col3x3(xb.view(a.B, a.H, a.W, xb.shape[1]), mode)
+        if xin.dim() == 4:
+            Hin, Win = xin.shape[1] - 2, xin.shape[2] - 2           # (already upsampled for mode 2)
+            y = ops.gemm(xin, w, bias=b, residual=residual, out_dtype=F32, conv=(2 if mode == 1 else 1, Hin, Win, xin.shape[3]))
+            return _Act(y, a.B, Hin // 2 if mode == 1 else Hin, Win // 2 if mode == 1 else Win)
+        cols, Ho, Wo = ops.vae_im2col3x3(xin.view(a.B, a.H, a.W, xin.shape[1]), mode)
         y = ops.gemm(cols, w, bias=b, residual=residual, out_dtype=F32)
         return _Act(y, a.B, Ho, Wo)
 
+    def _resample_operand(self, a, upsample):
+        """fp32 activation -> zero-bordered bf16 conv operand (nearest x2 upsampled for Upsample2D)."""
+        s = 2 if upsample else 1
+        return ops.vae_pad_cast(a.x, a.B, a.H, a.W, self._padded(a.B, a.H * s, a.W * s, a.x.shape[1], a.x.device), upsample)
+
     def _resnet(self, a, r):
-        h = self._conv3(self._gn(a, r.norm1, True), a, r.conv1)
+        h = self._conv3(self._gn(a, r.norm1, True, padded=True), a, r.conv1)
         sc = a.x
         if hasattr(r, "conv_shortcut"):
             w, b = r.conv_shortcut.packed()
             sc = ops.gemm(ops.cast(a.x, BF16), w, bias=b, out_dtype=F32)
-        return self._conv3(self._gn(h, r.norm2, True), h, r.conv2, residual=sc)
+        return self._conv3(self._gn(h, r.norm2, True, padded=True), h, r.conv2, residual=sc)
 
     def _attn(self, a, at):
         B, HW, C = a.B, a.H * a.W, a.x.shape[1]
@@ -225,9 +249,9 @@ class AutoencoderKL(nn.Module):
             for r in blk.resnets:
                 a = self._resnet(a, r)
             if hasattr(blk, "downsamplers"):
-                a = self._conv3(ops.cast(a.x, BF16), a, blk.downsamplers[0].conv, mode=1)
+                a = self._conv3(self._resample_operand(a, False), a, blk.downsamplers[0].conv, mode=1)
         a = self._mid(a, e.mid_block)
-        a = self._conv3(self._gn(a, e.conv_norm_out, True), a, e.conv_out)
+        a = self._conv3(self._gn(a, e.conv_norm_out, True, padded=True), a, e.conv_out)
         moments = ops.vae_nhwc_to_nchw(a.x, B, 2 * self.config.latent_channels, a.H, a.W)
         return SimpleNamespace(latent_dist=DiagonalGaussianDistribution(moments))
 
@@ -245,6 +269,6 @@ class AutoencoderKL(nn.Module):
             for r in blk.resnets:
                 a = self._resnet(a, r)
             if hasattr(blk, "upsamplers"):
-                a = self._conv3(ops.cast(a.x, BF16), a, blk.upsamplers[0].conv, mode=2)
-        a = self._conv3(self._gn(a, d.conv_norm_out, True), a, d.conv_out)
+                a = self._conv3(self._resample_operand(a, True), a, blk.upsamplers[0].conv, mode=2)
+        a = self._conv3(self._gn(a, d.conv_norm_out, True, padded=True), a, d.conv_out)
         return SimpleNamespace(sample=ops.vae_nhwc_to_nchw(a.x, B, self.config.out_channels, a.H, a.W))

@@ -93,8 +93,28 @@ def test_vae_kernels_vs_torch():
     h = torch.randn(B * H * W, C2, generator=g) * 2 + 0.5
     ga, be = torch.randn(C2, generator=g), torch.randn(C2, generator=g)
     ref = F.silu(F.group_norm(h.view(B, H * W, C2).transpose(1, 2), G, ga, be, eps=1e-6)).transpose(1, 2).reshape(B * H * W, C2)
-    got = ops.vae_groupnorm(h.cuda(), ga.cuda(), be.cuda(), B, H * W, G, 1e-6, True)
+    got = ops.vae_groupnorm(h.cuda(), ga.cuda(), be.cuda(), B, H, W, G, 1e-6, True)
     assert rel(got.float(), ref) < 5e-3
+    padded = torch.zeros((B, H + 2, W + 2, C2), dtype=torch.bfloat16, device="cuda")
+    ops.vae_groupnorm(h.cuda(), ga.cuda(), be.cuda(), B, H, W, G, 1e-6, True, padded)
+    # (the statistics are atomic sums: the two runs may differ in the last bf16 bit)
+    assert rel(padded[:, 1:-1, 1:-1].reshape(B * H * W, C2).float(), got.float()) < 5e-3
+    assert float(padded[:, 0].abs().sum() + padded[:, -1].abs().sum() + padded[:, :, 0].abs().sum() + padded[:, :, -1].abs().sum()) == 0.0
+    # implicit-GEMM convolution (zero-bordered operand, no im2col): stride 1, Downsample2D, Upsample2D
+    C3, N3 = 64, 40
+    x3 = torch.randn(B * H * W, C3, generator=g)
+    w3 = torch.randn(N3, C3, 3, 3, generator=g) / 24
+    b3 = torch.randn(N3, generator=g)
+    wp3 = w3.permute(0, 2, 3, 1).reshape(N3, -1).to(torch.bfloat16).cuda()
+    wr3 = wp3.float().cpu().view(N3, 3, 3, C3).permute(0, 3, 1, 2)
+    xr3 = x3.to(torch.bfloat16).float().view(B, H, W, C3).permute(0, 3, 1, 2)
+    for mode, up, ref3 in ((1, False, F.conv2d(xr3, wr3, b3, padding=1)), (2, False, F.conv2d(F.pad(xr3, (0, 1, 0, 1)), wr3, b3, stride=2)),
+                           (1, True, F.conv2d(F.interpolate(xr3, scale_factor=2.0, mode="nearest"), wr3, b3, padding=1))):
+        s = 2 if up else 1
+        op = ops.vae_pad_cast(x3.cuda(), B, H, W, torch.zeros((B, H * s + 2, W * s + 2, C3), dtype=torch.bfloat16, device="cuda"), up)
+        y3 = ops.gemm(op, wp3, bias=b3.cuda(), out_dtype=torch.float32, conv=(mode, H * s, W * s, C3))
+        got3 = ops.vae_nhwc_to_nchw(y3, B, N3, ref3.shape[2], ref3.shape[3])
+        assert got3.shape == ref3.shape and rel(got3, ref3) < 1e-5, (mode, up)
     s = torch.randn(37, 100, generator=g) * 3
     assert rel(ops.vae_softmax_rows(s.cuda(), 0.25).float(), torch.softmax(s * 0.25, -1)) < 5e-3
 
