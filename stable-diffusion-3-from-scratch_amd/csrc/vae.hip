@@ -91,11 +91,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const TI* __restrict__ x,
   for (int e = 0; e < 8; e++) { a1[e] = 0.f; a2[e] = 0.f; }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
   if (ty < nty) {
-    for (int r = r0 + ty; r < r1; r += nty) {
-      float v[8];
+    for (int r = r0 + ty; r < r1; r += 2 * nty) {
+      float v[8], w[8];
+      const int r2 = r + nty;
       ld8(x + ((int64_t)b * HW + r) * C + tx * 8, v);
+      if (r2 < r1) ld8(x + ((int64_t)b * HW + r2) * C + tx * 8, w);
 #pragma unroll
       for (int e = 0; e < 8; e++) { a1[e] += v[e]; a2[e] += v[e] * v[e]; }
+      if (r2 < r1) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { a1[e] += w[e]; a2[e] += w[e] * w[e]; }
+      }
     }
     const int cpg = C / G;
 #pragma unroll
@@ -110,35 +116,55 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const TI* __restrict__ x,
 }
 
 // GroupNorm apply: y = (x - mean_g) * rstd_g * gamma_c + beta_c, optional SiLU, bf16 out.
-// pad != 0: y is a zero-bordered (B, H+2, W+2, C) tensor whose interior is written (operand of the implicit-GEMM convolution)
+// pad != 0: y is a zero-bordered (B, H+2, W+2, C) tensor whose interior is written (operand of the implicit-GEMM convolution).
+// grid = (pixel chunks, B); a thread owns one 8-channel group for all its pixels, so the group statistics, gamma and beta are
+// folded into a per-channel scale / offset once and the loop is load - fma - (SiLU) - store with two pixels in flight.
 template <typename TI>
-__global__ void gn_apply_kernel(const TI* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                int B, int H, int W, int C, int G, float eps, int silu, int pad, bf16_t* __restrict__ y) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(const TI* __restrict__ x, const float* __restrict__ sums, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int H, int W, int C, int G, float eps, int silu, int pad, int pix_per_block,
+                                                       bf16_t* __restrict__ y) {
   const int cg = C / 8, cpg = C / G, HW = H * W;
-  const int64_t total = (int64_t)B * HW * cg;
-  const float inv_n = 1.f / ((float)HW * (float)cpg);
-  for (int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * blockDim.x) {
-    const int t = (int)(gid % cg);
-    const int64_t b = gid / ((int64_t)HW * cg);
-    float v[8], ga[8], be[8];
-    ld8(x + gid * 8, v);
+  const int t = threadIdx.x % cg, ty = threadIdx.x / cg, nty = 256 / cg;
+  const int64_t b = blockIdx.y;
+  if (ty >= nty) return;
+  float sc[8], of[8];
+  {
+    float ga[8], be[8];
     ld8(gamma + t * 8, ga);
     ld8(beta + t * 8, be);
+    const float inv_n = 1.f / ((float)HW * (float)cpg);
 #pragma unroll
     for (int e = 0; e < 8; e++) {
       const int g = (t * 8 + e) / cpg;
       const float m = sums[(b * G + g) * 2] * inv_n;
       const float var = fmaxf(sums[(b * G + g) * 2 + 1] * inv_n - m * m, 0.f);
-      float o = (v[e] - m) * rsqrtf(var + eps) * ga[e] + be[e];
-      v[e] = silu ? silu_f(o) : o;
+      sc[e] = rsqrtf(var + eps) * ga[e];
+      of[e] = be[e] - m * sc[e];
     }
-    int64_t o = gid * 8;
-    if (pad) {
-      const int64_t pix = gid / cg;
-      const int p = (int)(pix % HW), yy = p / W, xx = p - yy * W;
-      o = (((b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * (int64_t)C) + t * 8;
+  }
+  const int p0 = blockIdx.x * pix_per_block, p1 = min(HW, p0 + pix_per_block);
+  for (int p = p0 + ty; p < p1; p += 2 * nty) {
+    float v0[8], v1[8];
+    const int q = p + nty;
+    ld8(x + ((b * HW + p) * (int64_t)C) + t * 8, v0);
+    if (q < p1) ld8(x + ((b * HW + q) * (int64_t)C) + t * 8, v1);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int pp = k ? q : p;
+      if (pp >= p1) break;
+      float (&v)[8] = k ? v1 : v0;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const float o = fmaf(v[e], sc[e], of[e]);
+        v[e] = silu ? silu_f(o) : o;
+      }
+      int64_t o = ((b * HW + pp) * (int64_t)C) + t * 8;
+      if (pad) {
+        const int yy = pp / W, xx = pp - yy * W;
+        o = (((b * (H + 2) + yy + 1) * (W + 2) + xx + 1) * (int64_t)C) + t * 8;
+      }
+      st8(y + o, v);
     }
-    st8(y + o, v);
   }
 }
 
@@ -210,14 +236,15 @@ extern "C" int mmdit_vae_groupnorm(const void* x, int x_dtype, const float* gamm
                                    float* sums_zeroed, void* y_bf16, int pad, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(x && gamma && beta && sums_zeroed && y_bf16 && batch > 0 && H > 0 && W > 0 && C % 8 == 0 && C / 8 <= 256 && groups > 0 && groups <= 64 && C % groups == 0);
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = 256, HW = H * W;
-  dim3 g1((HW + rpb - 1) / rpb, batch), g2(grid_cap((int64_t)batch * HW * (C / 8), 256));
+  const int rpb = 128, HW = H * W;
+  const int ppb = 128;   // pixels per apply workgroup
+  dim3 g1((HW + rpb - 1) / rpb, batch), g2((HW + ppb - 1) / ppb, batch);
   if (x_dtype == MMDIT_F32) {
     hipLaunchKernelGGL((gn_stats_kernel<float>), g1, dim3(256), 0, s, (const float*)x, HW, C, groups, rpb, sums_zeroed);
-    hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), 0, s, (const float*)x, sums_zeroed, gamma, beta, batch, H, W, C, groups, eps, silu, pad, (bf16_t*)y_bf16);
+    hipLaunchKernelGGL((gn_apply_kernel<float>), g2, dim3(256), 0, s, (const float*)x, sums_zeroed, gamma, beta, H, W, C, groups, eps, silu, pad, ppb, (bf16_t*)y_bf16);
   } else if (x_dtype == MMDIT_BF16) {
     hipLaunchKernelGGL((gn_stats_kernel<bf16_t>), g1, dim3(256), 0, s, (const bf16_t*)x, HW, C, groups, rpb, sums_zeroed);
-    hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), g2, dim3(256), 0, s, (const bf16_t*)x, sums_zeroed, gamma, beta, batch, H, W, C, groups, eps, silu, pad, (bf16_t*)y_bf16);
+    hipLaunchKernelGGL((gn_apply_kernel<bf16_t>), g2, dim3(256), 0, s, (const bf16_t*)x, sums_zeroed, gamma, beta, H, W, C, groups, eps, silu, pad, ppb, (bf16_t*)y_bf16);
   } else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }
