@@ -372,24 +372,31 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 
 template <typename T, bool GELU>
 __global__ __launch_bounds__(256) void mlp_act_fwd_kernel(const T* __restrict__ gu, T* __restrict__ h, int rows, int hidden) {
-  const int tx = threadIdx.x & 127, ty = threadIdx.x >> 7;
-  const int c = blockIdx.x * 1024 + tx * 8;
+  // 256 columns x CO_RCH rows per workgroup (32 column groups of 8 x 8 row lanes), two rows in flight per thread
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + tx * 8;
   if (c >= hidden) return;
   const int64_t ldi = GELU ? hidden : 2 * (int64_t)hidden;
   const int rend = min(rows, (int)(blockIdx.y + 1) * CO_RCH);
-  for (int r = blockIdx.y * CO_RCH + ty; r < rend; r += 2) {
-    float g[8], o[8];
-    ld8(gu + r * ldi + c, g);
-    if constexpr (GELU) {
+  for (int r0 = blockIdx.y * CO_RCH + ty; r0 < rend; r0 += 16) {
+    float g[2][8], u[2][8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) o[e] = gelu_f(g[e]);
-    } else {
-      float u[8];
-      ld8(gu + r * ldi + hidden + c, u);
-#pragma unroll
-      for (int e = 0; e < 8; e++) o[e] = silu_f(g[e]) * u[e];
+    for (int k = 0; k < 2; k++) {
+      const int r = r0 + 8 * k;
+      if (r < rend) {
+        ld8(gu + r * ldi + c, g[k]);
+        if constexpr (!GELU) ld8(gu + r * ldi + hidden + c, u[k]);
+      }
     }
-    st8(h + (int64_t)r * hidden + c, o);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int r = r0 + 8 * k;
+      if (r >= rend) break;
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = GELU ? gelu_f(g[k][e]) : silu_f(g[k][e]) * u[k][e];
+      st8(h + (int64_t)r * hidden + c, o);
+    }
   }
 }
 
@@ -755,7 +762,7 @@ extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void
 template <bool GELU>
 static int mlp_act_fwd(const void* gu, void* h, int dtype, int rows, int hidden, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(gu && h && rows > 0 && hidden > 0 && hidden % 8 == 0);
-  dim3 grid((hidden + 1023) / 1024, (rows + CO_RCH - 1) / CO_RCH);
+  dim3 grid((hidden + 255) / 256, (rows + CO_RCH - 1) / CO_RCH);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MMDIT_BF16) hipLaunchKernelGGL((mlp_act_fwd_kernel<bf16_t, GELU>), grid, dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)h, rows, hidden);
   else if (dtype == MMDIT_F32) hipLaunchKernelGGL((mlp_act_fwd_kernel<float, GELU>), grid, dim3(256), 0, s, (const float*)gu, (float*)h, rows, hidden);
