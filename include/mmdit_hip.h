@@ -27,6 +27,7 @@ extern "C" {
 
 #define MMDIT_F32 0
 #define MMDIT_BF16 1
+#define MMDIT_FP8 2   /* OCP e4m3fn, GEMM operands only (inference path): see mmdit_fp8_quantize */
 
 #define MMDIT_ERR_ARG (-1)      /* null pointer / bad size / misaligned */
 #define MMDIT_ERR_DTYPE (-2)    /* dtype combination not built */
@@ -82,6 +83,10 @@ typedef struct {
    * (0,1,0,1) (diffusers Downsample2D), M = batch * (conv_H/2) * (conv_W/2).  Output rows are the output pixels in NHWC
    * order.  Needs bf16 operands and conv_C % 32 == 0; lda is ignored. */
   int conv_mode, conv_H, conv_W, conv_C;
+  /* fp8 operands (a_dtype == b_dtype == MMDIT_FP8, row-major, K % 128 == 0): C = scale_a[0] * scale_b[0] * (A_q B_q^T), then the
+   * usual epilogue.  scale_*: device pointers to the per-tensor dequantisation scales written by mmdit_fp8_quantize. */
+  const float* scale_a;
+  const float* scale_b;
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 /* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,
@@ -94,6 +99,16 @@ int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t st
  * (the default K decomposition of stream_k launches).  Negative = the MMDIT_ERR_* the launch would return.
  * Lets profilers / benchmarks attribute timings to the exact kernel symbol. */
 int mmdit_gemm_plan(const mmdit_gemm_args* args, int count);
+
+/* Per-tensor fp8 (e4m3) quantisation for the inference GEMMs (BASELINE config 5): amax[0] = max(amax[0], max|x|) (caller zeroes
+ * it), then q = round_to_e4m3(x * 448 / amax) and scale[0] = amax / 448 (the dequantisation scale mmdit_gemm_args.scale_*).
+ * Two launches on the same stream; nothing is read back by the host. */
+int mmdit_fp8_amax(const void* x, int x_dtype, int64_t n, float* amax, mmdit_stream_t stream);
+int mmdit_fp8_quantize(const void* x, int x_dtype, int64_t n, const float* amax, void* q_fp8, float* scale, mmdit_stream_t stream);
+/* Delayed scaling, one pass: quantise with margin * (amax of the previous call at this call site) and collect this call's amax.
+ * state: 4 floats {amax ring [3], dequantisation scale (output)}; phase = call counter of the call site (the caller initialises
+ * state[phase % 3] with a two-pass mmdit_fp8_amax before the first call). */
+int mmdit_fp8_quantize_delayed(const void* x, int x_dtype, int64_t n, float* state, int phase, float margin, void* q_fp8, mmdit_stream_t stream);
 
 /* dtype conversion of n elements (bf16 shadow copies of the fp32 master weights; the
  * reference gets these from torch.autocast, model_trainer.py:416). n%8==0 not required. */

@@ -14,6 +14,7 @@ HEADER_PATH = os.path.join(_HERE, "..", "include", "mmdit_hip.h")
 F32, BF16 = 0, 1
 ACT_NONE, ACT_SILU = 0, 1
 PREC_BF16, PREC_SPLIT = 0, 1
+FP8 = 2   # dtype code of OCP e4m3 GEMM operands (stored in torch.uint8 / float8_e4m3fn tensors)
 
 _vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
 
@@ -34,6 +35,7 @@ class GemmArgs(ctypes.Structure):
         ("split_k", _i),
         ("stream_k", _i),
         ("conv_mode", _i), ("conv_H", _i), ("conv_W", _i), ("conv_C", _i),
+        ("scale_a", _vp), ("scale_b", _vp),
     ]
 
 
@@ -44,6 +46,9 @@ _SIGNATURES = {
     "mmdit_gemm": ([ctypes.POINTER(GemmArgs), _vp], _i),
     "mmdit_gemm_grouped": ([ctypes.POINTER(GemmArgs), _i, _vp], _i),
     "mmdit_gemm_plan": ([ctypes.POINTER(GemmArgs), _i], _i),
+    "mmdit_fp8_amax": ([_vp, _i, _i64, _vp, _vp], _i),
+    "mmdit_fp8_quantize": ([_vp, _i, _i64, _vp, _vp, _vp, _vp], _i),
+    "mmdit_fp8_quantize_delayed": ([_vp, _i, _i64, _vp, _i, ctypes.c_float, _vp, _vp], _i),
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),

@@ -232,7 +232,8 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 int check_problem(const mmdit_gemm_args* a) {
   MMDIT_CHECK_ARG(a->A && a->B && a->C);
   MMDIT_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 4 == 0);
-  const int esa = a->a_dtype == MMDIT_F32 ? 4 : 2, esb = a->b_dtype == MMDIT_F32 ? 4 : 2, esc = a->c_dtype == MMDIT_F32 ? 4 : 2;
+  const int esa = a->a_dtype == MMDIT_F32 ? 4 : a->a_dtype == MMDIT_FP8 ? 1 : 2, esb = a->b_dtype == MMDIT_F32 ? 4 : a->b_dtype == MMDIT_FP8 ? 1 : 2, esc = a->c_dtype == MMDIT_F32 ? 4 : 2;
+  MMDIT_CHECK_ARG(a->c_dtype == MMDIT_F32 || a->c_dtype == MMDIT_BF16);
   MMDIT_CHECK_ARG(aligned16(a->A) && aligned16(a->B) && ((uintptr_t)a->C & (4 * esc - 1)) == 0);
   MMDIT_CHECK_ARG((a->lda * esa) % 16 == 0 && (a->ldb * esb) % 16 == 0 && a->ldc % 4 == 0);
   if (a->a_kmajor) { MMDIT_CHECK_ARG(a->M % 8 == 0 && a->lda >= a->M); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->lda >= a->K); }
@@ -265,6 +266,8 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
   return c256 < c128 ? CFG_256x256 : CFG_128x128;
 }
 
+static inline int split_k_of(const mmdit_gemm_args* a) { return a->split_k > 1 ? a->split_k : 1; }
+
 static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only) {
   MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
   const mmdit_gemm_args* a0 = &args[0];
@@ -274,7 +277,14 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   // the register-staged kernel, for A/B measurements)
   static const bool no_dma = getenv("MMDIT_GEMM_NO_DMA") != nullptr;
   static const char* raster_env = getenv("MMDIT_GEMM_RASTER");
+  // fp8 (e4m3) operands: DMA kernel only, row-major x row-major, K a multiple of the 128-wide fp8 K-tile, per-tensor scales
+  const bool fp8 = a0->a_dtype == MMDIT_FP8 || a0->b_dtype == MMDIT_FP8;
   bool dma = !no_dma && a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16;
+  if (fp8) {
+    MMDIT_CHECK_ARG(a0->a_dtype == MMDIT_FP8 && a0->b_dtype == MMDIT_FP8 && a0->precision == MMDIT_PREC_BF16 && split_k_of(a0) == 1 && !a0->stream_k);
+    dma = true;
+  }
+  const int bk = fp8 ? 2 * BK : BK;   // elements per K-tile (two 64-byte ring halves per row)
   bool conv = false;
   const int split_k = a0->split_k > 1 ? a0->split_k : 1;
   for (int i = 0; i < count; i++) {
@@ -286,7 +296,8 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
                     a->b_kmajor == a0->b_kmajor && a->precision == a0->precision && a->act == a0->act && a->accumulate == a0->accumulate);
     if (a->aux) { MMDIT_CHECK_ARG(aux_dt < 0 || aux_dt == a->aux_dtype); aux_dt = a->aux_dtype; }
     MMDIT_CHECK_ARG((a->split_k > 1 ? a->split_k : 1) == split_k);
-    if (a->K % BK != 0) dma = false;
+    if (fp8) MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && a->K % bk == 0 && a->scale_a && a->scale_b && !a->conv_mode);
+    if (a->K % bk != 0) dma = false;
     if (a->a_kmajor && a->M < 8) dma = false;
     if (a->b_kmajor && a->N < 8) dma = false;
     if (a->conv_mode) {
@@ -300,7 +311,10 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
       continue;
     }
     // the DMA kernel addresses an operand as a wave-uniform 64-bit base + a 32-bit per-lane byte offset
-    if ((int64_t)(a->a_kmajor ? a->K : a->M) * a->lda * 2 >= (1ll << 32) || (int64_t)(a->b_kmajor ? a->K : a->N) * a->ldb * 2 >= (1ll << 32)) dma = false;
+    if ((int64_t)(a->a_kmajor ? a->K : a->M) * a->lda * 2 >= (1ll << 32) || (int64_t)(a->b_kmajor ? a->K : a->N) * a->ldb * 2 >= (1ll << 32)) {
+      MMDIT_CHECK_ARG(!fp8);
+      dma = false;
+    }
   }
   if (conv) MMDIT_CHECK_ARG(dma);   // no register-staged fallback for the implicit-GEMM convolution
   int bm = BM, bn = BN, cfg = CFG_128x128;
@@ -322,7 +336,8 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     p.tiles_n = (a->N + bn - 1) / bn;
     p.tiles_m = (a->M + bm - 1) / bm;
     p.tile_start = tiles;
-    p.nk = a->K / BK;
+    p.nk = a->K / bk;
+    p.scale_a = a->scale_a; p.scale_b = a->scale_b;
     p.unit_start = units;
     tiles += p.tiles_n * p.tiles_m;
     units += p.tiles_n * p.tiles_m * p.nk;
@@ -372,7 +387,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   }
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0)) : 64;   // see mmdit_gemm_plan
   hipStream_t s = (hipStream_t)stream;
-  if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, gp, s);
+  if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, fp8, gp, s);
   if (a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a0, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_SPLIT && a0->a_dtype == MMDIT_F32 && a0->b_dtype == MMDIT_F32) return dispatch_out<float, float, true>(a0, aux_dt, gp, s);
   return MMDIT_ERR_DTYPE;

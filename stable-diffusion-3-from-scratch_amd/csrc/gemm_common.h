@@ -19,6 +19,7 @@ struct Problem {
   // implicit-GEMM 3x3 convolution (conv_mode != 0): A is a zero-bordered NHWC bf16 tensor (batch, cHp, cWp, cC); output row
   // m = (b, yo, xo) reads pixel (s*yo + kh + o, s*xo + kw + o) for K index (kh*3 + kw)*cC + c  (mode 1: s=1, o=0; mode 2: s=2, o=1)
   int conv_mode, cHo, cWo, cHp, cWp, cC;
+  const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (device scalars); C = sa*sb*(A_q B_q^T)
 };
 struct GroupParams {
   Problem p[MAXG];
@@ -215,6 +216,6 @@ __device__ __forceinline__ void epilogue_direct(const f32x16 (&acc)[MI][NJ], con
 // tile configurations of the LDS-DMA kernel (gemm_dma.hip)
 enum DmaCfg { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2 };
 inline void dma_cfg_tile(int cfg, int& bm, int& bn) { bm = cfg == CFG_128x128 ? 128 : 256; bn = cfg == CFG_256x256 ? 256 : 128; }
-int launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, const GroupParams& gp, hipStream_t s);
+int launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s);
 
 }  // namespace gemm

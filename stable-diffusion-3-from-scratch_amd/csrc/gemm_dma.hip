@@ -23,6 +23,7 @@
 //   256x128: 8 waves 4x2, 2x2 accumulators, 128 KB LDS
 //   256x256: 8 waves 2x4, 4x2 accumulators, 128 KB LDS  -- half the L2->CU bytes per FLOP of 128x128
 #include "gemm_common.h"
+#include <type_traits>
 
 using namespace gemm;
 
@@ -37,11 +38,11 @@ constexpr int RING = MMDIT_GEMM_RING;   // slots; DMA distance = RING - 1 halves
 constexpr int EP32_WAVE_BYTES = 4096;
 
 // byte offset (from the operand's half-tile base pointer) of the 16 B this lane sources for 1-KiB piece c
-template <bool KM, int R>
+template <bool KM, int R, int ESZ = 2>
 __device__ __forceinline__ uint32_t piece_voff(int c, int lane, int64_t ld, int row0, int rows) {
   if (!KM) {
     const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);   // (r>>2)&3 == (lane>>4)&3
-    return (uint32_t)((int64_t)min(row0 + r, rows - 1) * ld * 2 + piece * 16);
+    return (uint32_t)((int64_t)min(row0 + r, rows - 1) * ld * ESZ + piece * 16);
   } else {
     constexpr int PPR = R / 8;       // 16-B pieces per k-row
     const int k = c * (64 / PPR) + lane / PPR, slot = lane % PPR, piece = slot ^ ((k & 3) << 2);
@@ -85,12 +86,19 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int r0, int ks, 
   }
 }
 
+// fp8 (e4m3) row-major half-tile [R][64] (64 B rows, same byte geometry as the bf16 half-tile): the fragment of k-step ks
+// (16 values) is the 16-B piece ks of the row, each lane half takes 8 of them -> one ds_read_b64
+__device__ __forceinline__ long load_frag8(const char* tile, int r0, int ks, int lane) {
+  const int r = r0 + (lane & 31);
+  return *LDS_PTR(const long, tile + r * 64 + ((ks ^ ((r >> 2) & 3)) << 4) + (lane >> 5) * 8);
+}
+
 // Epilogue (see gemm_common.h for the arithmetic).  acc[i][j] holds a C^T fragment (lane = output row); each
 // 32x32 block goes through the wave's 4-KiB staging block (16-B chunk c of row r at chunk c ^ (r&7): conflict-free
 // ds_write_b128 / ds_read_b128) and leaves as 8 rows x 128 B (fp32) / 64 B (bf16) per wave instruction.
 template <typename TC, typename TAUX, int MI, int NJ>
 __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
-                                           int lane, int sk, char* stage, bool atomic_out) {
+                                           int lane, int sk, char* stage, bool atomic_out, float alpha = 1.f) {
   TC* C = (TC*)p.C;
   TAUX* AUX = (TAUX*)p.aux;
   const bool first = sk == 0;
@@ -130,7 +138,7 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
         const f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
         const int row = row0 + it * 8;
         if (row >= p.M || col >= p.N) continue;
-        float v[4] = {t[0] + b4[0], t[1] + b4[1], t[2] + b4[2], t[3] + b4[3]};
+        float v[4] = {t[0] * alpha + b4[0], t[1] * alpha + b4[1], t[2] * alpha + b4[2], t[3] * alpha + b4[3]};   // alpha == 1 exactly unless fp8
         if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
         if (gp.act == MMDIT_ACT_SILU) {
 #pragma unroll
@@ -174,7 +182,7 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
 // 8 rows x 128 B (full lines, 16 B per lane): half the LDS bytes and half the store instructions of the fp32 staging.
 template <int MI, int NJ>
 __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
-                                              int lane, char* stage) {
+                                              int lane, char* stage, float alpha = 1.f) {
   static_assert(NJ == 2, "wave sub-tile must be 64 columns wide");
   bf16_t* C = (bf16_t*)p.C;
   const float* bias = p.bias;
@@ -187,7 +195,7 @@ __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Probl
     for (int j = 0; j < NJ; j++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        float v[4] = {acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+        float v[4] = {acc[i][j][g * 4] * alpha, acc[i][j][g * 4 + 1] * alpha, acc[i][j][g * 4 + 2] * alpha, acc[i][j][g * 4 + 3] * alpha};
         if (bias) {
           const int c = colw + j * 32 + 8 * g + 4 * wc;
           float b4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -252,7 +260,7 @@ __device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end)
     int sk;
     const Problem& p = locate_tile(gp, pos, it.tm, it.tn, sk);
     const int S = is_split_work(gp, pos) ? gp.split_k : 1;
-    const int nk_all = p.K / BK, per = (nk_all + S - 1) / S;
+    const int nk_all = p.nk, per = (nk_all + S - 1) / S;
     const int kt0 = sk * per, kt1 = max(kt0, min(nk_all, kt0 + per));
     it.pi = (int)(&p - &gp.p[0]);
     it.h0 = 2 * kt0;
@@ -267,12 +275,18 @@ __device__ __forceinline__ int next_pos(const GroupParams& gp, const Item& it) {
   return gp.stream_k ? it.pos + (it.h1 - it.h0) / 2 : it.pos + (int)gridDim.x;
 }
 
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) {
+  // FP8: e4m3 operands (row-major only).  A ring slot still holds 64 B per row = 64 fp8 values, so the whole DMA / ring /
+  // barrier machinery is byte-identical; a half is four 16-wide k-steps of v_mfma_f32_32x32x16_fp8_fp8 instead of two bf16
+  // ones (same MFMA rate, half the operand bytes per FLOP -- this kernel is operand-traffic-bound).
+  static_assert(!FP8 || (!A_KM && !B_KM), "fp8 operands are row-major");
+  constexpr int ESZ = FP8 ? 1 : 2, KSTEPS = FP8 ? 4 : 2;
+  using frag_t = typename std::conditional<FP8, long, bf16x8>::type;
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
   constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB;      // bytes of one ring slot
   constexpr int PA = TBM / 16 / NW, PB = TBN / 16 / NW, PP = PA + PB;   // 1-KiB DMA pieces per wave and half
-  constexpr int DSTRIDE = (2 * MI) / PP > 0 ? (2 * MI) / PP : 1;       // MFMA rows between two pieces
+  constexpr int DSTRIDE = ((FP8 ? 4 : 2) * MI) / PP > 0 ? ((FP8 ? 4 : 2) * MI) / PP : 1;   // MFMA rows between two pieces
   static_assert(PA >= 1 && PB >= 1 && PP <= 2 * MI && PP <= 4, "piece schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -309,10 +323,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       for (int i = 0; i < PA; i++) va[i] = conv_voff(wave * PA + i, lane, q, cit.tm * TBM);
     } else {
 #pragma unroll
-      for (int i = 0; i < PA; i++) va[i] = piece_voff<A_KM, TBM>(wave * PA + i, lane, q.lda, cit.tm * TBM, q.M);
+      for (int i = 0; i < PA; i++) va[i] = piece_voff<A_KM, TBM, ESZ>(wave * PA + i, lane, q.lda, cit.tm * TBM, q.M);
     }
 #pragma unroll
-    for (int i = 0; i < PB; i++) vb[i] = piece_voff<B_KM, TBN>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
+    for (int i = 0; i < PB; i++) vb[i] = piece_voff<B_KM, TBN, ESZ>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
     stepa = A_KM ? (int64_t)BKH * q.lda * 2 : BKH * 2;
     stepb = B_KM ? (int64_t)BKH * q.ldb * 2 : BKH * 2;
     sa = (const char*)q.A + ch * stepa;
@@ -371,11 +385,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     char* stage = smem + (STAGE_IN_RING ? dslot * H : RING * H) + wave * EP32_WAVE_BYTES;   // dslot: free until the next issue
     if (!(gp.debug & 8)) {
       const Problem& q = gp.p[it.pi];
+      float alpha = 1.f;
+      if constexpr (FP8) alpha = q.scale_a[0] * q.scale_b[0];
       bool fast = false;
       if constexpr (sizeof(TC) == 2 && NJ == 2)
         fast = !q.aux && !q.residual && !q.gate && !gp.accumulate && !it.atomic && (q.N & 7) == 0 && (q.ldc & 7) == 0 && ((uintptr_t)q.C & 15) == 0 && !(gp.debug & 64);
-      if (fast) epilogue_bf16<MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, stage);
-      else epilogue32<TC, TAUX, MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, it.atomic);
+      if (fast) epilogue_bf16<MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, stage, alpha);
+      else epilogue32<TC, TAUX, MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, it.atomic, alpha);
     }
     else if (acc[0][0][0] == 12345.678f) ((float*)gp.p[it.pi].C)[0] = 0.f;   // ablation: keep the accumulators live
   };
@@ -395,7 +411,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   // Fragment registers are carried from half to half: the last k-step of a half already reads the first fragments
   // of the NEXT half (which half_sync made visible one half early), so no half starts with an exposed LDS burst.
   // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m
-  bf16x8 a[MI], b[2][NJ];
+  frag_t a[MI], b[2][NJ];
+  auto ldA = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, ks, lane); else return load_frag_h<A_KM, TBM>(t, r0, ks, lane); };
+  auto ldB = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, ks, lane); else return load_frag_h<B_KM, TBN>(t, r0, ks, lane); };
   // one K half: multiply slot done&3 while the PP pieces of the cursor's half go into slot issued&3 (= (done-1)&3,
   // which every wave left before the barrier of half_sync).  No data-dependent branch inside.
   auto half_body = [&]() {
@@ -405,19 +423,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     const char* na = smem + nslot * H;   // (after the last half of the stream: read, never used)
     const char* nb = na + HA;
 #pragma unroll
-    for (int ks = 0; ks < BKH / 16; ks++) {
+    for (int ks = 0; ks < KSTEPS; ks++) {
       const int c = ks & 1, nx = c ^ 1;
-      const bool last = ks + 1 == BKH / 16;
+      const bool last = ks + 1 == KSTEPS;
       // B fragments are double-buffered, each A fragment is reloaded right after the last MFMA that reads it; the
       // order is pinned so every ds_read has MFMAs of cover and gets a counted lgkmcnt wait.
 #pragma unroll
-      for (int j = 0; j < NJ; j++) b[nx][j] = load_frag_h<B_KM, TBN>(last ? nb : tb, wn * (NJ * 32) + j * 32, last ? 0 : ks + 1, lane);
+      for (int j = 0; j < NJ; j++) b[nx][j] = ldB(last ? nb : tb, wn * (NJ * 32) + j * 32, last ? 0 : ks + 1);
 #pragma unroll
       for (int i = 0; i < MI; i++) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
-        a[i] = load_frag_h<A_KM, TBM>(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1, lane);
+        for (int j = 0; j < NJ; j++) {
+          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b[c][j], a[i], acc[i][j], 0, 0, 0);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
+        }
+        a[i] = ldA(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1);
         const int q = ks * MI + i;   // compile-time after unrolling
         if (q % DSTRIDE == 0 && q / DSTRIDE < PP) {
           __builtin_amdgcn_sched_barrier(0);
@@ -465,9 +486,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
           first = false;
           const char* ta = smem;
 #pragma unroll
-          for (int j = 0; j < NJ; j++) b[0][j] = load_frag_h<B_KM, TBN>(ta + HA, wn * (NJ * 32) + j * 32, 0, lane);
+          for (int j = 0; j < NJ; j++) b[0][j] = ldB(ta + HA, wn * (NJ * 32) + j * 32, 0);
 #pragma unroll
-          for (int i = 0; i < MI; i++) a[i] = load_frag_h<A_KM, TBM>(ta, wm * (MI * 32) + i * 32, 0, lane);
+          for (int i = 0; i < MI; i++) a[i] = ldA(ta, wm * (MI * 32) + i * 32, 0);
         }
         half_body();
 #pragma unroll 1
@@ -492,11 +513,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   if (pending) run_epilogue(prev);
 }
 
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX>
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false>
 int launch_cfg(const GroupParams& gp, hipStream_t s) {
   constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64;
   constexpr int smem = RING * slot + (WM * WN * EP32_WAVE_BYTES <= slot ? 0 : WM * WN * EP32_WAVE_BYTES);
-  auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX>;
+  auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX, FP8>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -529,7 +550,13 @@ int by_layout(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t 
 
 }  // namespace
 
-int gemm::launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, const GroupParams& gp, hipStream_t s) {
+int gemm::launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s) {
+  if (fp8) {   // e4m3 operands: row-major x row-major, bf16 or fp32 output (aux, if any, in the output dtype)
+    if (a_km || b_km || aux_dtype != c_dtype || cfg == CFG_256x128) return MMDIT_ERR_DTYPE;
+    if (c_dtype == MMDIT_BF16) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, bf16_t, bf16_t, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, true>(gp, s);
+    if (c_dtype == MMDIT_F32) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, float, float, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, float, float, true>(gp, s);
+    return MMDIT_ERR_DTYPE;
+  }
   if (c_dtype == MMDIT_F32 && aux_dtype == MMDIT_F32) return by_layout<float, float>(cfg, a_km, b_km, gp, s);
   if (c_dtype == MMDIT_F32 && aux_dtype == MMDIT_BF16) return by_layout<float, bf16_t>(cfg, a_km, b_km, gp, s);
   if (c_dtype == MMDIT_BF16 && aux_dtype == MMDIT_BF16) return by_layout<bf16_t, bf16_t>(cfg, a_km, b_km, gp, s);

@@ -820,6 +820,100 @@ extern "C" int mmdit_colsum(const void* x, int dtype, int rows, int cols, int64_
   return mmdit_launch_status();
 }
 
+namespace {
+template <typename TI>
+__global__ __launch_bounds__(256) void fp8_amax_kernel(const TI* __restrict__ x, int64_t n8, float* __restrict__ amax) {
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+    ld8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; e++) m = fmaxf(m, fabsf(v[e]));
+  }
+  __shared__ float sm[4];
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  // one atomic per workgroup (they all hit the same address); non-negative floats order like their bit patterns
+  if (threadIdx.x == 0) atomicMax((unsigned int*)amax, __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
+}
+template <typename TI>
+__global__ __launch_bounds__(256) void fp8_quant_kernel(const TI* __restrict__ x, int64_t n8, const float* __restrict__ amax, uint2* __restrict__ q, float* __restrict__ scale) {
+  const float a = fmaxf(amax[0], 1e-12f), s = 448.f / a;
+  if (blockIdx.x == 0 && threadIdx.x == 0) scale[0] = a / 448.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+    ld8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = fminf(fmaxf(v[e] * s, -448.f), 448.f);
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    q[i] = make_uint2((unsigned)lo, (unsigned)hi);
+  }
+}
+// Delayed scaling (one pass): quantise with the amax of the PREVIOUS call at this call site (x margin) while collecting this
+// call's amax for the next one.  state = {amax[0], amax[1], amax[2], scale}: call k reads amax[k % 3], maximises into
+// amax[(k+1) % 3] and clears amax[(k+2) % 3] (the target of call k+1, last read by call k-1) -- stream order makes that race-free.
+template <typename TI>
+__global__ __launch_bounds__(256) void fp8_quant_delayed_kernel(const TI* __restrict__ x, int64_t n8, float* __restrict__ state, int phase, float margin,
+                                                                uint2* __restrict__ q) {
+  __shared__ float sm[4];
+  const float a = fmaxf(state[phase % 3] * margin, 1e-12f), s = 448.f / a;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { state[3] = a / 448.f; state[(phase + 2) % 3] = 0.f; }
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float v[8];
+    ld8(x + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { m = fmaxf(m, fabsf(v[e])); v[e] = fminf(fmaxf(v[e] * s, -448.f), 448.f); }
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+    q[i] = make_uint2((unsigned)lo, (unsigned)hi);
+  }
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax((unsigned int*)(state + (phase + 1) % 3), __float_as_uint(fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]))));
+}
+}  // namespace
+
+extern "C" int mmdit_fp8_quantize_delayed(const void* x, int x_dtype, int64_t n, float* state, int phase, float margin, void* q_fp8, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && state && q_fp8 && n > 0 && n % 8 == 0 && phase >= 0 && margin >= 1.f);
+  hipStream_t s = (hipStream_t)stream;
+  const int g0 = grid_cap(n / 8, 256);
+  dim3 grid(g0 > 1024 ? 1024 : g0);
+  if (x_dtype == MMDIT_F32) hipLaunchKernelGGL((fp8_quant_delayed_kernel<float>), grid, dim3(256), 0, s, (const float*)x, n / 8, state, phase, margin, (uint2*)q_fp8);
+  else if (x_dtype == MMDIT_BF16) hipLaunchKernelGGL((fp8_quant_delayed_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, n / 8, state, phase, margin, (uint2*)q_fp8);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_fp8_amax(const void* x, int x_dtype, int64_t n, float* amax, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && amax && n > 0 && n % 8 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int g0 = grid_cap(n / 8, 256);
+  dim3 grid(g0 > 1024 ? 1024 : g0);
+  if (x_dtype == MMDIT_F32) hipLaunchKernelGGL((fp8_amax_kernel<float>), grid, dim3(256), 0, s, (const float*)x, n / 8, amax);
+  else if (x_dtype == MMDIT_BF16) hipLaunchKernelGGL((fp8_amax_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, n / 8, amax);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+extern "C" int mmdit_fp8_quantize(const void* x, int x_dtype, int64_t n, const float* amax, void* q_fp8, float* scale, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && amax && q_fp8 && scale && n > 0 && n % 8 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(grid_cap(n / 8, 256));
+  if (x_dtype == MMDIT_F32) hipLaunchKernelGGL((fp8_quant_kernel<float>), grid, dim3(256), 0, s, (const float*)x, n / 8, amax, (uint2*)q_fp8, scale);
+  else if (x_dtype == MMDIT_BF16) hipLaunchKernelGGL((fp8_quant_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, n / 8, amax, (uint2*)q_fp8, scale);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
 extern "C" int mmdit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(src && dst && n > 0);
   hipStream_t s = (hipStream_t)stream;

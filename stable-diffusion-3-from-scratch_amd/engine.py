@@ -29,11 +29,13 @@ BF16 = torch.bfloat16
 
 
 class Mode:
-    def __init__(self, fast: bool = True):
+    def __init__(self, fast: bool = True, fp8: bool = False):
         self.fast = fast
+        self.fp8 = fp8          # inference only: the four big GEMMs of a block take e4m3 operands (per-tensor scales)
         self.T = BF16 if fast else F32
         self.prec = PREC_BF16 if fast else PREC_SPLIT
         self.attn_mode = 0 if fast else 1
+        self._q = {}            # id(packed bf16 weight) -> (weight, fp8 copy, scale); weights are static while sampling
 
     def act(self, t):
         """Tensor as a GEMM A operand in this mode's activation dtype."""
@@ -42,6 +44,7 @@ class Mode:
 
 FAST = Mode(True)
 PARITY = Mode(False)
+FP8 = Mode(True, fp8=True)
 
 MOD_NAMES_FULL = ["shift1x", "scale1x", "gate1x", "shift2x", "scale2x", "gate2x", "shift1c", "scale1c", "gate1c", "shift2c", "scale2c", "gate2c"]
 
@@ -55,8 +58,26 @@ def _gemm(m, A, B, **kw):
     return ops.gemm(A, B, precision=m.prec, **kw)
 
 
-def _group(m, problems):
-    """One grouped launch; problems = list of dicts (A, B, + gemm kwargs)."""
+def _to_fp8(m, p):
+    """fp8 inference mode: quantise the activation on the fly (per-tensor amax -> e4m3), take the cached e4m3 copy of the
+    weight, drop the backward-only aux output.  Problems whose K is not a multiple of the 128-wide fp8 K-tile stay bf16."""
+    A, B = p["A"], p["B"]
+    if A.dtype != BF16 or B.dtype != BF16 or A.shape[1] % 128 or p.get("a_kmajor") or p.get("b_kmajor"):
+        return p
+    ent = m._q.get(id(B))
+    if ent is None:
+        qb, sb = ops.quant_fp8(B)
+        ent = m._q[id(B)] = (B, qb, sb, ops.Fp8Site())
+    qa, sa = ent[3].quantise(A)      # delayed scaling: consecutive sampler steps see nearly the same activation range
+    q = {k: v for k, v in p.items() if k != "aux"}
+    q.update(A=qa, B=ent[1], scale_a=sa, scale_b=ent[2])
+    return q
+
+
+def _group(m, problems, fp8=False):
+    """One grouped launch; problems = list of dicts (A, B, + gemm kwargs).  fp8: eligible for e4m3 operands in FP8 mode."""
+    if fp8 and m.fp8:
+        problems = [_to_fp8(m, p) for p in problems]
     for p in problems:
         p["precision"] = m.prec
     return ops.gemm_grouped(problems)
@@ -223,7 +244,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
 
     sv.ln1x, sv.mu1x, sv.rs1x = ops.ln_modulate_fwd(X, ms.scale1x, ms.shift1x, N, m.T)
     sv.ln1c, sv.mu1c, sv.rs1c = ops.ln_modulate_fwd(C, ms.scale1c, ms.shift1c, Mt, m.T)
-    sv.qkv_x, sv.qkv_c = _group(m, [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T)])
+    sv.qkv_x, sv.qkv_c = _group(m, [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T)], fp8=True)
     sv.Q = torch.empty((B, H, S, 64), dtype=BF16, device=dev)
     sv.K, sv.V = torch.empty_like(sv.Q), torch.empty_like(sv.Q)
     ops.qk_norm_rope_fwd(sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, sv.Q, sv.K, sv.V)
@@ -237,7 +258,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
         sv.Oca = m.act(sv.Oc.view(B * Mt, d))
         sv.acc_oc = torch.empty((B * Mt, d), dtype=m.T, device=dev)
         probs.append(dict(A=sv.Oca, B=w.Wo_c, gate=ms.gate1c, rows_per_batch=Mt, residual=C, aux=sv.acc_oc, out_dtype=F32))
-    outs = _group(m, probs)
+    outs = _group(m, probs, fp8=True)
     X1, C1 = outs[0], (outs[1] if both else C)
     sv.X1, sv.C1 = X1, C1
 
@@ -246,7 +267,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
     if both:
         sv.ln2c, sv.mu2c, sv.rs2c = ops.ln_modulate_fwd(C1, ms.scale2c, ms.shift2c, Mt, m.T)
         probs.append(dict(A=sv.ln2c, B=w.mlp_c.Wup, bias=w.mlp_c.bup, out_dtype=m.T))
-    outs = _group(m, probs)
+    outs = _group(m, probs, fp8=True)
     sv.gu_x = outs[0]
     sv.h_x = ops.mlp_act_fwd(sv.gu_x, w.mlp_x.hidden, w.mlp_x.gelu)
     sv.acc_mx = torch.empty((B * N, d), dtype=m.T, device=dev)
@@ -256,7 +277,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
         sv.h_c = ops.mlp_act_fwd(sv.gu_c, w.mlp_c.hidden, w.mlp_c.gelu)
         sv.acc_mc = torch.empty((B * Mt, d), dtype=m.T, device=dev)
         probs.append(dict(A=sv.h_c, B=w.mlp_c.Wdown, bias=w.mlp_c.bdown, gate=ms.gate2c, rows_per_batch=Mt, residual=C1, aux=sv.acc_mc, out_dtype=F32))
-    outs = _group(m, probs)
+    outs = _group(m, probs, fp8=True)
     X2, C2 = outs[0], (outs[1] if both else C1)
     return X2, C2, sv
 

@@ -8,9 +8,9 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SILU, BF16, F32, PREC_BF16, PREC_SPLIT, GemmArgs, check
+from ._lib import ACT_NONE, ACT_SILU, BF16, F32, FP8, PREC_BF16, PREC_SPLIT, GemmArgs, check
 
-_DT = {torch.float32: F32, torch.bfloat16: BF16}
+_DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
 # (entries: (kernel variant, algorithmic FLOPs, start event, end event)); None = no instrumentation.
@@ -89,7 +89,7 @@ def torch_dtype(code: int):
 
 # ---------------------------------------------------------------------------------------------
 def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None):
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None, scale_a=None, scale_b=None):
     """conv = (mode, H, W, C): A is a zero-bordered NHWC bf16 tensor (batch, H+2, W+2, C) -- implicit-GEMM 3x3 convolution."""
     if conv is not None:
         mode, cH, cW, cC = conv
@@ -114,6 +114,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), (K_ if conv is not None else A.stride(0))
     if conv is not None:
         a.conv_mode, a.conv_H, a.conv_W, a.conv_C = conv
+    a.scale_a, a.scale_b = _p(scale_a), _p(scale_b)
     a.B, a.b_dtype, a.b_kmajor, a.ldb = _p(B), _dt(B), int(b_kmajor), B.stride(0)
     a.C, a.c_dtype, a.ldc = _p(out), _dt(out), out.stride(0)
     a.M, a.N, a.K = M, N, K_
@@ -170,6 +171,36 @@ def gemm(A, B, **kw):
     """C[M,N] = epilogue(A[M,K] B[N,K]^T).  A: (M,K) or k-major (K,M); B: (N,K) or k-major (K,N).
     gate may be a strided 2-D view (rows = batch) with unit inner stride."""
     return gemm_grouped([dict(A=A, B=B, **kw)])[0]
+
+
+def quant_fp8(x):
+    """Per-tensor e4m3 quantisation: returns (q: torch.float8_e4m3fn like x, scale: fp32 (1,) dequantisation scale on the device)."""
+    n = x.numel()
+    buf = torch.zeros(2, dtype=torch.float32, device=x.device)       # [amax, scale]
+    q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    L = _lib.lib()
+    check(L.mmdit_fp8_amax(_p(_c(x)), _dt(x), n, _p(buf), _s()), "mmdit_fp8_amax")
+    check(L.mmdit_fp8_quantize(_p(x), _dt(x), n, _p(buf), _p(q), _p(buf[1:]), _s()), "mmdit_fp8_quantize")
+    return q, buf[1:]
+
+
+class Fp8Site:
+    """Delayed-scaling state of one activation call site (one GEMM A operand): the first call measures amax with the two-pass
+    quantiser, later calls quantise in ONE pass with margin x the previous call's amax while collecting their own."""
+
+    def __init__(self, margin=1.5):
+        self.state, self.phase, self.margin = None, 0, margin
+
+    def quantise(self, x):
+        L = _lib.lib()
+        q = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+        if self.state is None:
+            self.state = torch.zeros(4, dtype=torch.float32, device=x.device)
+            check(L.mmdit_fp8_amax(_p(_c(x)), _dt(x), x.numel(), _p(self.state), _s()), "mmdit_fp8_amax")      # -> state[0] = amax
+        check(L.mmdit_fp8_quantize_delayed(_p(_c(x)), _dt(x), x.numel(), _p(self.state), self.phase, float(self.margin if self.phase else 1.0),
+                                           _p(q), _s()), "mmdit_fp8_quantize_delayed")
+        self.phase += 1
+        return q, self.state[3:]
 
 
 def cast(src, dtype, out=None):

@@ -347,3 +347,41 @@ def test_gemm_stream_k_grouped_wgrad(ops):
     outs = ops.gemm_grouped(probs)
     for o, r in zip(outs, refs):
         assert rel(o, r) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16)])
+def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
+    """fp8 (e4m3, per-tensor scale) operand GEMM of the inference path vs the same quantised values multiplied in fp32."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    W = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda")
+    qa, sa = ops.quant_fp8(A)
+    qw, sw = ops.quant_fp8(W)
+    # quantisation itself: dequantised values within e4m3 precision of the input, scale = amax / 448
+    assert abs(float(sa) - float(A.float().abs().max()) / 448.0) < 1e-6 * float(sa) + 1e-12
+    assert rel(qa.float() * sa, A.float()) < 4e-2
+    y = ops.gemm(qa, qw, bias=bias, out_dtype=out_dtype, scale_a=sa, scale_b=sw)
+    ref = (qa.float() * sa) @ (qw.float() * sw).t() + bias
+    assert rel(y.float(), ref) < (5e-3 if out_dtype == torch.bfloat16 else 1e-5)
+    # and it is a faithful approximation of the bf16 product
+    assert rel(y.float(), A.float() @ W.float().t() + bias) < 6e-2
+
+
+def test_fp8_delayed_scaling_site(ops):
+    """One-pass quantiser with delayed scaling: call k uses margin x amax(call k-1); values above that range saturate at +-448."""
+    g = torch.Generator(device="cuda").manual_seed(1)
+    site = ops.Fp8Site(margin=1.5)
+    x0 = torch.randn((512, 256), generator=g, device="cuda").to(torch.bfloat16)
+    q0, s0 = site.quantise(x0)                       # first call: measured amax, no margin
+    assert abs(float(s0) * 448.0 - float(x0.float().abs().max())) < 1e-3 and rel(q0.float() * s0, x0.float()) < 4e-2
+    x1 = x0 * 1.3                                    # grows, but stays inside the 1.5x margin of the previous amax
+    q1, s1 = site.quantise(x1)
+    assert abs(float(s1) - 1.5 * float(x0.float().abs().max()) / 448.0) < 1e-6 and rel(q1.float() * s1, x1.float()) < 5e-2
+    x2 = x1 * 4.0                                    # outgrows the margin: saturates instead of overflowing to NaN
+    q2, s2 = site.quantise(x2)
+    assert abs(float(s2) - 1.5 * float(x1.float().abs().max()) / 448.0) < 1e-6
+    d2 = q2.float() * s2
+    assert torch.isfinite(d2).all() and float(d2.abs().max()) <= 1.5 * float(x1.float().abs().max()) * (1 + 1e-6)
+    q3, s3 = site.quantise(x0)                       # the ring has moved on to amax(x2)
+    assert abs(float(s3) - 1.5 * float(x2.float().abs().max()) / 448.0) < 1e-5

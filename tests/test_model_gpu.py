@@ -453,3 +453,23 @@ def test_gpu_resident_ema_matches_reference_cpu_loop():
     for k in res[0]:
         assert torch.allclose(res[0][k], res[1][k], rtol=1e-6, atol=1e-8), k
     assert any(not torch.equal(res[0][k], make_state_dict(0, **CONFIGS["micro"])[k]) for k in res[0])
+
+
+def test_fp8_inference_mode():
+    """precision "fp8" (BASELINE config 5: e4m3 operands, per-tensor scales, the four big GEMMs of every block): forward-only,
+    close to the bf16 forward (fp8 has 3 mantissa bits: a few percent per GEMM), refuses to train."""
+    for cname, h, w in (("xs", 64, 64), ("b", 32, 32)):
+        x, c, cp = make_inputs(21, 2, h, w, text_scale=30.0)
+        t = torch.tensor([0.2, 0.9])
+        net, _ = build(cname, precision="fast")
+        with torch.no_grad():
+            v_fast = net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())
+            net.set_precision("fp8")
+            assert net.precision == "fp8"
+            v_fp8 = net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())
+        r = rel(v_fp8, v_fast)
+        print(f"[fp8] {cname}: forward rel-L2 vs bf16 fast mode = {r:.3e}")
+        assert torch.isfinite(v_fp8).all() and 1e-4 < r < 8e-2
+        with pytest.raises(RuntimeError):
+            net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())        # grad mode on: refused
+        net.set_precision("fast")
