@@ -375,7 +375,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   gp.persistent = !no_persist;
   if (aux_dt < 0) aux_dt = a0->c_dtype;
   gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = tail_split; gp.full_tiles = full_tiles;
-  static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation bits: 1 = no DMA in the main loop, 2 = no LDS reads / MFMA, 4 = no cross-tile prefetch, 8 = no epilogue
+  static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation bits (tools/gemm_ablate.py): 2 = operand stream only (no LDS reads / MFMA), 8 = no epilogue, 64 = no bf16 fast epilogue
   gp.debug = debug_env ? atoi(debug_env) : 0;
   static const char* epi_env = getenv("MMDIT_GEMM_EPI");
   gp.epi_direct = epi_env ? (atoi(epi_env) == 0) : 0;

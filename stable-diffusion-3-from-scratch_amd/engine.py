@@ -16,6 +16,8 @@ Precision modes:
   fast   : bf16 activations / bf16 MFMA operands, fp32 accumulation, fp32 residual stream, flash attention.
   parity : fp32 activations, 3-term split-bf16 (fp32-exact) MFMA GEMMs, attention core that reproduces the
            rounding points of the reference's CPU branch (Attention.py:277-284).  For the 1e-3 golden check.
+  fp8    : fast, plus e4m3 operands (per-tensor scales, delayed activation scaling) for the QKV / out / MLP GEMMs of every
+           block.  Forward only (the sampler, BASELINE config 5).
 """
 from types import SimpleNamespace as NS
 
