@@ -139,14 +139,18 @@ def main():
     loss_val = float(loss)
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
+        # three extra (untimed) steps with every GEMM launch bracketed by HIP events.  EVERY rank runs them -- the steps contain
+        # the gradient all-reduce, so a rank-0-only loop would leave the other ranks out of the collectives -- rank 0 reports.
         from sd3_amd import engine
         overlap, engine._WG_OVERLAP = engine._WG_OVERLAP, False   # serialise the side-stream wgrad launches: clean per-kernel durations
-        ops.PROFILE = []
+        ops.PROFILE = [] if rank == 0 else None
         for _ in range(3):
             step += 1
             trainer.train_step(step)
         torch.cuda.synchronize()
+        engine._WG_OVERLAP = overlap
+    if rank == 0 and not args.no_roofline:
         stats = {}
         for name, flops, e0, e1 in ops.PROFILE:
             s = stats.setdefault(name, [0, 0.0, 0.0])
@@ -154,7 +158,6 @@ def main():
             s[1] += flops
             s[2] += e0.elapsed_time(e1) * 1e-3
         ops.PROFILE = None
-        engine._WG_OVERLAP = overlap
         tot_t = sum(s[2] for s in stats.values())
         tot_f = sum(s[1] for s in stats.values())
         dom = max(stats.items(), key=lambda kv: kv[1][2])
