@@ -272,6 +272,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
   const mmdit_gemm_args* a0 = &args[0];
   GroupParams gp;
+  gp.tail_first = -1; gp.tail_rounds = 0; gp.tail_G = 0;
   int aux_dt = -1;
   // LDS-DMA fast path: bf16 operands, every K a multiple of the 64-wide K-tile (MMDIT_GEMM_NO_DMA=1 forces
   // the register-staged kernel, for A/B measurements)
@@ -323,8 +324,17 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   const bool stream_k = dma && !no_sk && a0->stream_k && a0->c_dtype == MMDIT_F32 && split_k == 1 && a0->act == MMDIT_ACT_NONE && !a0->accumulate;
   if (dma) { cfg = pick_dma_cfg(args, count, split_k, stream_k); dma_cfg_tile(cfg, bm, bn); }
   int tiles = 0, units = 0;
+  // K-decomposed launches take the problems longest-K first: the tiles of the first round are then ordered long -> short and the
+  // balanced tail below can hand the split leftovers to the workgroups that finish their first tile early
+  static const char* kdec_env = getenv("MMDIT_GEMM_KDEC");
+  static const bool kdec_streamk = kdec_env && kdec_env[0] == 's', kdec_plain = kdec_env && kdec_env[0] == 'p';
+  int order[MAXG];
+  for (int i = 0; i < count; i++) order[i] = i;
+  if (stream_k && !kdec_streamk)
+    for (int i = 1; i < count; i++)
+      for (int j = i; j > 0 && args[order[j]].K > args[order[j - 1]].K; j--) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
   for (int i = 0; i < count; i++) {
-    const mmdit_gemm_args* a = &args[i];
+    const mmdit_gemm_args* a = &args[order[i]];
     Problem& p = gp.p[i];
     p.A = a->A; p.B = a->B; p.C = a->C; p.aux = a->aux;
     p.bias = a->bias; p.gate = a->gate; p.residual = a->residual;
@@ -349,8 +359,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   // workgroups of an XCD then walk K together and share operand panels through its L2 (stream-K's contiguous unit ranges
   // never do: measured 3.8x operand over-fetch, HBM-bound) -- and only the T % slots leftover tiles are cut S ways along K.
   // MMDIT_GEMM_KDEC=streamk selects the stream-K schedule instead.
-  static const char* kdec_env = getenv("MMDIT_GEMM_KDEC");
-  static const bool kdec_streamk = kdec_env && kdec_env[0] == 's';
+  // MMDIT_GEMM_KDEC=plain keeps the tail schedule but spreads the tail units over all workgroups.
   int full_tiles = split_k > 1 ? 0 : tiles, tail_split = split_k;
   bool tail_mode = false;
   if (stream_k && !kdec_streamk) {
@@ -368,6 +377,28 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
         // per 256x256 fp32 partial = 0.0028 rounds)
         const double c = (double)((r * S + G - 1) / G) / S + (S > 1 ? 0.0028 * r * S : 0.0);
         if (c < best) { best = c; tail_split = S; }
+      }
+      // Balanced tail (one full round, problems of different K): in the first round the tiles of the shorter problems finish
+      // early; give the tail units to exactly those workgroups (E of them) instead of stacking them on top of the longest tiles.
+      if (full_tiles == G && !kdec_plain) {
+        const int nk_max = gp.p[0].nk;
+        int first_short = G, nk_short = 0, nk_tail = 0;
+        for (int i = 0; i < count; i++) {
+          const Problem& q = gp.p[i];
+          if (q.nk < nk_max && q.tile_start < G && first_short == G) { first_short = q.tile_start; nk_short = q.nk; }
+          if (q.tile_start + q.tiles_m * q.tiles_n > full_tiles) nk_tail = q.nk > nk_tail ? q.nk : nk_tail;
+        }
+        const int E = G - first_short;
+        if (E > 0) {
+          double bbest = 1e30;
+          int bS = 0, brounds = 0;
+          for (int S = 1; S <= 64 && S * 2 <= nk_min; S++) {
+            const int rounds = (r * S + E - 1) / E, extra = rounds * ((nk_tail + S - 1) / S);
+            const double load = (double)(nk_short + extra) / nk_max, c = (load > 1.0 ? load - 1.0 : 0.0) + (S > 1 ? 0.0028 * r * S : 0.0);
+            if (c < bbest) { bbest = c; bS = S; brounds = rounds; }
+          }
+          if (bbest < best) { tail_split = bS; gp.tail_first = first_short; gp.tail_rounds = brounds; gp.tail_G = G; }
+        }
       }
     }
   }

@@ -26,6 +26,9 @@ struct GroupParams {
   int count, total_tiles, act, accumulate, split_k, raster, debug, epi_direct;
   int full_tiles;   // tiles [0, full_tiles) are multiplied over their whole K by one workgroup; tiles [full_tiles, total_tiles) are cut
                     // split_k ways along K (partials added atomically into a pre-zeroed fp32 C)
+  // Balanced tail (tail_first >= 0; needs full_tiles == tail_G, problems sorted by K descending): the split tail units go only to
+  // the workgroups whose first-round tile is a SHORT one (its position in the tile order >= tail_first), tail_rounds units each.
+  int tail_first, tail_rounds, tail_G;
   int stream_k, total_units, persistent;   // stream-K: every workgroup gets an equal share of the (tile, K-tile) units
 };
 
@@ -36,7 +39,9 @@ struct GroupParams {
 //    groups' rows, so that one group of B panels (raster*BN rows of the weight) stays L2-resident while the
 //    A row panels stream past it once.
 // work items of a launch: the unsplit tiles first, then (tile, K-slice) pairs of the split tail
-__device__ __host__ __forceinline__ int total_work(const GroupParams& gp) { return gp.full_tiles + (gp.total_tiles - gp.full_tiles) * gp.split_k; }
+__device__ __host__ __forceinline__ int total_work(const GroupParams& gp) {
+  return gp.tail_first >= 0 ? gp.full_tiles + gp.tail_rounds * gp.tail_G : gp.full_tiles + (gp.total_tiles - gp.full_tiles) * gp.split_k;
+}
 __device__ __forceinline__ bool is_split_work(const GroupParams& gp, int work) { return work >= gp.full_tiles && gp.split_k > 1; }
 
 // work index -> contiguous range per XCD of a sequence of W items (workgroup b runs on XCD b % 8; full_tiles is a multiple of 8
@@ -46,7 +51,9 @@ __device__ __forceinline__ int xcd_chunk(int w, int W) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
 }
 
-__device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int work, int& tm, int& tn, int& sk) {
+__device__ __forceinline__ const Problem& locate_in_problem(const GroupParams& gp, int t, int& tm, int& tn);
+
+__device__ __forceinline__ int work_tile(const GroupParams& gp, int work, int& sk) {
   // Inside the split tail the K-slice is the SLOW index (k-chunk-major): an XCD owns (mostly) one K-slice of ALL tail
   // tiles, so each operand panel of that slice is fetched once into its L2 instead of once per tile.
   int t;
@@ -58,6 +65,14 @@ __device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int
     sk = lin / Tt;
     t = gp.full_tiles + lin - sk * Tt;
   }
+  return t;
+}
+
+__device__ __forceinline__ const Problem& locate_tile(const GroupParams& gp, int work, int& tm, int& tn, int& sk) {
+  return locate_in_problem(gp, work_tile(gp, work, sk), tm, tn);
+}
+
+__device__ __forceinline__ const Problem& locate_in_problem(const GroupParams& gp, int t, int& tm, int& tn) {
   int pi = 0;
 #pragma unroll 1
   for (int i = 1; i < gp.count; i++) pi = (t >= gp.p[i].tile_start) ? i : pi;

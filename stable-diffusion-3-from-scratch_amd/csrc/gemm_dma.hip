@@ -257,8 +257,18 @@ __device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end)
     it.sk = k0 == 0 ? 0 : 1;
     it.atomic = true;
   } else {
-    int sk;
-    const Problem& p = locate_tile(gp, pos, it.tm, it.tn, sk);
+    int sk, t;
+    if (gp.tail_first >= 0 && pos >= gp.full_tiles) {
+      // balanced tail: round rnd of the tail gives one unit to each workgroup whose first-round tile was a short one (the
+      // kernel bounds `end` per workgroup so that only positions with a unit are visited)
+      const int rnd = (pos - gp.full_tiles) / gp.tail_G, l = xcd_chunk((int)blockIdx.x, gp.full_tiles);
+      const int Tt = gp.total_tiles - gp.full_tiles, u = rnd * (gp.tail_G - gp.tail_first) + l - gp.tail_first;
+      sk = u / Tt;
+      t = gp.full_tiles + u - sk * Tt;
+    } else {
+      t = work_tile(gp, pos, sk);
+    }
+    const Problem& p = locate_in_problem(gp, t, it.tm, it.tn);
     const int S = is_split_work(gp, pos) ? gp.split_k : 1;
     const int nk_all = p.nk, per = (nk_all + S - 1) / S;
     const int kt0 = sk * per, kt1 = max(kt0, min(nk_all, kt0 + per));
@@ -304,6 +314,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   } else {
     pos = blockIdx.x;
     end = total_work(gp);
+    if (gp.tail_first >= 0) {   // balanced tail: this workgroup's share of the tail units (none if its first tile is a long one)
+      const int e = xcd_chunk((int)blockIdx.x, gp.full_tiles) - gp.tail_first, E = gp.tail_G - gp.tail_first;
+      const int left = (gp.total_tiles - gp.full_tiles) * gp.split_k - e;
+      end = gp.full_tiles + (e < 0 || left <= 0 ? 0 : (left + E - 1) / E) * gp.tail_G;
+    }
   }
 
   // ---- DMA cursor: (item, half) the next issued half belongs to --------------------------------------------

@@ -349,6 +349,23 @@ def test_gemm_stream_k_grouped_wgrad(ops):
         assert rel(o, r) < 1e-5
 
 
+def test_gemm_block_wgrads_balanced_tail(ops):
+    """All eight weight gradients of one MMDiT-B block at batch 64 (image K = 16384, text K = 9856; 288 tiles of 256x256 on 256
+    workgroups): one full round plus a split tail that goes to the workgroups holding the short (text) tiles.  Given in
+    image/text-interleaved order (the library sorts by K); every product vs an fp32 reference of the same bf16 operands."""
+    Mx, Mc, d, h = 16384, 9856, 768, 3072
+    probs, refs = [], []
+    for i, (N, K) in enumerate([(3 * d, d), (d, d), (2 * h, d), (d, h)]):
+        for Mr in (Mx, Mc):
+            dY, X = rnd(Mr, N, seed=60 + 2 * i + (Mr == Mc), dtype=torch.bfloat16), rnd(Mr, K, seed=80 + 2 * i + (Mr == Mc), dtype=torch.bfloat16)
+            probs.append(dict(A=dY, B=X, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
+            refs.append(dY.float().T @ X.float())
+    for _ in range(2):   # twice: the partial tiles are added atomically into freshly zeroed outputs each time
+        outs = ops.gemm_grouped(probs)
+        for o, r in zip(outs, refs):
+            assert rel(o, r) < 5e-5
+
+
 @pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16)])
 def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
     """fp8 (e4m3, per-tensor scale) operand GEMM of the inference path vs the same quantised values multiplied in fp32."""
