@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--torch-optimizer", action="store_true", help="development A/B: torch's multi-tensor unscale/clip/AdamW kernels instead of the three HIP launches")
     ap.add_argument("--force-dist", action="store_true", help="development: run the N>1 code path (RCCL group + gradient reducer) with one rank")
     args = ap.parse_args()
 
@@ -112,7 +113,7 @@ def main():
     trainer = model_trainer(net, batchSize=args.batch, accumulation_steps=1, totalSteps=10 ** 9, lr=1e-4, ema_update_freq=10 ** 9, ema_decay=0.999,
                             warmup_steps=1000, use_lr_scheduler=False, device=dev, saveDir="/tmp/bench_ckpt", numSaveSteps=10 ** 9,
                             null_prob_pooled=0.1, null_prob_gemma=0.316, null_prob_bert=0.316, use_amp=True, max_res=256,
-                            device_rng=True, use_ema=False, force_reducer=args.force_dist)
+                            device_rng=True, use_ema=False, force_reducer=args.force_dist, hip_optimizer=not args.torch_optimizer)
     net.train()
 
     def sync():
@@ -179,7 +180,10 @@ def main():
                "config": {"workload": "MMDiT-B (12 blocks, d=768, 12 heads, SwiGLU 4x, RoPE2d) 256^2 images -> 32x32x16 latents, synthetic "
                                       "Gemma-2-2b-shaped text embeds (154x2304) + pooled (768); fwd+bwd+grad-allreduce+clip+AdamW (fp32 master weights)",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-               "mfma_roofline_frac_step": round(value * TRAIN_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16), 4), "final_loss": round(loss_val, 5)}
+               "mfma_roofline_frac_step": round(value * TRAIN_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16), 4), "final_loss": round(loss_val, 5),
+               "optimizer": "hip (unscale+clip+AdamW, 3 launches)" if trainer.hip_optimizer else "torch (multi-tensor)"}
+        if trainer.hip_optimizer:
+            out["optimizer_table_builds"] = trainer.optim.table_builds
         if roofline is not None:
             out["roofline"] = roofline
         if world == 1 and not args.no_cpu_baseline:

@@ -247,6 +247,34 @@ int mmdit_vae_pad_cast(const void* x, int x_dtype, int batch, int H, int W, int 
  * (single-head mid-block attention, attention_processor.py). */
 int mmdit_vae_softmax_rows(const float* x, int rows, int cols, int ld, float scale, void* y_bf16, mmdit_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Optimizer step: GradScaler.unscale_ + torch.nn.utils.clip_grad_norm_ + AdamW.step of the reference
+ * trainer (model_trainer.py:260-269 builds AdamW(lr, eps=1e-8, weight_decay=0.01, betas=(0.9, 0.999)); 463-503 runs
+ * unscale_ / clip / step / update) as three launches over the whole parameter list.  All tensors fp32.
+ * The parameter list is a DEVICE array of mmdit_adamw_tensor and a DEVICE chunk map: chunk c covers elements
+ * [chunk_off[c], min(numel, chunk_off[c] + MMDIT_ADAMW_CHUNK)) of tensor chunk_tensor[c] (one workgroup per chunk).
+ * ------------------------------------------------------------------------- */
+#define MMDIT_ADAMW_CHUNK 65536
+typedef struct mmdit_adamw_tensor {
+  float* param;
+  const float* grad;      /* as produced by backward: still multiplied by the loss scale */
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t numel;
+} mmdit_adamw_tensor;
+/* partials[c] = sum of grad^2 over chunk c (no atomics: deterministic). */
+int mmdit_grad_sumsq(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, float* partials, mmdit_stream_t stream);
+/* out3[0] = gradient multiplier (1/loss_scale) * min(1, max_norm / (norm + 1e-6)), norm = sqrt(sum partials) / loss_scale
+ * (max_norm <= 0: no clipping); out3[1] = found_inf (1.0 if the norm is not finite, else 0.0); out3[2] = norm.
+ * loss_scale: device scalar of the GradScaler, or NULL for 1. */
+int mmdit_clip_coef(const float* partials, int n_chunks, const float* loss_scale, float max_norm, float* out3, mmdit_stream_t stream);
+/* AdamW update of every chunk with grad * coef_found[0] (coef_found = out3 above, or NULL for multiplier 1); the step is
+ * skipped entirely when coef_found[1] != 0.  step_count: device scalar holding the number of steps taken so far (the
+ * caller adds 1 - found_inf afterwards, as torch's fused AdamW does with its per-parameter `step` tensors):
+ *   p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step_count+1. */
+int mmdit_adamw_step(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, const float* coef_found,
+                     const float* step_count, double lr, double beta1, double beta2, double eps, double weight_decay, mmdit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ ACT_NONE, ACT_SILU = 0, 1
 PREC_BF16, PREC_SPLIT = 0, 1
 FP8 = 2   # dtype code of OCP e4m3 GEMM operands (stored in torch.uint8 / float8_e4m3fn tensors)
 
-_vp, _i, _i64, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+_vp, _i, _i64, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 
 class GemmArgs(ctypes.Structure):
@@ -75,7 +75,11 @@ _SIGNATURES = {
     "mmdit_unpatchify": ([_vp, _i, _i, _i, _i, _i, _vp, _i, _vp], _i),
     "mmdit_time_embed_fwd": ([_vp, _vp, _vp, _i, _i, _vp, _i, _vp], _i),
     "mmdit_time_embed_bwd": ([_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _vp], _i),
+    "mmdit_grad_sumsq": ([_vp, _vp, _vp, _i, _vp, _vp], _i),
+    "mmdit_clip_coef": ([_vp, _i, _vp, _f, _vp, _vp], _i),
+    "mmdit_adamw_step": ([_vp, _vp, _vp, _i, _vp, _vp, _d, _d, _d, _d, _d, _vp], _i),
 }
+ADAMW_CHUNK = 65536   # MMDIT_ADAMW_CHUNK
 
 _lib = None
 

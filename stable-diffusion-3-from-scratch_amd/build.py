@@ -8,7 +8,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdit_hip.so")
-SOURCES = ["gemm.hip", "gemm_dma.hip", "rowops.hip", "attention.hip", "vae.hip"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "rowops.hip", "attention.hip", "vae.hip", "optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=5) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(cc, SOURCES))
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:

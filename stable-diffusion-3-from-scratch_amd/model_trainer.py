@@ -12,7 +12,9 @@ MI355X-native differences: one process per GPU, every rank is a model rank (no l
 from `data_source`, synthetic by default); gradient averaging is sd3_amd.reducer.GradReducer (bucketed
 RCCL all-reduce on a side HIP stream, fired block by block from the backward schedule, skipped on
 non-final accumulation micro-steps) instead of DistributedDataParallel; no wandb (stdout / JSONL log).
-The loss, AdamW and the scheduler stay in PyTorch-ROCm as BASELINE.json's north_star prescribes.
+The loss, the AdamW object (state, param groups, checkpoint format) and the scheduler stay in PyTorch-ROCm as
+BASELINE.json's north_star prescribes; with hip_optimizer=True (default on a GPU) the arithmetic of unscale + clip + AdamW
+runs as three HIP launches (optim.ClipAdamW), hip_optimizer=False runs torch's own kernels.
 """
 import copy
 import json
@@ -26,6 +28,7 @@ from torch import nn
 
 from .helpers.multi_gpu_helpers import is_main_process
 from .helpers.TimeSampler import TimeSampler
+from .optim import ClipAdamW
 from .reducer import GradReducer, broadcast_parameters
 
 
@@ -86,7 +89,7 @@ class model_trainer:
                  wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
                  data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False,
-                 fused_unscale_clip=True, ema_on_gpu=True):
+                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
@@ -123,7 +126,11 @@ class model_trainer:
 
         self.fused_unscale_clip = bool(fused_unscale_clip)
         fused = bool(fused_optimizer and self.device.type == "cuda")
-        self.optim = torch.optim.AdamW(self.model.parameters(), lr=lr, eps=1e-8, weight_decay=0.01, betas=(0.9, 0.999), fused=fused)
+        # hip_optimizer: unscale + clip + AdamW as three HIP launches (optim.ClipAdamW) -- the same torch.optim.AdamW
+        # object otherwise (state, param_groups, checkpoints, scheduler); False keeps torch's own multi-tensor kernels.
+        self.hip_optimizer = bool(hip_optimizer and self.device.type == "cuda")
+        opt_cls = ClipAdamW if self.hip_optimizer else torch.optim.AdamW
+        self.optim = opt_cls(self.model.parameters(), lr=lr, eps=1e-8, weight_decay=0.01, betas=(0.9, 0.999), fused=fused)
         self.scheduler = get_scheduler(self.optim, num_warmup_steps=warmup_steps, num_training_steps=totalSteps, use_lr_scheduler=use_lr_scheduler)
         self.grad_scaler = torch.amp.GradScaler("cuda", enabled=self.device.type == "cuda") if self.use_amp else None
 
@@ -151,6 +158,7 @@ class model_trainer:
                                                         seed=1234 + self.rank)
         self._gen = torch.Generator(device=self.device).manual_seed(4321 + self.rank) if device_rng else None
         self.last_loss = None
+        self.last_grad_norm = None   # hip_optimizer: device scalar, the unscaled gradient norm of the last step
         if is_main_process():
             total_params = sum(p.numel() for p in self.model.parameters()) / 1e6
             print(f"Number of parameters in the model: {total_params:.2f}M")
@@ -210,7 +218,28 @@ class model_trainer:
         st["found_inf_per_device"] = {total.device: (~torch.isfinite(total)).to(torch.float32)}
         st["stage"] = OptState.UNSCALED
 
+    def _hip_optimizer_step(self):
+        """unscale_ + clip_grad_norm_(1.0, only under AMP as in the reference) + AdamW in ClipAdamW.step_clipped, with the
+        GradScaler bookkeeping that unscale_() / step() would have done so that update() adjusts the loss scale as usual."""
+        sc = self.grad_scaler
+        scaled = sc is not None and sc.is_enabled()
+        found_inf, self.last_grad_norm = self.optim.step_clipped(sc._scale if scaled else None, 1.0 if self.use_amp else None)
+        if scaled:
+            from torch.amp.grad_scaler import OptState
+            st = sc._per_optimizer_states[id(self.optim)]
+            if st["stage"] is not OptState.READY:
+                raise RuntimeError("the optimizer was already unscaled / stepped since the last GradScaler.update()")
+            st["found_inf_per_device"] = {found_inf.device: found_inf}
+            st["stage"] = OptState.STEPPED
+
     def optimizer_step(self, step):
+        if self.hip_optimizer:
+            self._hip_optimizer_step()
+            self.scheduler.step(step)
+            if self.grad_scaler is not None:
+                self.grad_scaler.update()
+            self.optim.zero_grad()
+            return
         if self.grad_scaler is not None and self.use_amp and self.grad_scaler.is_enabled() and self.fused_unscale_clip:
             self._unscale_and_clip(1.0)
         else:

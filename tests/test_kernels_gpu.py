@@ -402,3 +402,70 @@ def test_fp8_delayed_scaling_site(ops):
     assert torch.isfinite(d2).all() and float(d2.abs().max()) <= 1.5 * float(x1.float().abs().max()) * (1 + 1e-6)
     q3, s3 = site.quantise(x0)                       # the ring has moved on to amax(x2)
     assert abs(float(s3) - 1.5 * float(x2.float().abs().max()) / 448.0) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ optimizer
+def test_clip_adamw_matches_torch_sequence(ops):
+    """ClipAdamW.step_clipped (three HIP launches) vs the reference's sequence on the same scaled gradients: unscale (divide
+    by the power-of-two loss scale), torch.nn.utils.clip_grad_norm_(1.0), torch.optim.AdamW(fused).step(), skipped when a
+    gradient is inf.  Two param groups (different lr / weight decay), ragged and unaligned sizes, lr changing per step.
+    Tolerance 2e-6 relative on parameters and moments after 5 steps; step counters and found_inf exact."""
+    from sd3_amd.optim import ClipAdamW
+    shapes = [(1,), (7,), (768, 768), (65536 + 3,), (200001,), (3, 65536), (64, 768)]
+    base = [rnd(*s, seed=100 + i) for i, s in enumerate(shapes)]
+    # views at odd element offsets of one arena: the gradients of the engine are such views (no 16-byte alignment guaranteed)
+    arena = torch.zeros(sum(b.numel() for b in base) + 1, device="cuda")
+
+    def make(cls):
+        ps = [torch.nn.Parameter(b.clone()) for b in base]
+        return ps, cls([dict(params=ps[:4], weight_decay=0.01), dict(params=ps[4:], weight_decay=0.1, lr=3e-4)], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, fused=True)
+
+    pa, oa = make(ClipAdamW)
+    pb, ob = make(torch.optim.AdamW)
+    scale = torch.tensor(1024.0, device="cuda")
+    for step, (mag, poison) in enumerate([(1e-3, False), (2.0, False), (1.0, True), (0.5, False), (1e-2, False)]):
+        for grp_a, grp_b in zip(oa.param_groups, ob.param_groups):
+            grp_a["lr"] = grp_b["lr"] = grp_b["lr"] * 0.9
+        off = 1
+        for i, (qa, qb) in enumerate(zip(pa, pb)):
+            g = rnd(*qa.shape, seed=1000 + 10 * step + i) * mag * 1024.0
+            if poison and i == 2:
+                g.view(-1)[5] = float("inf")
+            qa.grad = arena[off:off + g.numel()].view(g.shape)
+            qa.grad.copy_(g)
+            off += g.numel()
+            qb.grad = g / 1024.0
+        found_inf, norm = oa.step_clipped(scale, 1.0)
+        total = torch.nn.utils.clip_grad_norm_(pb, 1.0)
+        if bool(torch.isfinite(total)):
+            ob.step()
+        assert float(found_inf) == (1.0 if poison else 0.0)
+        if not poison:
+            assert abs(float(norm) - float(total)) < 1e-5 * float(total)
+        for qa, qb in zip(pa, pb):
+            sa, sb = oa.state[qa], ob.state[qb]
+            assert float(sa["step"]) == float(sb["step"]) if len(sb) else float(sa["step"]) == 0.0
+    for qa, qb in zip(pa, pb):
+        assert rel(qa, qb) < 2e-6
+        assert rel(oa.state[qa]["exp_avg"], ob.state[qb]["exp_avg"]) < 2e-6
+        assert rel(oa.state[qa]["exp_avg_sq"], ob.state[qb]["exp_avg_sq"]) < 2e-6
+    assert float(oa.state[pa[0]]["step"]) == 4.0
+    # interchangeable state: torch's state_dict loads into ClipAdamW and the next step agrees again
+    pc, oc = make(ClipAdamW)
+    with torch.no_grad():
+        for qc, qb in zip(pc, pb):
+            qc.copy_(qb)
+    import copy
+    oc.load_state_dict(copy.deepcopy(ob.state_dict()))   # (load_state_dict keeps same-dtype/device tensors by reference)
+    assert set(oa.state_dict()["state"][0].keys()) == set(ob.state_dict()["state"][0].keys())
+    for i, (qc, qb) in enumerate(zip(pc, pb)):
+        qb.grad = rnd(*qb.shape, seed=5000 + i) * 0.1
+        qc.grad = qb.grad.clone()
+    oc.step_clipped(None, None)      # no loss scale, no clipping: plain AdamW
+    ob.step()
+    for qc, qb in zip(pc, pb):
+        assert rel(qc, qb) < 2e-6
+        assert float(oc.state[qc]["step"]) == float(ob.state[qb]["step"]) == 5.0
+    # the step counters are views of one flat tensor and survive a state_dict round trip
+    sd = copy.deepcopy(oc.state_dict())
+    assert all(float(s["step"]) == 5.0 and s["step"].dim() == 0 for s in sd["state"].values())
