@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("MMDIT_LIB") or os.path.join(_HERE, "libmmdit_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "mmdit_hip.h")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_SWIGLU = 0, 1, 2
 PREC_BF16, PREC_SPLIT = 0, 1
 FP8 = 2   # dtype code of OCP e4m3 GEMM operands (stored in torch.uint8 / float8_e4m3fn tensors)
 

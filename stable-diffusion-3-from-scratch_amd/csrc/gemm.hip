@@ -238,7 +238,7 @@ int check_problem(const mmdit_gemm_args* a) {
   MMDIT_CHECK_ARG((a->lda * esa) % 16 == 0 && (a->ldb * esb) % 16 == 0 && a->ldc % 4 == 0);
   if (a->a_kmajor) { MMDIT_CHECK_ARG(a->M % 8 == 0 && a->lda >= a->M); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->lda >= a->K); }
   if (a->b_kmajor) { MMDIT_CHECK_ARG(a->N % 8 == 0 && a->ldb >= a->N); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->ldb >= a->K); }
-  MMDIT_CHECK_ARG(a->ldc >= a->N);
+  MMDIT_CHECK_ARG(a->ldc >= (a->act == MMDIT_ACT_SWIGLU ? a->N / 2 : a->N));
   if (a->bias) MMDIT_CHECK_ARG(aligned16(a->bias));
   if (a->gate) MMDIT_CHECK_ARG(a->residual && a->rows_per_batch > 0 && aligned16(a->gate) && a->ld_gate % 4 == 0);
   if (a->residual) MMDIT_CHECK_ARG(aligned16(a->residual) && a->ld_res % 4 == 0);
@@ -318,11 +318,23 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     }
   }
   if (conv) MMDIT_CHECK_ARG(dma);   // no register-staged fallback for the implicit-GEMM convolution
+  const bool swiglu = a0->act == MMDIT_ACT_SWIGLU;
+  if (swiglu) {
+    // C[M, N/2] = silu(g) * u with [g | u] = A B^T + bias the two halves of the N = 2h columns, aux[M, N] = [g | u]: DMA kernel only
+    if (!dma) return MMDIT_ERR_SHAPE;
+    for (int i = 0; i < count; i++) {
+      const mmdit_gemm_args* a = &args[i];
+      MMDIT_CHECK_ARG(!fp8 && !a->a_kmajor && !a->b_kmajor && a->c_dtype == MMDIT_BF16 && a->aux && a->aux_dtype == MMDIT_BF16 && !a->gate && !a->residual &&
+                      !a->accumulate && split_k == 1 && !a->stream_k && !a->conv_mode);
+      if (a->N % 256 != 0) return MMDIT_ERR_SHAPE;
+      MMDIT_CHECK_ARG(a->ldc >= a->N / 2 && a->ldc % 8 == 0 && a->ld_aux >= a->N && a->ld_aux % 8 == 0 && aligned16(a->C) && aligned16(a->aux));
+    }
+  }
   int bm = BM, bn = BN, cfg = CFG_128x128;
   // stream-K for the weight gradients (k-major A): fp32 C must be pre-zeroed by the caller (a0->stream_k)
   static const bool no_sk = getenv("MMDIT_GEMM_NO_STREAMK") != nullptr;
   const bool stream_k = dma && !no_sk && a0->stream_k && a0->c_dtype == MMDIT_F32 && split_k == 1 && a0->act == MMDIT_ACT_NONE && !a0->accumulate;
-  if (dma) { cfg = pick_dma_cfg(args, count, split_k, stream_k); dma_cfg_tile(cfg, bm, bn); }
+  if (dma) { cfg = swiglu ? CFG_256x256 : pick_dma_cfg(args, count, split_k, stream_k); dma_cfg_tile(cfg, bm, bn); }
   int tiles = 0, units = 0;
   // K-decomposed launches take the problems longest-K first: the tiles of the first round are then ordered long -> short and the
   // balanced tail below can hand the split leftovers to the workgroups that finish their first tile early

@@ -223,6 +223,87 @@ __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Probl
   }
 }
 
+// ---- SwiGLU-fused w12 GEMM (MMDIT_ACT_SWIGLU): B = packed [2h, K] weight (gate rows 0..h-1, up rows h..2h-1) -----------------
+// A 256-column tile covers hidden indices [128 tn, 128 tn + 128): tile-local B row r = 64 wn + 32 j + c is the gate (j = 0)
+// or up (j = 1) row of hidden index 128 tn + 32 wn + c, so every lane holds g and u of the same (row, hidden index) in
+// acc[i][0] / acc[i][1] and the activation is formed in registers.
+__device__ __forceinline__ uint32_t swiglu_voff(int c, int lane, int64_t ld, int tn, int h) {
+  const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);
+  const int row = ((r >> 5) & 1) * h + tn * 128 + (r >> 6) * 32 + (r & 31);
+  return (uint32_t)((int64_t)row * ld * 2 + piece * 16);
+}
+
+// Writes the bf16 pre-activations (+ bias) to aux[M, 2h] and h = silu(g) * u to C[M, h].  The activation is computed from the
+// ROUNDED pre-activations, i.e. bit-identical to mmdit_swiglu_fwd applied to aux.  Staging as in epilogue_bf16 (32 rows x
+// 128 B for g|u, then 32 rows x 64 B for the activation, wave-private).
+template <int MI>
+__device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage) {
+  bf16_t* Hout = (bf16_t*)p.C;
+  bf16_t* GU = (bf16_t*)p.aux;
+  const float* bias = p.bias;
+  const int h = p.N >> 1;
+  const int wr = lane & 31, wc = lane >> 5;
+  const int hc = tn * 128 + wn * 32;                 // first hidden index of this wave
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    u32x2 pa[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float vg[4] = {acc[i][0][g * 4], acc[i][0][g * 4 + 1], acc[i][0][g * 4 + 2], acc[i][0][g * 4 + 3]};
+      float vu[4] = {acc[i][1][g * 4], acc[i][1][g * 4 + 1], acc[i][1][g * 4 + 2], acc[i][1][g * 4 + 3]};
+      if (bias) {
+        const int c = hc + 8 * g + 4 * wc;
+        float b4[4];
+        ld4(bias + c, b4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) vg[e] += b4[e];
+        ld4(bias + h + c, b4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) vu[e] += b4[e];
+      }
+      const u32x2 pg = {pack_bf2(vg[0], vg[1]), pack_bf2(vg[2], vg[3])}, pu = {pack_bf2(vu[0], vu[1]), pack_bf2(vu[2], vu[3])};
+      *LDS_PTR(u32x2, stage + wr * 128 + ((g ^ (wr & 7)) << 4) + wc * 8) = pg;
+      *LDS_PTR(u32x2, stage + wr * 128 + (((4 + g) ^ (wr & 7)) << 4) + wc * 8) = pu;
+      float a[4];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const float g0 = __builtin_bit_cast(float, pg[e] << 16), g1 = __builtin_bit_cast(float, pg[e] & 0xffff0000u);
+        const float u0 = __builtin_bit_cast(float, pu[e] << 16), u1 = __builtin_bit_cast(float, pu[e] & 0xffff0000u);
+        a[2 * e] = silu_f(g0) * u0;
+        a[2 * e + 1] = silu_f(g1) * u1;
+      }
+      pa[g] = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+    {
+      const int rr = lane >> 3, rc = lane & 7;
+      const int col = (rc & 4 ? h : 0) + hc + (rc & 3) * 8;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = m0 + wm * (MI * 32) + i * 32 + r;
+        if (row < p.M) *(u32x4*)(GU + (int64_t)row * p.ld_aux + col) = t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; g++) *LDS_PTR(u32x2, stage + wr * 64 + ((g ^ (wr & 3)) << 4) + wc * 8) = pa[g];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int rr = lane >> 2, rc = lane & 3;
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const int r = it * 16 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 64 + ((rc ^ (r & 3)) << 4));
+        const int row = m0 + wm * (MI * 32) + i * 32 + r;
+        if (row < p.M) *(u32x4*)(Hout + (int64_t)row * p.ldc + hc + rc * 8) = t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+}
+
 // one unit of work of a workgroup: K halves [h0, h1) of output tile (tm, tn) of problem p
 struct Item {
   int pi;   // problem index (kept as an index so that every access stays a scalar kernarg load)
@@ -285,12 +366,13 @@ __device__ __forceinline__ int next_pos(const GroupParams& gp, const Item& it) {
   return gp.stream_k ? it.pos + (it.h1 - it.h0) / 2 : it.pos + (int)gridDim.x;
 }
 
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false>
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false, bool SWIGLU = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) {
   // FP8: e4m3 operands (row-major only).  A ring slot still holds 64 B per row = 64 fp8 values, so the whole DMA / ring /
   // barrier machinery is byte-identical; a half is four 16-wide k-steps of v_mfma_f32_32x32x16_fp8_fp8 instead of two bf16
   // ones (same MFMA rate, half the operand bytes per FLOP -- this kernel is operand-traffic-bound).
   static_assert(!FP8 || (!A_KM && !B_KM), "fp8 operands are row-major");
+  static_assert(!SWIGLU || (!A_KM && !B_KM && !FP8 && WN == 4 && NJ == 2 && sizeof(TC) == 2 && sizeof(TAUX) == 2), "SwiGLU epilogue: bf16, row-major, 256-column tile");
   constexpr int ESZ = FP8 ? 1 : 2, KSTEPS = FP8 ? 4 : 2;
   using frag_t = typename std::conditional<FP8, long, bf16x8>::type;
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
@@ -341,7 +423,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       for (int i = 0; i < PA; i++) va[i] = piece_voff<A_KM, TBM, ESZ>(wave * PA + i, lane, q.lda, cit.tm * TBM, q.M);
     }
 #pragma unroll
-    for (int i = 0; i < PB; i++) vb[i] = piece_voff<B_KM, TBN, ESZ>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
+    for (int i = 0; i < PB; i++) {
+      if constexpr (SWIGLU) vb[i] = swiglu_voff(wave * PB + i, lane, q.ldb, cit.tn, q.N >> 1);
+      else vb[i] = piece_voff<B_KM, TBN, ESZ>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
+    }
     stepa = A_KM ? (int64_t)BKH * q.lda * 2 : BKH * 2;
     stepb = B_KM ? (int64_t)BKH * q.ldb * 2 : BKH * 2;
     sa = (const char*)q.A + ch * stepa;
@@ -402,6 +487,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       const Problem& q = gp.p[it.pi];
       float alpha = 1.f;
       if constexpr (FP8) alpha = q.scale_a[0] * q.scale_b[0];
+      if constexpr (SWIGLU) {
+        epilogue_swiglu<MI>(acc, q, it.tm * TBM, it.tn, wm, wn, lane, stage);
+        return;
+      }
       bool fast = false;
       if constexpr (sizeof(TC) == 2 && NJ == 2)
         fast = !q.aux && !q.residual && !q.gate && !gp.accumulate && !it.atomic && (q.N & 7) == 0 && (q.ldc & 7) == 0 && ((uintptr_t)q.C & 15) == 0 && !(gp.debug & 64);
@@ -528,11 +617,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   if (pending) run_epilogue(prev);
 }
 
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false>
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false, bool SWIGLU = false>
 int launch_cfg(const GroupParams& gp, hipStream_t s) {
   constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64;
   constexpr int smem = RING * slot + (WM * WN * EP32_WAVE_BYTES <= slot ? 0 : WM * WN * EP32_WAVE_BYTES);
-  auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX, FP8>;
+  auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX, FP8, SWIGLU>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -566,6 +655,10 @@ int by_layout(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t 
 }  // namespace
 
 int gemm::launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s) {
+  if (gp.act == MMDIT_ACT_SWIGLU) {   // packed w12 GEMM with the activation in the epilogue (gemm.hip has checked the rest)
+    if (a_km || b_km || fp8 || c_dtype != MMDIT_BF16 || aux_dtype != MMDIT_BF16 || cfg != CFG_256x256) return MMDIT_ERR_DTYPE;
+    return launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, false, true>(gp, s);
+  }
   if (fp8) {   // e4m3 operands: row-major x row-major, bf16 or fp32 output (aux, if any, in the output dtype)
     if (a_km || b_km || aux_dtype != c_dtype || cfg == CFG_256x128) return MMDIT_ERR_DTYPE;
     if (c_dtype == MMDIT_BF16) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, bf16_t, bf16_t, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, true>(gp, s);

@@ -113,6 +113,7 @@ def _dgrad(m, dY, W, out_dtype, **kw):
 import os as _os
 _WG_MODE = _os.environ.get("MMDIT_WGRAD_MODE", "streamk")
 _WG_OVERLAP = _os.environ.get("MMDIT_WGRAD_STREAM", "1") != "0"
+_FUSE_SWIGLU = _os.environ.get("MMDIT_FUSE_SWIGLU", "1") != "0"   # SwiGLU activation in the up-projection GEMM's epilogue (A/B switch)
 _wg_streams = {}
 
 
@@ -265,18 +266,34 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
     sv.X1, sv.C1 = X1, C1
 
     sv.ln2x, sv.mu2x, sv.rs2x = ops.ln_modulate_fwd(X1, ms.scale2x, ms.shift2x, N, m.T)
-    probs = [dict(A=sv.ln2x, B=w.mlp_x.Wup, bias=w.mlp_x.bup, out_dtype=m.T)]
+    # SwiGLU in the up-projection's epilogue (bf16 mode, hidden % 128 == 0, K % 64 == 0): the GEMM writes the pre-activations and
+    # the activation; otherwise (GELU, parity / fp8 mode, odd sizes) the activation is a row kernel over the GEMM output
+    fuse = _FUSE_SWIGLU and m.fast and not m.fp8 and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % 64 == 0
+
+    def up(xn, mw, rows):
+        if fuse:
+            return dict(A=xn, B=mw.Wup, bias=mw.bup, act=ops.ACT_SWIGLU, aux=torch.empty((rows, 2 * mw.hidden), dtype=m.T, device=dev))
+        return dict(A=xn, B=mw.Wup, bias=mw.bup, out_dtype=m.T)
+
+    probs = [up(sv.ln2x, w.mlp_x, B * N)]
     if both:
         sv.ln2c, sv.mu2c, sv.rs2c = ops.ln_modulate_fwd(C1, ms.scale2c, ms.shift2c, Mt, m.T)
-        probs.append(dict(A=sv.ln2c, B=w.mlp_c.Wup, bias=w.mlp_c.bup, out_dtype=m.T))
-    outs = _group(m, probs, fp8=True)
-    sv.gu_x = outs[0]
-    sv.h_x = ops.mlp_act_fwd(sv.gu_x, w.mlp_x.hidden, w.mlp_x.gelu)
+        probs.append(up(sv.ln2c, w.mlp_c, B * Mt))
+    outs = _group(m, probs, fp8=not fuse)
+    pre = [p.get("aux") for p in probs]
+    if fuse:
+        sv.gu_x, sv.h_x = pre[0], outs[0]
+    else:
+        sv.gu_x = outs[0]
+        sv.h_x = ops.mlp_act_fwd(sv.gu_x, w.mlp_x.hidden, w.mlp_x.gelu)
     sv.acc_mx = torch.empty((B * N, d), dtype=m.T, device=dev)
     probs = [dict(A=sv.h_x, B=w.mlp_x.Wdown, bias=w.mlp_x.bdown, gate=ms.gate2x, rows_per_batch=N, residual=X1, aux=sv.acc_mx, out_dtype=F32)]
     if both:
-        sv.gu_c = outs[1]
-        sv.h_c = ops.mlp_act_fwd(sv.gu_c, w.mlp_c.hidden, w.mlp_c.gelu)
+        if fuse:
+            sv.gu_c, sv.h_c = pre[1], outs[1]
+        else:
+            sv.gu_c = outs[1]
+            sv.h_c = ops.mlp_act_fwd(sv.gu_c, w.mlp_c.hidden, w.mlp_c.gelu)
         sv.acc_mc = torch.empty((B * Mt, d), dtype=m.T, device=dev)
         probs.append(dict(A=sv.h_c, B=w.mlp_c.Wdown, bias=w.mlp_c.bdown, gate=ms.gate2c, rows_per_batch=Mt, residual=C1, aux=sv.acc_mc, out_dtype=F32))
     outs = _group(m, probs, fp8=True)

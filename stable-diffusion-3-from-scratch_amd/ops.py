@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SILU, BF16, F32, FP8, PREC_BF16, PREC_SPLIT, GemmArgs, check
+from ._lib import ACT_NONE, ACT_SILU, ACT_SWIGLU, BF16, F32, FP8, PREC_BF16, PREC_SPLIT, GemmArgs, check
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 
@@ -106,6 +106,11 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
         N, Kb = B.shape
     if K_ != Kb:
         raise RuntimeError(f"gemm: inner dimensions differ ({K_} vs {Kb})")
+    if act == ACT_SWIGLU:   # packed SwiGLU up-projection: out (M, h) = silu(g) * u, aux (M, 2h) = the pre-activations [g | u]
+        if aux is None or aux.dtype != torch.bfloat16 or tuple(aux.shape) != (M, N) or (out is not None and tuple(out.shape) != (M, N // 2)):
+            raise RuntimeError("gemm(act=ACT_SWIGLU): aux must be the bf16 (M, 2h) pre-activation buffer, out (M, h)")
+        if out is None:
+            out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=A.device)
     if out is None:
         if split_k > 1 or stream_k:
             out = zeros((M, N), A.device)   # slices accumulate atomically
@@ -147,7 +152,7 @@ def _variant(arr, n, outs):
     if plan == 64:
         ab = "t,t" if a.precision == PREC_BF16 else "f,f"
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
-    return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "")
+    return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "") + ("+swiglu" if a.act == ACT_SWIGLU else "")
 
 
 def gemm_grouped(problems):

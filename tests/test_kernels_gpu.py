@@ -349,6 +349,28 @@ def test_gemm_stream_k_grouped_wgrad(ops):
         assert rel(o, r) < 1e-5
 
 
+@pytest.mark.parametrize("M,h,K,bias", [(1000, 256, 128, True), (16384, 3072, 768, True), (300, 128, 64, False)])
+def test_gemm_swiglu_epilogue_equals_gemm_plus_row_kernel(ops, M, h, K, bias):
+    """act=ACT_SWIGLU (activation formed in the w12 GEMM's epilogue) must be BIT-identical to the plain bf16 GEMM followed by
+    mmdit_swiglu_fwd: same pre-activations [g | u], same h = silu(g) * u; and both agree with an fp32 torch reference of
+    F.linear + silu * (MLP.py:15-40) within bf16 rounding (4e-3).  Ragged M, grouped launch of two problems."""
+    probs, refs = [], []
+    for s in range(2):
+        Mr = M if s == 0 else M // 2 + 3
+        X, W = rnd(Mr, K, seed=70 + s, dtype=torch.bfloat16), rnd(2 * h, K, seed=72 + s, scale=0.05, dtype=torch.bfloat16)
+        b = rnd(2 * h, seed=74 + s) if bias else None
+        gu = ops.gemm(X, W, bias=b, out_dtype=torch.bfloat16)
+        refs.append((gu, ops.mlp_act_fwd(gu, h, False), X, W, b))
+        probs.append(dict(A=X, B=W, bias=b, act=ops.ACT_SWIGLU, aux=torch.empty((Mr, 2 * h), dtype=torch.bfloat16, device="cuda")))
+    outs = ops.gemm_grouped(probs)
+    for p, o, (gu, hh, X, W, b) in zip(probs, outs, refs):
+        assert o.shape == hh.shape and torch.equal(p["aux"], gu) and torch.equal(o, hh)
+        pre = X.float() @ W.float().T + (b if b is not None else 0.0)
+        assert rel(o, F.silu(pre[:, :h]) * pre[:, h:]) < 4e-3
+    with pytest.raises(RuntimeError):     # hidden not a multiple of 128: unsupported shape, the caller keeps the two-kernel path
+        ops.gemm(rnd(64, 64, dtype=torch.bfloat16), rnd(2 * 72, 64, dtype=torch.bfloat16), act=ops.ACT_SWIGLU, aux=torch.empty((64, 144), dtype=torch.bfloat16, device="cuda"))
+
+
 def test_gemm_block_wgrads_balanced_tail(ops):
     """All eight weight gradients of one MMDiT-B block at batch 64 (image K = 16384, text K = 9856; 288 tiles of 256x256 on 256
     workgroups): one full round plus a split tail that goes to the workgroups holding the short (text) tiles.  Given in

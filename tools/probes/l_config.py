@@ -9,7 +9,8 @@ dev = torch.device("cuda:0")
 net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu", device=dev,
                  positional_encoding="RoPE2d", dim=1024, num_heads=16, num_blocks=24)
 tr = model_trainer(net, batchSize=B, accumulation_steps=1, totalSteps=1000, lr=1e-4, ema_update_freq=10**9, ema_decay=0.999, warmup_steps=10,
-                   use_lr_scheduler=True, device=dev, saveDir="/tmp/_b", numSaveSteps=10**9, max_res=512, device_rng=True, use_ema=False)
+                   use_lr_scheduler=True, device=dev, saveDir="/tmp/_b", numSaveSteps=10**9, max_res=512, device_rng=True, use_ema=False,
+                   hip_optimizer=os.environ.get("HIPOPT", "1") != "0")
 losses = [float(tr.train_step(s)) for s in range(1, 4)]
 torch.cuda.synchronize()
 t0 = time.perf_counter()

@@ -15,10 +15,10 @@ def main():
     # step boundaries: first FusedOptimizer launch after a gap of non-optimizer kernels
     marks, in_opt = [], False
     for name, st, en in rows:
-        is_opt = "FusedOptimizer" in name
+        is_opt = "FusedOptimizer" in name or "adamw_kernel" in name
         if is_opt and not in_opt:
             marks.append(st)
-        if not is_opt and "multi_tensor_apply" not in name:
+        if not is_opt and "multi_tensor_apply" not in name and "grad_sumsq" not in name and "clip_coef" not in name:
             in_opt = False
         elif is_opt:
             in_opt = True
