@@ -40,8 +40,10 @@ def pmc_traffic(kernel):
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
-        if name in d:
-            return d[name]["hbm_bytes_per_launch"], d[name]["mfma_util"], os.path.relpath(f, ROOT)
+        # the profiler prints every template argument: <..., FP8, SWIGLU> follow the ones ops._variant names
+        for key in (name[:-1] + (",0,1>" if "+swiglu" in kernel else ",0,0>"), name):
+            if key in d:
+                return d[key]["hbm_bytes_per_launch"], d[key]["mfma_util"], os.path.relpath(f, ROOT)
     return None, None, None
 
 
