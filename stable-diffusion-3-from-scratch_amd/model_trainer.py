@@ -28,6 +28,7 @@ from torch import nn
 
 from .helpers.multi_gpu_helpers import is_main_process
 from .helpers.TimeSampler import TimeSampler
+from .helpers.checkpoint_stream import CheckpointStreamer
 from .optim import ClipAdamW
 from .reducer import GradReducer, broadcast_parameters
 
@@ -89,7 +90,7 @@ class model_trainer:
                  wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
                  data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False,
-                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True):
+                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
@@ -144,6 +145,8 @@ class model_trainer:
         if self.ema_model_cpu is not None and ema_on_gpu and self.device.type == "cuda":
             self._ema_gpu = [q.detach().to(self.device, copy=True) for q, p in zip(self.ema_model_cpu.parameters(), self.model.parameters())
                              if p.requires_grad]
+        # checkpoint streaming: device-side snapshot + background D2H and file writes instead of a blocking saveModel
+        self.ckpt_stream = CheckpointStreamer(self.device) if (async_checkpoint and self.device.type == "cuda") else None
         if optimFile and not reset_optim:
             self.optim.load_state_dict(torch.load(optimFile, map_location=self.device, weights_only=False))
         if schedulerFile:
@@ -288,6 +291,27 @@ class model_trainer:
             torch.cuda.synchronize(self.device)
         return self.ema_model_cpu
 
+    def ema_state_dict(self):
+        """state_dict of the EMA model with the GPU-resident averages as DEVICE tensors (no host copy, no synchronisation):
+        what the checkpoint streamer snapshots.  Without a GPU-resident average this is ema_model_cpu.state_dict()."""
+        sd = self.ema_model_cpu.state_dict()
+        if self._ema_gpu is not None:
+            names = [n for n, p in self.model.named_parameters() if p.requires_grad]
+            for n, e in zip(names, self._ema_gpu):
+                sd[n] = e
+        return sd
+
+    def save_checkpoint(self, n):
+        """The reference's six files for optimizer step n (model_trainer.py:545-548); streamed in the background when
+        async_checkpoint is on (call self.ckpt_stream.wait() before reading them back)."""
+        self.model.wandb_id = self.wandb_id
+        if self.ckpt_stream is not None:
+            ema = self.ema_state_dict() if self.ema_model_cpu is not None else None
+        else:
+            ema = self.sync_ema_to_cpu().state_dict() if self.ema_model_cpu is not None else None
+        self.model.saveModel(saveDir=self.saveDir, EMA_state_dict=ema, optimizer=self.optim, scheduler=self.scheduler, grad_scalar=self.grad_scaler,
+                             step=n, streamer=self.ckpt_stream)
+
     def train(self):
         if dist.is_initialized():
             dist.barrier()
@@ -309,7 +333,7 @@ class model_trainer:
             if self.ema_model_cpu is not None and n % self.ema_update_freq == 0:
                 self.update_ema()
             if n % self.numSaveSteps == 0 and is_main_process():
-                self.model.wandb_id = self.wandb_id
-                self.model.saveModel(saveDir=self.saveDir, EMA_state_dict=self.sync_ema_to_cpu().state_dict() if self.ema_model_cpu is not None else None,
-                                     optimizer=self.optim, scheduler=self.scheduler, grad_scalar=self.grad_scaler, step=n)
+                self.save_checkpoint(n)
                 print("Saving model")
+        if self.ckpt_stream is not None:
+            self.ckpt_stream.wait()

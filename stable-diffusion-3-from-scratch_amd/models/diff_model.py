@@ -283,8 +283,9 @@ class diff_model(nn.Module):
         return (output, imgs) if save_intermediate else output
 
     # ------------------------------------------------------------------------------------------
-    def saveModel(self, saveDir, EMA_state_dict=None, optimizer=None, scheduler=None, grad_scalar=None, step=None):
-        """Six-file checkpoint layout of the reference (diff_model.py:489-536)."""
+    def saveModel(self, saveDir, EMA_state_dict=None, optimizer=None, scheduler=None, grad_scalar=None, step=None, streamer=None):
+        """Six-file checkpoint layout of the reference (diff_model.py:489-536).  streamer (helpers.checkpoint_stream.CheckpointStreamer):
+        snapshot on the device and write the same files from a background thread instead of blocking the training loop."""
         names = {"model": "model", "ema": "model_ema", "optim": "optim", "sched": "scheduler", "scaler": "scaler", "defs": "model_params"}
         if step:
             names = {k: v + f"_{step}s" for k, v in names.items()}
@@ -292,6 +293,18 @@ class diff_model(nn.Module):
         self.defaults["wandb_id"] = self.wandb_id
         if not os.path.isdir(saveDir):
             os.makedirs(saveDir)
+        if streamer is not None:
+            files = [(self.state_dict(), saveDir + os.sep + names["model"] + ".pkl")]
+            if EMA_state_dict:
+                files.append((EMA_state_dict, saveDir + os.sep + names["ema"] + ".pkl"))
+            if optimizer:
+                files.append((optimizer.state_dict(), saveDir + os.sep + names["optim"] + ".pkl"))
+            if scheduler:
+                files.append((scheduler.state_dict(), saveDir + os.sep + names["sched"] + ".pkl"))
+            if grad_scalar:
+                files.append((grad_scalar.state_dict(), saveDir + os.sep + names["scaler"] + ".pkl"))
+            streamer.save(files, [(self.defaults, saveDir + os.sep + names["defs"] + ".json")])
+            return
         torch.save(self.state_dict(), saveDir + os.sep + names["model"] + ".pkl")
         if EMA_state_dict:
             torch.save(EMA_state_dict, saveDir + os.sep + names["ema"] + ".pkl")
