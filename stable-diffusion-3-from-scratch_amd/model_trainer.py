@@ -29,6 +29,7 @@ from torch import nn
 from .helpers.multi_gpu_helpers import is_main_process
 from .helpers.TimeSampler import TimeSampler
 from .helpers.checkpoint_stream import CheckpointStreamer
+from .helpers.wire_format import unpad_latents
 from .optim import ClipAdamW
 from .reducer import GradReducer, broadcast_parameters
 
@@ -90,7 +91,7 @@ class model_trainer:
                  wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
                  data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False,
-                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True):
+                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True, inf_padded_latents=False):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
@@ -160,6 +161,7 @@ class model_trainer:
         self.data_source = data_source or SyntheticData(batchSize, self.model.inCh, self.model.class_dim, (max_res // 8, max_res // 8), self.device,
                                                         seed=1234 + self.rank)
         self._gen = torch.Generator(device=self.device).manual_seed(4321 + self.rank) if device_rng else None
+        self.inf_padded_latents = bool(inf_padded_latents)
         self.last_loss = None
         self.last_grad_norm = None   # hip_optimizer: device scalar, the unscaled gradient norm of the last step
         if is_main_process():
@@ -183,6 +185,8 @@ class model_trainer:
         """One forward/backward micro-step; returns the (already /accumulation_steps) loss tensor."""
         with torch.no_grad():
             batch_x_0, batch_txt, batch_txt_pooled = self.data_source()
+            if self.inf_padded_latents:      # latents arrive in the reference's +inf-padded wire format (model_trainer.py:362-370)
+                batch_x_0 = unpad_latents(batch_x_0)
             t_vals, n_pooled, n_gemma, n_bert = self._sample_conditioning(batch_x_0.shape[0])
             batch_x_t, epsilon_t = self.model.noise_batch(batch_x_0, t_vals)
         # Hook path (post-accumulate hooks see the ACCUMULATED gradient): reduce on the final micro-step only (DDP no_sync).

@@ -1,4 +1,4 @@
-"""Checkpoint streaming (helpers/checkpoint_stream.py): same six files as the reference's saveModel
+"""Trainer I/O: checkpoint streaming (helpers/checkpoint_stream.py) -- same six files as the reference's saveModel
 (diff_model.py:489-536), written in the background from a snapshot taken at the call."""
 import json
 import os
@@ -80,3 +80,60 @@ def test_trainer_streams_checkpoint_while_training(tmp_path):
                       positional_encoding="RoPE2d", **CONFIGS["micro"])
     net2.loadModel(str(tmp_path), "model_2s.pkl", "model_params_2s.json")
     assert all(torch.equal(v, want_model[k]) for k, v in net2.state_dict().items())
+
+
+@pytest.mark.parametrize("h,w", [(32, 32), (24, 40), (16, 16), (40, 24)])
+def test_inf_padded_wire_format_roundtrip(h, w):
+    """pad_latents / unpad_latents are the reference's loader -> model rank format: +inf padding to (max_res/8)^2
+    (VAE_T5_CLIP.py:438) and the receiver's recovery, here checked against the reference's own expression
+    x[x != inf].reshape(B, C, H - #inf rows, W - #inf cols) (model_trainer.py:362-370)."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.helpers.wire_format import pad_latents, unpad_latents
+    g = torch.Generator().manual_seed(h * 100 + w)
+    x = torch.randn((3, 16, h, w), generator=g).to(torch.bfloat16)
+    p = pad_latents(x, 320)
+    assert p.shape == (3, 16, 40, 40) and (p[:, :, h:, :] == float("inf")).all() and (p[:, :, :, w:] == float("inf")).all()
+    orig_shape = (3, 16, p.shape[2] - (p[0, 0] == torch.inf).sum(-2)[0].item(), p.shape[3] - (p[0, 0] == torch.inf).sum(-1)[0].item())
+    ref = p[p != torch.inf].reshape(orig_shape)
+    got = unpad_latents(p)
+    assert got.shape == x.shape and torch.equal(got, ref) and torch.equal(got, x)
+    with pytest.raises(RuntimeError):
+        pad_latents(x, 8 * min(h, w) - 8)
+
+
+@pytest.mark.gpu
+def test_trainer_consumes_inf_padded_bucketed_batches():
+    """A data source in the reference's wire format -- aspect-ratio buckets that change from batch to batch, each padded with
+    +inf to (max_res/8)^2 -- drives the trainer (inf_padded_latents=True): the model sees the unpadded latent of every bucket
+    and the loss stays finite."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.helpers.wire_format import pad_latents
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu", device=dev,
+                     positional_encoding="RoPE2d", **CONFIGS["micro"])
+    net.load_state_dict(make_state_dict(0, **CONFIGS["micro"]))
+    buckets, g, calls = [(16, 16), (12, 20), (20, 12), (8, 16)], torch.Generator(device="cuda").manual_seed(3), []
+
+    def source():
+        h, w = buckets[len(calls) % len(buckets)]
+        calls.append((h, w))
+        x = torch.randn((4, 16, h, w), generator=g, device=dev).to(torch.bfloat16)
+        return (pad_latents(x, 160), torch.randn((4, 154, 2304), generator=g, device=dev).to(torch.bfloat16),
+                torch.randn((4, 768), generator=g, device=dev).to(torch.bfloat16))
+
+    tr = model_trainer(net, batchSize=4, accumulation_steps=1, totalSteps=10, lr=1e-3, ema_update_freq=1, ema_decay=0.9, warmup_steps=2,
+                       use_lr_scheduler=True, device=dev, saveDir="/tmp/_t", numSaveSteps=100, max_res=160, device_rng=True, use_ema=False,
+                       data_source=source, inf_padded_latents=True)
+    seen, fwd = [], net.forward
+
+    def spy(x_t, *a, **kw):
+        seen.append(tuple(x_t.shape[-2:]))
+        return fwd(x_t, *a, **kw)
+
+    net.forward = spy
+    losses = [float(tr.train_step(s)) for s in range(1, 6)]
+    assert seen == [buckets[i % 4] for i in range(5)]
+    assert all(l == l and abs(l) < 1e3 for l in losses)
