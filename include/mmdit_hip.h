@@ -36,9 +36,10 @@ extern "C" {
 #define MMDIT_ACT_NONE 0
 #define MMDIT_ACT_SILU 1
 #define MMDIT_ACT_SWIGLU 2      /* packed SwiGLU up-projection (MLP.py:15-40 / xformers SwiGLU w12): B = w12 [2h, K], N = 2h;
-                                 * aux[M, 2h] (bf16, required) = [g | u] = A B^T + bias, C[M, h] (bf16) = silu(g) * u computed from the
-                                 * bf16-rounded aux values (== mmdit_swiglu_fwd(aux)).  bf16 row-major operands, K % 64 == 0, h % 128 == 0
-                                 * (else MMDIT_ERR_SHAPE: run the GEMM and mmdit_swiglu_fwd separately); no gate / residual / split. */
+                                 * aux[M, 2h] (bf16, optional: training keeps it for backward) = [g | u] = A B^T + bias, C[M, h] (bf16) =
+                                 * silu(g) * u computed from the bf16-rounded [g | u] (== mmdit_swiglu_fwd of the plain GEMM's output).
+                                 * Row-major bf16 operands with K % 64 == 0 or e4m3 operands with K % 128 == 0, h % 128 == 0 (else
+                                 * MMDIT_ERR_SHAPE: run the GEMM and mmdit_swiglu_fwd separately); no gate / residual / split. */
 
 #define MMDIT_PREC_BF16 0       /* single-pass bf16 MFMA operands, fp32 accumulate */
 #define MMDIT_PREC_SPLIT 1      /* 3-term split-bf16, 6-pass MFMA: fp32-exact products (parity mode) */

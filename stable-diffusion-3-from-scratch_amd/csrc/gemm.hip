@@ -324,10 +324,11 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     if (!dma) return MMDIT_ERR_SHAPE;
     for (int i = 0; i < count; i++) {
       const mmdit_gemm_args* a = &args[i];
-      MMDIT_CHECK_ARG(!fp8 && !a->a_kmajor && !a->b_kmajor && a->c_dtype == MMDIT_BF16 && a->aux && a->aux_dtype == MMDIT_BF16 && !a->gate && !a->residual &&
+      MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && a->c_dtype == MMDIT_BF16 && (!a->aux || a->aux_dtype == MMDIT_BF16) && !a->gate && !a->residual &&
                       !a->accumulate && split_k == 1 && !a->stream_k && !a->conv_mode);
       if (a->N % 256 != 0) return MMDIT_ERR_SHAPE;
-      MMDIT_CHECK_ARG(a->ldc >= a->N / 2 && a->ldc % 8 == 0 && a->ld_aux >= a->N && a->ld_aux % 8 == 0 && aligned16(a->C) && aligned16(a->aux));
+      MMDIT_CHECK_ARG(a->ldc >= a->N / 2 && a->ldc % 8 == 0 && aligned16(a->C));
+      if (a->aux) MMDIT_CHECK_ARG(a->ld_aux >= a->N && a->ld_aux % 8 == 0 && aligned16(a->aux));
     }
   }
   int bm = BM, bn = BN, cfg = CFG_128x128;

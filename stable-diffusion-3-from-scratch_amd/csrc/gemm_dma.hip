@@ -227,17 +227,19 @@ __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Probl
 // A 256-column tile covers hidden indices [128 tn, 128 tn + 128): tile-local B row r = 64 wn + 32 j + c is the gate (j = 0)
 // or up (j = 1) row of hidden index 128 tn + 32 wn + c, so every lane holds g and u of the same (row, hidden index) in
 // acc[i][0] / acc[i][1] and the activation is formed in registers.
+template <int ESZ>
 __device__ __forceinline__ uint32_t swiglu_voff(int c, int lane, int64_t ld, int tn, int h) {
   const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);
   const int row = ((r >> 5) & 1) * h + tn * 128 + (r >> 6) * 32 + (r & 31);
-  return (uint32_t)((int64_t)row * ld * 2 + piece * 16);
+  return (uint32_t)((int64_t)row * ld * ESZ + piece * 16);
 }
 
-// Writes the bf16 pre-activations (+ bias) to aux[M, 2h] and h = silu(g) * u to C[M, h].  The activation is computed from the
+// Writes the bf16 pre-activations (+ bias) to aux[M, 2h] (if given: training keeps them for backward) and h = silu(g) * u to
+// C[M, h]; alpha = product of the fp8 operand scales (1 for bf16 operands).  The activation is computed from the
 // ROUNDED pre-activations, i.e. bit-identical to mmdit_swiglu_fwd applied to aux.  Staging as in epilogue_bf16 (32 rows x
 // 128 B for g|u, then 32 rows x 64 B for the activation, wave-private).
 template <int MI>
-__device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage) {
+__device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage, float alpha) {
   bf16_t* Hout = (bf16_t*)p.C;
   bf16_t* GU = (bf16_t*)p.aux;
   const float* bias = p.bias;
@@ -249,8 +251,8 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
     u32x2 pa[4];
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-      float vg[4] = {acc[i][0][g * 4], acc[i][0][g * 4 + 1], acc[i][0][g * 4 + 2], acc[i][0][g * 4 + 3]};
-      float vu[4] = {acc[i][1][g * 4], acc[i][1][g * 4 + 1], acc[i][1][g * 4 + 2], acc[i][1][g * 4 + 3]};
+      float vg[4] = {acc[i][0][g * 4] * alpha, acc[i][0][g * 4 + 1] * alpha, acc[i][0][g * 4 + 2] * alpha, acc[i][0][g * 4 + 3] * alpha};
+      float vu[4] = {acc[i][1][g * 4] * alpha, acc[i][1][g * 4 + 1] * alpha, acc[i][1][g * 4 + 2] * alpha, acc[i][1][g * 4 + 3] * alpha};
       if (bias) {
         const int c = hc + 8 * g + 4 * wc;
         float b4[4];
@@ -262,8 +264,10 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
         for (int e = 0; e < 4; e++) vu[e] += b4[e];
       }
       const u32x2 pg = {pack_bf2(vg[0], vg[1]), pack_bf2(vg[2], vg[3])}, pu = {pack_bf2(vu[0], vu[1]), pack_bf2(vu[2], vu[3])};
-      *LDS_PTR(u32x2, stage + wr * 128 + ((g ^ (wr & 7)) << 4) + wc * 8) = pg;
-      *LDS_PTR(u32x2, stage + wr * 128 + (((4 + g) ^ (wr & 7)) << 4) + wc * 8) = pu;
+      if (GU) {
+        *LDS_PTR(u32x2, stage + wr * 128 + ((g ^ (wr & 7)) << 4) + wc * 8) = pg;
+        *LDS_PTR(u32x2, stage + wr * 128 + (((4 + g) ^ (wr & 7)) << 4) + wc * 8) = pu;
+      }
       float a[4];
 #pragma unroll
       for (int e = 0; e < 2; e++) {
@@ -275,7 +279,7 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
       pa[g] = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
-    {
+    if (GU) {
       const int rr = lane >> 3, rc = lane & 7;
       const int col = (rc & 4 ? h : 0) + hc + (rc & 3) * 8;
 #pragma unroll
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   // barrier machinery is byte-identical; a half is four 16-wide k-steps of v_mfma_f32_32x32x16_fp8_fp8 instead of two bf16
   // ones (same MFMA rate, half the operand bytes per FLOP -- this kernel is operand-traffic-bound).
   static_assert(!FP8 || (!A_KM && !B_KM), "fp8 operands are row-major");
-  static_assert(!SWIGLU || (!A_KM && !B_KM && !FP8 && WN == 4 && NJ == 2 && sizeof(TC) == 2 && sizeof(TAUX) == 2), "SwiGLU epilogue: bf16, row-major, 256-column tile");
+  static_assert(!SWIGLU || (!A_KM && !B_KM && WN == 4 && NJ == 2 && sizeof(TC) == 2 && sizeof(TAUX) == 2), "SwiGLU epilogue: bf16, row-major, 256-column tile");
   constexpr int ESZ = FP8 ? 1 : 2, KSTEPS = FP8 ? 4 : 2;
   using frag_t = typename std::conditional<FP8, long, bf16x8>::type;
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     }
 #pragma unroll
     for (int i = 0; i < PB; i++) {
-      if constexpr (SWIGLU) vb[i] = swiglu_voff(wave * PB + i, lane, q.ldb, cit.tn, q.N >> 1);
+      if constexpr (SWIGLU) vb[i] = swiglu_voff<ESZ>(wave * PB + i, lane, q.ldb, cit.tn, q.N >> 1);
       else vb[i] = piece_voff<B_KM, TBN, ESZ>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
     }
     stepa = A_KM ? (int64_t)BKH * q.lda * 2 : BKH * 2;
@@ -488,7 +492,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       float alpha = 1.f;
       if constexpr (FP8) alpha = q.scale_a[0] * q.scale_b[0];
       if constexpr (SWIGLU) {
-        epilogue_swiglu<MI>(acc, q, it.tm * TBM, it.tn, wm, wn, lane, stage);
+        epilogue_swiglu<MI>(acc, q, it.tm * TBM, it.tn, wm, wn, lane, stage, alpha);
         return;
       }
       bool fast = false;
@@ -656,8 +660,8 @@ int by_layout(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t 
 
 int gemm::launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s) {
   if (gp.act == MMDIT_ACT_SWIGLU) {   // packed w12 GEMM with the activation in the epilogue (gemm.hip has checked the rest)
-    if (a_km || b_km || fp8 || c_dtype != MMDIT_BF16 || aux_dtype != MMDIT_BF16 || cfg != CFG_256x256) return MMDIT_ERR_DTYPE;
-    return launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, false, true>(gp, s);
+    if (a_km || b_km || c_dtype != MMDIT_BF16 || aux_dtype != MMDIT_BF16 || cfg != CFG_256x256) return MMDIT_ERR_DTYPE;
+    return fp8 ? launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, true, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, false, true>(gp, s);
   }
   if (fp8) {   // e4m3 operands: row-major x row-major, bf16 or fp32 output (aux, if any, in the output dtype)
     if (a_km || b_km || aux_dtype != c_dtype || cfg == CFG_256x128) return MMDIT_ERR_DTYPE;

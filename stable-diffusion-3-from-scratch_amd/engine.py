@@ -230,8 +230,9 @@ def cond_fwd_all(m, blocks, y):
     return [(pres[i], yps[i], mods[i]) for i in range(nb)], pre_all
 
 
-def block_fwd(m, w, X, C, y, dims, rope, cond=None):
+def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True):
     """X (B*N,d) fp32, C (B*M,d) fp32, y (B,d) in m.T.  cond: this block's (pre, yp, mod) from cond_fwd_all.
+    keep=False (inference): the backward-only GEMM side outputs (pre-gate accumulators, SwiGLU pre-activations) are not written.
     Returns X2, C2, saved."""
     B, N, Mt, H, d = dims
     S, dev = N + Mt, X.device
@@ -255,11 +256,11 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
     sv.Ox, sv.Oc, sv.lse = ops.attn_fwd(sv.Q, sv.K, sv.V, N, 64 ** -0.5, m.attn_mode)
 
     sv.Oxa = m.act(sv.Ox.view(B * N, d))
-    sv.acc_ox = torch.empty((B * N, d), dtype=m.T, device=dev)
+    sv.acc_ox = torch.empty((B * N, d), dtype=m.T, device=dev) if keep else None
     probs = [dict(A=sv.Oxa, B=w.Wo_x, gate=ms.gate1x, rows_per_batch=N, residual=X, aux=sv.acc_ox, out_dtype=F32)]
     if both:
         sv.Oca = m.act(sv.Oc.view(B * Mt, d))
-        sv.acc_oc = torch.empty((B * Mt, d), dtype=m.T, device=dev)
+        sv.acc_oc = torch.empty((B * Mt, d), dtype=m.T, device=dev) if keep else None
         probs.append(dict(A=sv.Oca, B=w.Wo_c, gate=ms.gate1c, rows_per_batch=Mt, residual=C, aux=sv.acc_oc, out_dtype=F32))
     outs = _group(m, probs, fp8=True)
     X1, C1 = outs[0], (outs[1] if both else C)
@@ -268,25 +269,25 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
     sv.ln2x, sv.mu2x, sv.rs2x = ops.ln_modulate_fwd(X1, ms.scale2x, ms.shift2x, N, m.T)
     # SwiGLU in the up-projection's epilogue (bf16 mode, hidden % 128 == 0, K % 64 == 0): the GEMM writes the pre-activations and
     # the activation; otherwise (GELU, parity / fp8 mode, odd sizes) the activation is a row kernel over the GEMM output
-    fuse = _FUSE_SWIGLU and m.fast and not m.fp8 and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % 64 == 0
+    fuse = _FUSE_SWIGLU and m.fast and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % (128 if m.fp8 else 64) == 0
 
     def up(xn, mw, rows):
         if fuse:
-            return dict(A=xn, B=mw.Wup, bias=mw.bup, act=ops.ACT_SWIGLU, aux=torch.empty((rows, 2 * mw.hidden), dtype=m.T, device=dev))
+            return dict(A=xn, B=mw.Wup, bias=mw.bup, act=ops.ACT_SWIGLU, aux=torch.empty((rows, 2 * mw.hidden), dtype=m.T, device=dev) if keep else None)
         return dict(A=xn, B=mw.Wup, bias=mw.bup, out_dtype=m.T)
 
     probs = [up(sv.ln2x, w.mlp_x, B * N)]
     if both:
         sv.ln2c, sv.mu2c, sv.rs2c = ops.ln_modulate_fwd(C1, ms.scale2c, ms.shift2c, Mt, m.T)
         probs.append(up(sv.ln2c, w.mlp_c, B * Mt))
-    outs = _group(m, probs, fp8=not fuse)
+    outs = _group(m, probs, fp8=True)
     pre = [p.get("aux") for p in probs]
     if fuse:
         sv.gu_x, sv.h_x = pre[0], outs[0]
     else:
         sv.gu_x = outs[0]
         sv.h_x = ops.mlp_act_fwd(sv.gu_x, w.mlp_x.hidden, w.mlp_x.gelu)
-    sv.acc_mx = torch.empty((B * N, d), dtype=m.T, device=dev)
+    sv.acc_mx = torch.empty((B * N, d), dtype=m.T, device=dev) if keep else None
     probs = [dict(A=sv.h_x, B=w.mlp_x.Wdown, bias=w.mlp_x.bdown, gate=ms.gate2x, rows_per_batch=N, residual=X1, aux=sv.acc_mx, out_dtype=F32)]
     if both:
         if fuse:
@@ -294,7 +295,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None):
         else:
             sv.gu_c = outs[1]
             sv.h_c = ops.mlp_act_fwd(sv.gu_c, w.mlp_c.hidden, w.mlp_c.gelu)
-        sv.acc_mc = torch.empty((B * Mt, d), dtype=m.T, device=dev)
+        sv.acc_mc = torch.empty((B * Mt, d), dtype=m.T, device=dev) if keep else None
         probs.append(dict(A=sv.h_c, B=w.mlp_c.Wdown, bias=w.mlp_c.bdown, gate=ms.gate2c, rows_per_batch=Mt, residual=C1, aux=sv.acc_mc, out_dtype=F32))
     outs = _group(m, probs, fp8=True)
     X2, C2 = outs[0], (outs[1] if both else C1)
@@ -394,7 +395,7 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
 # ----------------------------------------------------------------------------------------------
 # whole model
 # ----------------------------------------------------------------------------------------------
-def model_fwd(m, W, x_t, t, c, c_pooled, rope):
+def model_fwd(m, W, x_t, t, c, c_pooled, rope, keep=True):
     """W: packed weights (see models/diff_model.py).  x_t (B,Cin,H,W); t (B,) fp32;
     c (B,tokens,2304); c_pooled (B,class_dim).  Returns v (B,Cin,H,W) fp32 and the saved state."""
     B, Cin, Hh, Ww = x_t.shape
@@ -418,7 +419,7 @@ def model_fwd(m, W, x_t, t, c, c_pooled, rope):
     sv.blocks = []
     conds, sv.pre_all = cond_fwd_all(m, W.blocks, sv.y)
     for wb, cond in zip(W.blocks, conds):
-        X, C, bs = block_fwd(m, wb, X, C, sv.y, dims, rope, cond)
+        X, C, bs = block_fwd(m, wb, X, C, sv.y, dims, rope, cond, keep)
         sv.blocks.append(bs)
 
     sv.Xf = X

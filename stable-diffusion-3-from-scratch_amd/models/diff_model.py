@@ -30,7 +30,7 @@ class _MMDiTFn(torch.autograd.Function):
         m = net._mode()
         W = net.weights(m)
         rope = net.blocks[0].attn.rotary_emb.tables(x_t.shape[-2] // 2, x_t.shape[-1] // 2, x_t.device)
-        v, sv = engine.model_fwd(m, W, x_t, t, c, c_pooled, rope)
+        v, sv = engine.model_fwd(m, W, x_t, t, c, c_pooled, rope, keep=net._keep_saved)
         if any(ctx.needs_input_grad):
             ctx.net, ctx.m, ctx.sv, ctx.rope = net, m, sv, rope
         return v
@@ -127,6 +127,7 @@ class diff_model(nn.Module):
         # "fast" = bf16 MFMA operands (training default, = the reference's bf16 autocast);
         # "parity" = split-bf16 GEMMs + reference-rounding attention for the 1e-3 golden check.
         self.precision = "fast"
+        self._keep_saved = True
         self.grad_reducer = None   # set by model_trainer for data-parallel runs (sd3_amd.reducer.GradReducer)
         self._packs = NS(Wt=Pack([self.t_emb2.weight]), Wcond=Pack([self.cond_MLP.weight]), Wc1=Pack([self.c_proj.weight]),
                          Wc2=Pack([self.c_proj2.weight]), Wpatch=Pack([self.pos_enc.proj.weight]), Wpe=Pack([self.patch_emb.weight]),
@@ -229,6 +230,7 @@ class diff_model(nn.Module):
             c = c.float()
         if c_pooled.dtype not in (torch.float32, torch.bfloat16):
             c_pooled = c_pooled.float()
+        self._keep_saved = torch.is_grad_enabled()      # inference: the backward-only side outputs of the forward schedule are skipped
         return _MMDiTFn.apply(self, x_t.contiguous(), t.float().contiguous(), c.contiguous(), c_pooled.contiguous(), *self._param_list())
 
     # ------------------------------------------------------------------------------------------

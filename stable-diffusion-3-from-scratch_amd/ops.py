@@ -107,8 +107,8 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     if K_ != Kb:
         raise RuntimeError(f"gemm: inner dimensions differ ({K_} vs {Kb})")
     if act == ACT_SWIGLU:   # packed SwiGLU up-projection: out (M, h) = silu(g) * u, aux (M, 2h) = the pre-activations [g | u]
-        if aux is None or aux.dtype != torch.bfloat16 or tuple(aux.shape) != (M, N) or (out is not None and tuple(out.shape) != (M, N // 2)):
-            raise RuntimeError("gemm(act=ACT_SWIGLU): aux must be the bf16 (M, 2h) pre-activation buffer, out (M, h)")
+        if (aux is not None and (aux.dtype != torch.bfloat16 or tuple(aux.shape) != (M, N))) or (out is not None and tuple(out.shape) != (M, N // 2)):
+            raise RuntimeError("gemm(act=ACT_SWIGLU): aux (optional) is the bf16 (M, 2h) pre-activation buffer, out (M, h)")
         if out is None:
             out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=A.device)
     if out is None:

@@ -367,6 +367,16 @@ def test_gemm_swiglu_epilogue_equals_gemm_plus_row_kernel(ops, M, h, K, bias):
         assert o.shape == hh.shape and torch.equal(p["aux"], gu) and torch.equal(o, hh)
         pre = X.float() @ W.float().T + (b if b is not None else 0.0)
         assert rel(o, F.silu(pre[:, :h]) * pre[:, h:]) < 4e-3
+    # inference form: no pre-activation output, same activation
+    o2 = ops.gemm_grouped([dict(A=p["A"], B=p["B"], bias=p["bias"], act=ops.ACT_SWIGLU) for p in probs])
+    assert all(torch.equal(a, b) for a, b in zip(o2, outs))
+    if K % 128 == 0:   # e4m3 operands (fp8 inference mode): again bit-identical to the fp8 GEMM followed by the row kernel
+        for p in probs:
+            qa, sa = ops.quant_fp8(p["A"])
+            qw, sw = ops.quant_fp8(p["B"])
+            gu8 = ops.gemm(qa, qw, bias=p["bias"], out_dtype=torch.bfloat16, scale_a=sa, scale_b=sw)
+            h8 = ops.gemm(qa, qw, bias=p["bias"], act=ops.ACT_SWIGLU, scale_a=sa, scale_b=sw)
+            assert torch.equal(h8, ops.mlp_act_fwd(gu8, h, False))
     with pytest.raises(RuntimeError):     # hidden not a multiple of 128: unsupported shape, the caller keeps the two-kernel path
         ops.gemm(rnd(64, 64, dtype=torch.bfloat16), rnd(2 * 72, 64, dtype=torch.bfloat16), act=ops.ACT_SWIGLU, aux=torch.empty((64, 144), dtype=torch.bfloat16, device="cuda"))
 
