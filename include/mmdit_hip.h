@@ -280,6 +280,16 @@ int mmdit_clip_coef(const float* partials, int n_chunks, const float* loss_scale
 int mmdit_adamw_step(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, const float* coef_found,
                      const float* step_count, double lr, double beta1, double beta2, double eps, double weight_decay, mmdit_stream_t stream);
 
+/* fp32 master weights -> bf16 GEMM operand copies for a whole parameter list in one launch (the reference gets its bf16 copies
+ * from torch.autocast's weight cache, model_trainer.py:416).  Same chunk map as above: chunk c covers elements
+ * [chunk_off[c], +MMDIT_ADAMW_CHUNK) of tensors[chunk_tensor[c]]; tensors / maps are DEVICE arrays. */
+typedef struct mmdit_cast_tensor {
+  const float* src;
+  void* dst;              /* bf16 */
+  int64_t numel;
+} mmdit_cast_tensor;
+int mmdit_cast_multi(const mmdit_cast_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, mmdit_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

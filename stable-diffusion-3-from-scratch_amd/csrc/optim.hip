@@ -145,7 +145,34 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(const mmdit_adamw_tensor* __
   }
 }
 
+// fp32 master weights -> bf16 operand copies, every tensor of the model in one launch (same chunk map scheme)
+__global__ __launch_bounds__(TPB) void cast_multi_kernel(const mmdit_cast_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor,
+                                                          const int64_t* __restrict__ chunk_off) {
+  const int c = blockIdx.x;
+  const mmdit_cast_tensor t = tensors[chunk_tensor[c]];
+  const int64_t off = chunk_off[c];
+  const int n = (int)min((int64_t)CHUNK, t.numel - off);
+  const float* s = t.src + off;
+  bf16_t* d = (bf16_t*)t.dst + off;
+  int done = 0;
+  if ((((uintptr_t)s | (uintptr_t)d) & 15) == 0) {
+    const int n8 = n >> 3;
+    for (int i = threadIdx.x; i < n8; i += TPB) {
+      const float4 a = ((const float4*)s)[2 * i], b = ((const float4*)s)[2 * i + 1];
+      ((uint4*)d)[i] = make_uint4(pack_bf2(a.x, a.y), pack_bf2(a.z, a.w), pack_bf2(b.x, b.y), pack_bf2(b.z, b.w));
+    }
+    done = n8 << 3;
+  }
+  for (int j = done + threadIdx.x; j < n; j += TPB) d[j] = (bf16_t)(pack_bf2(s[j], 0.f) & 0xffffu);
+}
+
 }  // namespace
+
+extern "C" int mmdit_cast_multi(const mmdit_cast_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(tensors && chunk_tensor && chunk_off && n_chunks > 0);
+  hipLaunchKernelGGL(cast_multi_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, tensors, chunk_tensor, chunk_off);
+  return mmdit_launch_status();
+}
 
 extern "C" int mmdit_grad_sumsq(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, float* partials, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(tensors && chunk_tensor && chunk_off && partials && n_chunks > 0);

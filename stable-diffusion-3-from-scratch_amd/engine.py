@@ -66,10 +66,10 @@ def _to_fp8(m, p):
     A, B = p["A"], p["B"]
     if A.dtype != BF16 or B.dtype != BF16 or A.shape[1] % 128 or p.get("a_kmajor") or p.get("b_kmajor"):
         return p
-    ent = m._q.get(id(B))
-    if ent is None:
+    ent, gen = m._q.get(id(B)), getattr(B, "_mmdit_gen", 0)     # (the bf16 copy is refreshed in place: packing.Pack.generation)
+    if ent is None or ent[4] != gen:
         qb, sb = ops.quant_fp8(B)
-        ent = m._q[id(B)] = (B, qb, sb, ops.Fp8Site())
+        ent = m._q[id(B)] = (B, qb, sb, ent[3] if ent is not None else ops.Fp8Site(), gen)
     qa, sa = ent[3].quantise(A)      # delayed scaling: consecutive sampler steps see nearly the same activation range
     q = {k: v for k, v in p.items() if k != "aux"}
     q.update(A=qa, B=ent[1], scale_a=sa, scale_b=ent[2])

@@ -215,6 +215,30 @@ def cast(src, dtype, out=None):
     return out
 
 
+_CAST_TABLES = {}
+
+
+def cast_multi(pairs):
+    """fp32 -> bf16 for a list of (src, dst) CUDA tensor pairs in ONE launch (mmdit_cast_multi).  The device pointer table and
+    chunk map are cached per set of pointers (weights and their bf16 copies are persistent buffers)."""
+    import numpy as np
+    dev = pairs[0][0].device
+    key = tuple((s.data_ptr(), d.data_ptr(), s.numel()) for s, d in pairs)
+    t = _CAST_TABLES.get(key)
+    if t is None:
+        for s, d in pairs:
+            if s.dtype != torch.float32 or d.dtype != torch.bfloat16 or not s.is_contiguous() or not d.is_contiguous() or s.numel() != d.numel() or d.device != dev:
+                raise RuntimeError("cast_multi: contiguous fp32 sources and bf16 destinations of equal size on one device")
+        rec = np.array(key, dtype=np.int64).reshape(-1)
+        ct = np.concatenate([np.full((n + _lib.ADAMW_CHUNK - 1) // _lib.ADAMW_CHUNK, i, dtype=np.int32) for i, (_, _, n) in enumerate(key)])
+        co = np.concatenate([np.arange(0, n, _lib.ADAMW_CHUNK, dtype=np.int64) for _, _, n in key])
+        host = [torch.from_numpy(a).pin_memory() for a in (rec, ct, co)]
+        if len(_CAST_TABLES) >= 8:
+            _CAST_TABLES.pop(next(iter(_CAST_TABLES)))
+        t = _CAST_TABLES[key] = dict(host=host, dev=[h.to(dev, non_blocking=True) for h in host], n=len(ct))
+    check(_lib.lib().mmdit_cast_multi(_p(t["dev"][0]), _p(t["dev"][1]), _p(t["dev"][2]), t["n"], _s()), "mmdit_cast_multi")
+
+
 def ln_modulate_fwd(x, scale, shift, rows_per_batch, out_dtype):
     rows, d = x.shape
     out = torch.empty((rows, d), dtype=out_dtype, device=x.device)

@@ -11,7 +11,7 @@ import ctypes
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, packing
 
 _REC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("numel", "<i8")])   # mmdit_adamw_tensor
 
@@ -126,6 +126,7 @@ class ClipAdamW(torch.optim.AdamW):
             _lib.check(L.mmdit_adamw_step(vp(t["tensors"]), ctypes.c_void_p(t["chunk_tensor"].data_ptr() + 4 * c0), ctypes.c_void_p(t["chunk_off"].data_ptr() + 8 * c0), c1 - c0,
                                           vp(t["out3"]), vp(step0), float(lr), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), s), "mmdit_adamw_step")
         steps_flat.add_(1.0 - t["out3"][1])
+        packing.bump_epoch()     # the kernels wrote the parameters through raw pointers: the bf16 operand copies are stale now
         # out3 is overwritten by the next call: hand out copies
         res = t["out3"].clone()
         return res[1], res[2]

@@ -4,11 +4,32 @@ Parameters keep the reference's names, shapes and fp32 dtype (state_dict / optim
 SURVEY.md 8b).  For the MFMA GEMMs several of them are concatenated row-wise (q|k|v, the 12
 modulation matrices of a block, ...) into one operand in the activation dtype of the precision
 mode; the reference gets its bf16 copies from torch.autocast's weight cache
-(model_trainer.py:416).  Copies are refreshed only when a parameter's version / storage changes.
+(model_trainer.py:416).  Copies are refreshed -- all stale ones of a device in one launch -- when a parameter's version / storage
+changed or an optimizer stepped (see _EPOCH below).
 """
+import weakref
+
 import torch
 
 from . import ops
+
+# Staleness.  Tensor._version is NOT enough: torch's fused AdamW (and this package's HIP optimizer step, which writes through
+# raw pointers) update parameters without bumping it -- measured on ROCm: version 1 -> 1 across optimizer.step() -- so a cache
+# keyed on versions alone keeps multiplying with the initial weights.  Every optimizer step therefore advances a global epoch
+# (a global torch.optim post-step hook, so the reference's own trainer is covered; ClipAdamW.step_clipped calls bump_epoch()
+# itself) and the epoch is part of every cache key.
+_EPOCH = [0]
+_REGISTRY = weakref.WeakSet()
+
+
+def bump_epoch(*_a, **_k):
+    """Parameters may have changed behind Tensor._version: every Pack re-derives its copy at the next use."""
+    _EPOCH[0] += 1
+
+
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register_post_hook  # noqa: E402
+
+_register_post_hook(bump_epoch)
 
 
 class Pack:
@@ -18,24 +39,46 @@ class Pack:
         self.cols = self.params[0].numel() // self.params[0].shape[0]
         self._key = None
         self._val = None
+        self._buf = None        # persistent bf16 buffer of the fast mode (refreshed in place: its address is part of cached launch tables)
+        self.generation = 0     # refresh count (consumers that derive further copies, e.g. the fp8 weight cache, key on it)
+        _REGISTRY.add(self)
 
     def _state(self, mode):
-        return (mode.fast,) + tuple((p._version, p.data_ptr()) for p in self.params)
+        return (mode.fast, _EPOCH[0]) + tuple((p._version, p.data_ptr()) for p in self.params)
+
+    def _pairs(self):
+        dev = self.params[0].device
+        if self._buf is None or self._buf.device != dev:
+            self._buf = torch.empty((sum(self.rows), self.cols), dtype=torch.bfloat16, device=dev)
+        out, a = [], 0
+        for p, r in zip(self.params, self.rows):
+            out.append((p.detach().view(r, self.cols), self._buf[a:a + r]))
+            a += r
+        return out
+
+    def _mark(self, mode):
+        self.generation += 1
+        self._val = self._buf
+        self._val._mmdit_gen = self.generation
+        self._key = self._state(mode)
 
     def get(self, mode):
         key = self._state(mode)
         if key != self._key:
-            views = [p.detach().view(r, self.cols) for p, r in zip(self.params, self.rows)]
             if not mode.fast:
+                views = [p.detach().view(r, self.cols) for p, r in zip(self.params, self.rows)]
                 self._val = views[0] if len(views) == 1 else torch.cat(views, 0)
+                self._key = key
+            elif self.params[0].is_cuda:
+                # one launch refreshes this pack and every other stale bf16 copy on the device (all of them after an optimizer step)
+                dev = self.params[0].device
+                stale = [self] + [q for q in list(_REGISTRY) if q is not self and q._buf is not None and q.params[0].device == dev and q._state(mode) != q._key]
+                pairs = [pr for q in stale for pr in q._pairs()]
+                ops.cast_multi(pairs)
+                for q in stale:
+                    q._mark(mode)
             else:
-                out = torch.empty((sum(self.rows), self.cols), dtype=mode.T, device=views[0].device)
-                a = 0
-                for v, r in zip(views, self.rows):
-                    ops.cast(v, mode.T, out=out[a:a + r])
-                    a += r
-                self._val = out
-            self._key = key
+                raise RuntimeError("the bf16 (fast) precision mode runs on an MI355X only; use set_precision('parity') tensors on a GPU or move the model to the GPU")
         return self._val
 
     def split_grad(self, G, out: dict):

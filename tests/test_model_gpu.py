@@ -467,6 +467,43 @@ def test_hip_optimizer_step_matches_torch_path():
     assert any(not torch.equal(res[0][0][k], make_state_dict(0, **CONFIGS["micro"])[k].cuda()) for k in res[0][0])
 
 
+@pytest.mark.parametrize("hip", [True, False])
+def test_forward_follows_the_optimizer(hip):
+    """After optimizer steps (this package's HIP step, or torch's fused AdamW as the reference trainer runs it) the forward must
+    multiply with the UPDATED weights: bit-identical to a fresh model that loads the trained state_dict.  Regression test: torch's
+    fused AdamW and raw-pointer kernels do not bump Tensor._version, so version-keyed bf16 weight copies went stale."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+
+    def build():
+        net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                         device=torch.device("cuda:0"), positional_encoding="RoPE2d", **CONFIGS["micro"])
+        net.load_state_dict(make_state_dict(0, **CONFIGS["micro"]))
+        return net
+
+    torch.manual_seed(0)
+    net = build()
+    tr = model_trainer(net, batchSize=4, accumulation_steps=1, totalSteps=10, lr=1e-2, ema_update_freq=1, ema_decay=0.9, warmup_steps=0,
+                       use_lr_scheduler=False, device=torch.device("cuda:0"), saveDir="/tmp/_t", numSaveSteps=100, max_res=128,
+                       device_rng=True, use_ema=False, hip_optimizer=hip)
+    x, c, cp = [a.cuda() for a in make_inputs(3, 2, 16, 16)]
+    t = torch.tensor([0.3, 0.7], device="cuda")
+    with torch.no_grad():
+        y0 = net(x, t, c.clone(), cp.clone()).float().clone()
+    for s in (1, 2):
+        tr.train_step(s)
+    w = net.blocks[0].attn.query_proj_x.weight
+    assert float((w.detach() - make_state_dict(0, **CONFIGS["micro"])["blocks.0.attn.query_proj_x.weight"].cuda()).abs().max()) > 1e-3
+    fresh = build()
+    fresh.load_state_dict(net.state_dict())
+    with torch.no_grad():
+        y1 = net(x, t, c.clone(), cp.clone()).float()
+        y2 = fresh(x, t, c.clone(), cp.clone()).float()
+    assert torch.equal(y1, y2)
+    assert float((y1 - y0).norm() / y0.norm()) > 1e-2           # (and the two steps at lr 1e-2 did change the function)
+
+
 def test_gpu_resident_ema_matches_reference_cpu_loop():
     """update_ema on the GPU-resident average == the reference's per-parameter CPU loop (model_trainer.py:537-541);
     sync_ema_to_cpu() brings `ema_model_cpu` (what the checkpoint stores) up to date."""
