@@ -166,3 +166,5 @@ def broadcast_parameters(module, group=None, src=0):
         return
     for p in module.parameters():
         dist.broadcast(p.data, src=dist.get_global_rank(group, src) if group is not None else src, group=group)
+    from . import packing
+    packing.bump_epoch()     # collectives write through .data: any bf16 weight copy derived before the broadcast is stale
