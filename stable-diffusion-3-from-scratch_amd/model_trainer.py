@@ -91,7 +91,7 @@ class model_trainer:
                  wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
                  data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False,
-                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True, inf_padded_latents=False):
+                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True, inf_padded_latents=False, loss_scaling=True):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
@@ -134,7 +134,9 @@ class model_trainer:
         opt_cls = ClipAdamW if self.hip_optimizer else torch.optim.AdamW
         self.optim = opt_cls(self.model.parameters(), lr=lr, eps=1e-8, weight_decay=0.01, betas=(0.9, 0.999), fused=fused)
         self.scheduler = get_scheduler(self.optim, num_warmup_steps=warmup_steps, num_training_steps=totalSteps, use_lr_scheduler=use_lr_scheduler)
-        self.grad_scaler = torch.amp.GradScaler("cuda", enabled=self.device.type == "cuda") if self.use_amp else None
+        # loss_scaling=False: the GradScaler-free bf16 step -- bf16 has fp32's exponent range, the reference's dynamic
+        # loss scale is not needed; the scaler object stays (disabled) so that the six-file checkpoint layout is unchanged
+        self.grad_scaler = torch.amp.GradScaler("cuda", enabled=self.device.type == "cuda" and bool(loss_scaling)) if self.use_amp else None
 
         if load_ema_file and self.ema_model_cpu is not None:
             self.ema_model_cpu.load_state_dict(torch.load(load_ema_file, map_location="cpu", weights_only=False))

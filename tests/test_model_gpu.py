@@ -459,6 +459,26 @@ def test_hip_optimizer_step_matches_torch_path():
             tr.optimizer_step(step + 1)
         scales.append(float(tr.grad_scaler.get_scale()))
         res.append(({k: v.detach().clone() for k, v in tr.model.state_dict().items()}, scales, tr.optim.param_groups[0]["lr"]))
+    # GradScaler-free bf16 step (loss_scaling=False): same update from the same UNSCALED gradients, finite steps only
+    tr = make(True)
+    tr.grad_scaler = torch.amp.GradScaler("cuda", enabled=False)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for step, (mag, poison) in enumerate([(1e-4, False), (3.0, False)]):
+        for q in tr.model.parameters():
+            if q.requires_grad:
+                q.grad = torch.randn(q.shape, generator=g, device="cuda") * mag
+        tr.optimizer_step(step + 1)
+    ref2 = make(True)
+    ref2.grad_scaler.scale(torch.ones((), device="cuda"))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for step, (mag, poison) in enumerate([(1e-4, False), (3.0, False)]):
+        scale = float(ref2.grad_scaler.get_scale())
+        for q in ref2.model.parameters():
+            if q.requires_grad:
+                q.grad = torch.randn(q.shape, generator=g, device="cuda") * mag * scale
+        ref2.optimizer_step(step + 1)
+    for (k, a), (_, b) in zip(tr.model.state_dict().items(), ref2.model.state_dict().items()):
+        assert float((a.double() - b.double()).norm()) <= 2e-6 * float(b.double().norm()) + 1e-12, k
     assert res[0][1] == res[1][1] and res[0][1][3] < res[0][1][2]      # same scale history; backed off after the inf step
     assert res[0][2] == res[1][2]
     for k in res[0][0]:
