@@ -300,8 +300,18 @@ __global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __rest
   for (int e = 0; e < 8; e++) { w[e] = 0.f; aw[e] = 0.f; }
   if (part < 2) ld8((part == 0 ? wq : wk) + chunk * 8, w);
   const int rstride = gridDim.x;
+  // grid a multiple of the tokens per sample: every row of this workgroup is the same token, its RoPE factors are loaded once
+  const bool same_token = rcos && rstride % tokens == 0;
+  float cs[2][8], sn[2][8];
+  if (same_token && part < 2) {
+    const int n = blockIdx.x % tokens;
+    ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[0]);
+    ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[0]);
+#pragma unroll
+    for (int e = 0; e < 8; e++) { cs[1][e] = cs[0][e]; sn[1][e] = sn[0][e]; }
+  }
   for (int row0 = blockIdx.x; row0 < rows; row0 += 2 * rstride) {
-    float dz[2][8], x[2][8], cs[2][8], sn[2][8];
+    float dz[2][8], x[2][8];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
       const int row = row0 + k * rstride;
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __rest
         ld8(gbase + (((int64_t)b * heads + head) * s_total + tok0 + n) * 64 + chunk * 8, dz[k]);
         if (part < 2) {
           ld8(qkv + (((int64_t)row * 3 + part) * heads + head) * 64 + chunk * 8, x[k]);
-          if (rcos) {
+          if (rcos && !same_token) {
             ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[k]);
             ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[k]);
           }
@@ -749,7 +759,10 @@ extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void
   hipStream_t s = (hipStream_t)stream;
   MMDIT_CHECK_ARG(heads >= 1 && 24 * heads <= 1024);   // one row per workgroup of 24*heads threads
   const int rows = batch * tokens;
-  dim3 grid(rows < 512 ? rows : 512);
+  // <= 2 workgroups per CU (atomics, see the kernel), rounded to a multiple of the tokens per sample when RoPE applies
+  int g = rows < 512 ? rows : 512;
+  if (rope_cos && tokens <= 1024 && rows >= tokens) g = (g / tokens > 0 ? g / tokens : 1) * tokens;
+  dim3 grid(g);
 #define QKB(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<TG, TI, TO>), grid, dim3(24 * heads), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, rows, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk)
   if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_BF16 && dqkv_dtype == MMDIT_BF16) QKB(bf16_t, bf16_t, bf16_t);
   else if (dq_dtype == MMDIT_F32 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(float, float, float);
