@@ -240,44 +240,68 @@ __device__ __forceinline__ float group8_sum(float v) {
   return v;
 }
 
+// Forward: same thread mapping as the backward kernel below -- a workgroup of 24 * heads threads is one qkv row (thread = (part,
+// head, 8-element chunk), no per-element index divisions, norm weights in registers), rows blockIdx.x, + gridDim.x, ... two in
+// flight; with the grid a multiple of the tokens per sample all rows of a workgroup are the same token and the RoPE factors are
+// loaded once.
 template <typename TI>
-__global__ __launch_bounds__(256) void qk_norm_rope_fwd_kernel(const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
-                                                               const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                               int64_t total, int tokens, int heads, int s_total, int tok0,
-                                                               bf16_t* __restrict__ Q, bf16_t* __restrict__ K, bf16_t* __restrict__ V) {
-  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
-    const int chunk = (int)(gid & 7);
-    int64_t hv = gid >> 3;
-    const int head = (int)(hv % heads); hv /= heads;
-    const int part = (int)(hv % 3);
-    const int64_t row = hv / 3;
-    const int n = (int)(row % tokens);
-    const int64_t b = row / tokens;
-    float x[8];
-    ld8(qkv + gid * 8, x);
-    if (part < 2) {
-      float ss = 0.f;
+__global__ __launch_bounds__(1024) void qk_norm_rope_fwd_kernel(const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                                int rows, int tokens, int heads, int s_total, int tok0,
+                                                                bf16_t* __restrict__ Q, bf16_t* __restrict__ K, bf16_t* __restrict__ V) {
+  const int hc = threadIdx.x % (8 * heads), part = threadIdx.x / (8 * heads), head = hc >> 3, chunk = hc & 7;
+  bf16_t* obase = part == 0 ? Q : part == 1 ? K : V;
+  float w[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) ss += x[e] * x[e];
-      const float rinv = rsqrtf(group8_sum(ss) * (1.f / 64.f) + RMS_EPS);
-      float w[8];
-      ld8((part == 0 ? wq : wk) + chunk * 8, w);
+  for (int e = 0; e < 8; e++) w[e] = 0.f;
+  if (part < 2) ld8((part == 0 ? wq : wk) + chunk * 8, w);
+  const int rstride = gridDim.x;
+  const bool same_token = rcos && rstride % tokens == 0;
+  float cs[2][8], sn[2][8];
+  if (same_token && part < 2) {
+    const int n = blockIdx.x % tokens;
+    ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[0]);
+    ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[0]);
 #pragma unroll
-      for (int e = 0; e < 8; e++) x[e] = x[e] * rinv * w[e];
-      if (rcos) {
-        float c[8], s[8];
-        ld8(rcos + (int64_t)n * 64 + chunk * 8, c);
-        ld8(rsin + (int64_t)n * 64 + chunk * 8, s);
+    for (int e = 0; e < 8; e++) { cs[1][e] = cs[0][e]; sn[1][e] = sn[0][e]; }
+  }
+  for (int row0 = blockIdx.x; row0 < rows; row0 += 2 * rstride) {
+    float x[2][8];
 #pragma unroll
-        for (int p = 0; p < 4; p++) {
-          float a = x[2 * p], bb = x[2 * p + 1];
-          x[2 * p] = a * c[2 * p] - bb * s[2 * p];
-          x[2 * p + 1] = bb * c[2 * p + 1] + a * s[2 * p + 1];
+    for (int k = 0; k < 2; k++) {
+      const int row = row0 + k * rstride;
+      if (row < rows) {
+        ld8(qkv + (((int64_t)row * 3 + part) * heads + head) * 64 + chunk * 8, x[k]);
+        if (part < 2 && rcos && !same_token) {
+          const int n = row % tokens;
+          ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[k]);
+          ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[k]);
         }
       }
     }
-    bf16_t* dst = (part == 0 ? Q : part == 1 ? K : V) + ((b * heads + head) * (int64_t)s_total + tok0 + n) * 64 + chunk * 8;
-    st8(dst, x);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int row = row0 + k * rstride;
+      if (row >= rows) break;
+      const int n = row % tokens, b = row / tokens;
+      if (part < 2) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) ss += x[k][e] * x[k][e];
+        const float rinv = rsqrtf(group8_sum(ss) * (1.f / 64.f) + RMS_EPS);
+#pragma unroll
+        for (int e = 0; e < 8; e++) x[k][e] = x[k][e] * rinv * w[e];
+        if (rcos) {
+#pragma unroll
+          for (int p = 0; p < 4; p++) {
+            float a = x[k][2 * p], bb = x[k][2 * p + 1];
+            x[k][2 * p] = a * cs[k][2 * p] - bb * sn[k][2 * p];
+            x[k][2 * p + 1] = bb * cs[k][2 * p + 1] + a * sn[k][2 * p + 1];
+          }
+        }
+      }
+      st8(obase + (((int64_t)b * heads + head) * s_total + tok0 + n) * 64 + chunk * 8, x[k]);
+    }
   }
 }
 
@@ -743,10 +767,13 @@ extern "C" int mmdit_qk_norm_rope_fwd(const void* qkv, int qkv_dtype, const floa
   MMDIT_CHECK_ARG(qkv && wq && wk && Q && K && V && batch > 0 && tokens > 0 && heads > 0 && tok0 >= 0 && tok0 + tokens <= s_total);
   MMDIT_CHECK_ARG((rope_cos == nullptr) == (rope_sin == nullptr));
   hipStream_t s = (hipStream_t)stream;
-  const int64_t total = (int64_t)batch * tokens * 3 * heads * 8;
-  dim3 grid(grid_cap(total, 256));
-  if (qkv_dtype == MMDIT_BF16) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)qkv, wq, wk, rope_cos, rope_sin, total, tokens, heads, s_total, tok0, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
-  else if (qkv_dtype == MMDIT_F32) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)qkv, wq, wk, rope_cos, rope_sin, total, tokens, heads, s_total, tok0, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
+  MMDIT_CHECK_ARG(24 * heads <= 1024);   // one row per workgroup of 24*heads threads
+  const int rows = batch * tokens;
+  int g = rows < 1024 ? rows : 1024;
+  if (rope_cos && tokens <= 1024 && rows >= tokens) g = (g / tokens > 0 ? g / tokens : 1) * tokens;
+  dim3 grid(g);
+  if (qkv_dtype == MMDIT_BF16) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<bf16_t>), grid, dim3(24 * heads), 0, s, (const bf16_t*)qkv, wq, wk, rope_cos, rope_sin, rows, tokens, heads, s_total, tok0, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
+  else if (qkv_dtype == MMDIT_F32) hipLaunchKernelGGL((qk_norm_rope_fwd_kernel<float>), grid, dim3(24 * heads), 0, s, (const float*)qkv, wq, wk, rope_cos, rope_sin, rows, tokens, heads, s_total, tok0, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
   else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }
