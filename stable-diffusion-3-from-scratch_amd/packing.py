@@ -78,7 +78,7 @@ class Pack:
                 for q in stale:
                     q._mark(mode)
             else:
-                raise RuntimeError("the bf16 (fast) precision mode runs on an MI355X only; use set_precision('parity') tensors on a GPU or move the model to the GPU")
+                raise RuntimeError("bf16 weight copies are produced by the HIP library on an MI355X only (no CPU fallback): move the model to the GPU")
         return self._val
 
     def split_grad(self, G, out: dict):
