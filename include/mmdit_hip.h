@@ -266,6 +266,8 @@ typedef struct mmdit_adamw_tensor {
   float* exp_avg;
   float* exp_avg_sq;
   int64_t numel;
+  void* shadow_bf16;      /* optional: the bf16 GEMM-operand copy of this parameter, rewritten by mmdit_adamw_step together with
+                           * the fp32 master (saves the separate fp32 -> bf16 refresh pass); NULL = none */
 } mmdit_adamw_tensor;
 /* partials[c] = sum of grad^2 over chunk c (no atomics: deterministic). */
 int mmdit_grad_sumsq(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, float* partials, mmdit_stream_t stream);

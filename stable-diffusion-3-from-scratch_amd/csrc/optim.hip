@@ -115,8 +115,9 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(const mmdit_adamw_tensor* __
   const float* G = t.grad + off;
   float* M = t.exp_avg + off;
   float* V = t.exp_avg_sq + off;
+  bf16_t* S = t.shadow_bf16 ? (bf16_t*)t.shadow_bf16 + off : nullptr;
   int done = 0;
-  if ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0) {
+  if ((((uintptr_t)P | (uintptr_t)G | (uintptr_t)M | (uintptr_t)V) & 15) == 0 && ((uintptr_t)S & 7) == 0) {
     const int n4 = n >> 2;
     for (int i = threadIdx.x; i < n4; i += 2 * TPB) {
       const bool two = i + TPB < n4;
@@ -128,12 +129,14 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(const mmdit_adamw_tensor* __
       adam1(p0.z, g0.z * coef, m0.z, v0.z, k, step_size, bc2_sqrt);
       adam1(p0.w, g0.w * coef, m0.w, v0.w, k, step_size, bc2_sqrt);
       ((float4*)P)[i] = p0; ((float4*)M)[i] = m0; ((float4*)V)[i] = v0;
+      if (S) ((uint2*)S)[i] = make_uint2(pack_bf2(p0.x, p0.y), pack_bf2(p0.z, p0.w));
       if (two) {
         adam1(p1.x, g1.x * coef, m1.x, v1.x, k, step_size, bc2_sqrt);
         adam1(p1.y, g1.y * coef, m1.y, v1.y, k, step_size, bc2_sqrt);
         adam1(p1.z, g1.z * coef, m1.z, v1.z, k, step_size, bc2_sqrt);
         adam1(p1.w, g1.w * coef, m1.w, v1.w, k, step_size, bc2_sqrt);
         ((float4*)P)[i2] = p1; ((float4*)M)[i2] = m1; ((float4*)V)[i2] = v1;
+        if (S) ((uint2*)S)[i2] = make_uint2(pack_bf2(p1.x, p1.y), pack_bf2(p1.z, p1.w));
       }
     }
     done = n4 << 2;
@@ -142,6 +145,7 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(const mmdit_adamw_tensor* __
     float p = P[j], m = M[j], v = V[j];
     adam1(p, G[j] * coef, m, v, k, step_size, bc2_sqrt);
     P[j] = p; M[j] = m; V[j] = v;
+    if (S) S[j] = f2bf(p);
   }
 }
 

@@ -7,13 +7,14 @@ and the reference's `optim.pkl` checkpoints are interchangeable with it and the 
 torch's own; `step_clipped()` is the fused sequence.  There is no CPU fallback: it needs the HIP library and CUDA tensors.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
 
 from . import _lib, packing
 
-_REC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("numel", "<i8")])   # mmdit_adamw_tensor
+_REC = np.dtype([("param", "<u8"), ("grad", "<u8"), ("exp_avg", "<u8"), ("exp_avg_sq", "<u8"), ("numel", "<i8"), ("shadow", "<u8")])   # mmdit_adamw_tensor
 
 
 class ClipAdamW(torch.optim.AdamW):
@@ -25,6 +26,8 @@ class ClipAdamW(torch.optim.AdamW):
         self._table = None      # device pointer table + chunk map of the current parameter list
         self.table_builds = 0   # pointer-table uploads so far
         self._steps_flat, self._step_views = None, None
+        # the update kernel also rewrites the bf16 GEMM-operand copies (packing.shadow_targets); MMDIT_ADAMW_SHADOWS=0: A/B switch
+        self.write_shadows = os.environ.get("MMDIT_ADAMW_SHADOWS", "1") != "0"
 
     # ------------------------------------------------------------------------------------------
     def _state_of(self, p):
@@ -54,7 +57,8 @@ class ClipAdamW(torch.optim.AdamW):
         on the sizes (built once); the pointer table (40 B per tensor) is re-uploaded whenever a pointer moved -- the gradient
         arenas of the backward pass come from the caching allocator and do move -- through a small ring of pinned staging
         buffers and an asynchronous copy: no allocation and no host wait in the steady state."""
-        ptrs = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()) for grp in groups for p, g, m, v in grp)
+        ptrs = tuple((p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), s.data_ptr() if s is not None else 0)
+                     for grp in groups for p, g, m, v, s in grp)
         layout = (tuple(len(grp) for grp in groups), tuple(k[4] for k in ptrs), dev)
         t = self._table
         if t is None or t["layout"] != layout:
@@ -62,7 +66,7 @@ class ClipAdamW(torch.optim.AdamW):
             i = n = 0
             for grp in groups:
                 c0 = n
-                for p, _, _, _ in grp:
+                for p, _, _, _, _ in grp:
                     offs = np.arange(0, p.numel(), _lib.ADAMW_CHUNK, dtype=np.int64)
                     ct.append(np.full(len(offs), i, dtype=np.int32))
                     co.append(offs)
@@ -96,6 +100,11 @@ class ClipAdamW(torch.optim.AdamW):
         Returns (found_inf, grad_norm) as 0-dim device tensors (nothing is synchronised).  The stored .grad tensors are left
         as backward produced them (the reference zeroes them right after the step, model_trainer.py:503)."""
         groups, dev = [], None
+        shadows, shadow_packs = {}, []
+        if self.write_shadows:
+            p0 = next((p for g in self.param_groups for p in g["params"] if p.grad is not None), None)
+            if p0 is not None and p0.is_cuda:
+                shadows, shadow_packs = packing.shadow_targets(p0.device)
         for group in self.param_groups:
             rows = []
             for p in group["params"]:
@@ -104,7 +113,7 @@ class ClipAdamW(torch.optim.AdamW):
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() or not p.grad.is_contiguous():
                     raise RuntimeError("ClipAdamW.step_clipped needs contiguous fp32 CUDA parameters and gradients")
                 st = self._state_of(p)
-                rows.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"]))
+                rows.append((p, p.grad, st["exp_avg"], st["exp_avg_sq"], shadows.get(id(p))))
                 dev = p.device
             groups.append(rows)
         if dev is None:
@@ -126,7 +135,9 @@ class ClipAdamW(torch.optim.AdamW):
             _lib.check(L.mmdit_adamw_step(vp(t["tensors"]), ctypes.c_void_p(t["chunk_tensor"].data_ptr() + 4 * c0), ctypes.c_void_p(t["chunk_off"].data_ptr() + 8 * c0), c1 - c0,
                                           vp(t["out3"]), vp(step0), float(lr), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), s), "mmdit_adamw_step")
         steps_flat.add_(1.0 - t["out3"][1])
-        packing.bump_epoch()     # the kernels wrote the parameters through raw pointers: the bf16 operand copies are stale now
+        packing.bump_epoch()     # the kernels wrote the parameters through raw pointers: the bf16 operand copies are stale now ...
+        if shadow_packs:         # ... except the ones the update kernel has just rewritten
+            packing.mark_rewritten(shadow_packs, {id(r[0]) for rows in groups for r in rows if r[4] is not None})
         # out3 is overwritten by the next call: hand out copies
         res = t["out3"].clone()
         return res[1], res[2]

@@ -39,28 +39,36 @@ class Pack:
         self.cols = self.params[0].numel() // self.params[0].shape[0]
         self._key = None
         self._val = None
+        self._dsts = None
         self._buf = None        # persistent bf16 buffer of the fast mode (refreshed in place: its address is part of cached launch tables)
         self.generation = 0     # refresh count (consumers that derive further copies, e.g. the fp8 weight cache, key on it)
         _REGISTRY.add(self)
 
     def _state(self, mode):
-        return (mode.fast, _EPOCH[0]) + tuple((p._version, p.data_ptr()) for p in self.params)
+        return self._state_of(mode.fast)
 
-    def _pairs(self):
+    def _state_of(self, fast):
+        return (bool(fast), _EPOCH[0]) + tuple((p._version, p.data_ptr()) for p in self.params)
+
+    def _dst_views(self):
         dev = self.params[0].device
         if self._buf is None or self._buf.device != dev:
             self._buf = torch.empty((sum(self.rows), self.cols), dtype=torch.bfloat16, device=dev)
-        out, a = [], 0
-        for p, r in zip(self.params, self.rows):
-            out.append((p.detach().view(r, self.cols), self._buf[a:a + r]))
-            a += r
-        return out
+            self._dsts, a = [], 0
+            for r in self.rows:
+                self._dsts.append(self._buf[a:a + r])
+                a += r
+        return self._dsts
 
-    def _mark(self, mode):
+    def _pairs(self):
+        return [(p.detach().view(r, self.cols), d) for p, r, d in zip(self.params, self.rows, self._dst_views())]
+
+    def _mark(self, mode=None):
+        """The bf16 buffer holds the current parameters (mode None: the fast mode)."""
         self.generation += 1
         self._val = self._buf
         self._val._mmdit_gen = self.generation
-        self._key = self._state(mode)
+        self._key = self._state_of(True if mode is None else mode.fast)
 
     def get(self, mode):
         key = self._state(mode)
@@ -91,3 +99,25 @@ class Pack:
     def __deepcopy__(self, memo):
         import copy
         return Pack([copy.deepcopy(p, memo) for p in self.params])
+
+
+def shadow_targets(device):
+    """For an optimizer that rewrites the bf16 copies itself (optim.ClipAdamW): {id(param): bf16 view of its copy} over the
+    live packs that are in the bf16 mode on `device`; parameters that sit in more than one pack are left to the regular
+    refresh.  Returns (targets, packs)."""
+    count, target, packs = {}, {}, []
+    for q in list(_REGISTRY):
+        if q._buf is None or q._key is None or not q._key[0] or q._buf.device != device or q.params[0].device != device:
+            continue
+        packs.append(q)
+        for p, dst in zip(q.params, q._dst_views()):
+            count[id(p)] = count.get(id(p), 0) + 1
+            target[id(p)] = dst
+    return {k: t for k, t in target.items() if count[k] == 1}, packs
+
+
+def mark_rewritten(packs, rewritten_ids):
+    """After bump_epoch(): the packs whose every parameter had its bf16 copy rewritten by the optimizer are current again."""
+    for q in packs:
+        if all(id(p) in rewritten_ids for p in q.params):
+            q._mark()

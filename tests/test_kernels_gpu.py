@@ -501,3 +501,31 @@ def test_clip_adamw_matches_torch_sequence(ops):
     # the step counters are views of one flat tensor and survive a state_dict round trip
     sd = copy.deepcopy(oc.state_dict())
     assert all(float(s["step"]) == 5.0 and s["step"].dim() == 0 for s in sd["state"].values())
+
+
+def test_clip_adamw_rewrites_bf16_operand_copies(ops):
+    """The update kernel also rewrites the packed bf16 GEMM-operand copy of every parameter that lives in exactly one pack
+    (mmdit_adamw_tensor.shadow_bf16): after step_clipped those packs are current without a refresh pass and hold exactly
+    bf16(parameter); a parameter shared by two packs is left to the regular refresh."""
+    from sd3_amd import engine, packing
+    from sd3_amd.optim import ClipAdamW
+    ps = [torch.nn.Parameter(rnd(768, 768, seed=1, scale=0.02)), torch.nn.Parameter(rnd(64, 768, seed=2, scale=0.02)),
+          torch.nn.Parameter(rnd(40, 72, seed=3, scale=0.02))]
+    pk1, pk2, pk3 = packing.Pack(ps[:2]), packing.Pack([ps[2]]), packing.Pack([ps[2]])
+    for pk in (pk1, pk2, pk3):
+        pk.get(engine.FAST)
+    opt = ClipAdamW(ps, lr=1e-2)
+    before = [p.detach().clone() for p in ps]
+    for i, p in enumerate(ps):
+        p.grad = rnd(*p.shape, seed=10 + i)
+    opt.step_clipped(None, 1.0)
+    assert all(float((p.detach() - b).abs().max()) > 1e-3 for p, b in zip(ps, before))
+    assert pk1._key == pk1._state_of(True) and pk2._key != pk2._state_of(True) and pk3._key != pk3._state_of(True)
+    assert torch.equal(pk1.get(engine.FAST), torch.cat([ps[0].detach(), ps[1].detach()], 0).to(torch.bfloat16))
+    assert torch.equal(pk2.get(engine.FAST), ps[2].detach().to(torch.bfloat16)) and pk3._key == pk3._state_of(True)   # one refresh served both
+    assert torch.equal(pk3.get(engine.FAST), ps[2].detach().to(torch.bfloat16))
+    # an inf step leaves parameters and copies untouched
+    ps[0].grad.view(-1)[0] = float("inf")
+    snap = pk1._buf.clone()
+    found_inf, _ = opt.step_clipped(None, 1.0)
+    assert float(found_inf) == 1.0 and torch.equal(pk1.get(engine.FAST), snap)
