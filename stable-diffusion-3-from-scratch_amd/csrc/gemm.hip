@@ -254,6 +254,8 @@ int check_problem(const mmdit_gemm_args* a) {
 static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k) {
   static const char* force = getenv("MMDIT_GEMM_CFG");
   if (force) return atoi(force);
+  static const char* force_epi = getenv("MMDIT_GEMM_CFG_EPI");   // experiments: tile configuration of the gated-residual (fp32 C) launches only
+  if (force_epi && args[0].gate) return atoi(force_epi);
   if (stream_k) return CFG_256x256;   // no quantisation with stream-K: take the fewest bytes per FLOP
   // Wave quantisation decides (measured, tools/gemm_bench.py): a "round" of 128x128 tiles (2 workgroups per CU)
   // costs 1.0, a round of 256x256 tiles (1 per CU, 4x the FLOPs each) 1.58.
