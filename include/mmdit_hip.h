@@ -175,8 +175,8 @@ int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void* dV, int d
  * Ox (batch, n_img, heads*64), Oc (batch, S-n_img, heads*64), bf16.  lse: fp32 (batch,heads,S).
  * mode 0: flash (fp32 scores, online softmax).  mode 1: reproduces the rounding points of the
  * reference's CPU branch (scores->bf16, *scale->bf16, softmax->bf16, PV->bf16; two passes).
- * bwd: dOx/dOc bf16 (dOc may be NULL = zeros, last block), delta fp32 workspace (batch,heads,S),
- * dQ,dK,dV written (not accumulated) in dq_dtype.
+ * bwd: dOx/dOc bf16 (dOc may be NULL = zeros, last block), delta fp32 workspace (batch,heads,S) -- rowsum(dO * O), produced
+ * by the dQ pass and consumed by the dK/dV pass --, dQ,dK,dV written (not accumulated) in dq_dtype.
  * ------------------------------------------------------------------------- */
 int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img,
                    float scale, int mode, void* Ox, void* Oc, float* lse, mmdit_stream_t stream);

@@ -232,39 +232,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward prep: delta[b,h,s] = sum_d dO * O
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_prep_kernel(const bf16_t* __restrict__ Ox, const bf16_t* __restrict__ Oc, const bf16_t* __restrict__ dOx,
-                                                            const bf16_t* __restrict__ dOc, int64_t total, int H, int S, int n_img, float* __restrict__ delta) {
-  const int n_txt = S - n_img, D = H * HD;
-  for (int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x; gid < total; gid += (int64_t)gridDim.x * 256) {
-    const int chunk = (int)(gid & 7);
-    int64_t r = gid >> 3;
-    const int h = (int)(r % H); r /= H;
-    const int s = (int)(r % S);
-    const int64_t b = r / S;
-    const bf16_t* po = tok_ptr(Ox, Oc, b, s, n_img, n_txt, D, h);
-    const bf16_t* pd = tok_ptr(dOx, dOc, b, s, n_img, n_txt, D, h);
-    float acc = 0.f;
-    if (pd) {
-      float a[8], g[8];
-      ld8(po + chunk * 8, a); ld8(pd + chunk * 8, g);
-#pragma unroll
-      for (int e = 0; e < 8; e++) acc += a[e] * g[e];
-    }
-    acc += __shfl_xor(acc, 1, 64); acc += __shfl_xor(acc, 2, 64); acc += __shfl_xor(acc, 4, 64);
-    if (chunk == 0) delta[(b * H + h) * (int64_t)S + s] = acc;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
 template <int NW, typename TG>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               const bf16_t* __restrict__ Ox, const bf16_t* __restrict__ Oc,
                                                                const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
-                                                               const float* __restrict__ lse, const float* __restrict__ delta,
+                                                               const float* __restrict__ lse, float* __restrict__ delta,
                                                                int BH, int H, int S, int n_img, float scale, TG* __restrict__ dQ) {
+  // delta[q] = sum_d dO[q,d] O[q,d] is formed here from the query's own dO / O rows (each lane holds half of the 64 features of its
+  // query) and written out for the dK/dV kernel that follows on the same stream -- no separate preparation pass.
   constexpr int NT = NW * 64;
   __shared__ __attribute__((aligned(16))) char smem[2 * KT * P144];
   char* ktile = smem;
@@ -289,7 +266,23 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
     u32x4 z = {0, 0, 0, 0};
     dof[ks] = dop ? *(const bf16x8*)(dop + ks * 16 + (lane >> 5) * 8) : __builtin_bit_cast(bf16x8, z);
   }
-  const float lq = lse[(int64_t)bh * S + qc] * LOG2E, dq_delta = delta[(int64_t)bh * S + qc];
+  float dq_delta = 0.f;
+  {
+    const bf16_t* op = tok_ptr(Ox, Oc, b, qc, n_img, S - n_img, H * HD, h);
+    if (dop && op) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        const u32x4 o4 = *(const u32x4*)(op + ks * 16 + (lane >> 5) * 8), d4 = __builtin_bit_cast(u32x4, dof[ks]);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          dq_delta += __builtin_bit_cast(float, o4[e] << 16) * __builtin_bit_cast(float, d4[e] << 16) +
+                      __builtin_bit_cast(float, o4[e] & 0xffff0000u) * __builtin_bit_cast(float, d4[e] & 0xffff0000u);
+      }
+    }
+    dq_delta += __shfl_xor(dq_delta, 32, 64);
+    if (lane < 32 && q < S) delta[(int64_t)bh * S + q] = dq_delta;
+  }
+  const float lq = lse[(int64_t)bh * S + qc] * LOG2E;
   f32x16 acc[2];
 #pragma unroll
   for (int db = 0; db < 2; db++)
@@ -487,15 +480,12 @@ extern "C" int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const
   MMDIT_CHECK_ARG(Q && K && V && Ox && dOx && lse && delta && dQ && dK && dV && batch > 0 && heads > 0 && S > 0 && n_img > 0 && n_img <= S);
   MMDIT_CHECK_ARG(Oc || n_img == S);
   hipStream_t s = (hipStream_t)stream;
-  const int64_t total = (int64_t)batch * S * heads * 8;
-  int64_t g = (total + 255) / 256;
-  hipLaunchKernelGGL(attn_bwd_prep_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, (const bf16_t*)Ox, (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc,
-                     total, heads, S, n_img, delta);
+  // (delta = rowsum(dO * O) is produced by the dQ kernel, which runs first)
   const int nw = attn_waves();
 #define MMDIT_DKV(NW, TG) hipLaunchKernelGGL((attn_bwd_dkv_kernel<NW, TG>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                                              (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (TG*)dK, (TG*)dV)
 #define MMDIT_DQ(NW, TG) hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, TG>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
-                                            (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (TG*)dQ)
+                                            (const bf16_t*)V, (const bf16_t*)Ox, (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (TG*)dQ)
   if (dq_dtype == MMDIT_BF16) {
     if (nw == 8) MMDIT_DQ(8, bf16_t);
     else if (nw == 4) MMDIT_DQ(4, bf16_t);
