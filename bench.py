@@ -1,6 +1,6 @@
 """Benchmark of the MMDiT-B flow-matching TRAINING step on MI355X (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: starts the N ranks itself, one child process per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = one optimizer step on one synthetic batch per GPU (per-GPU batch 64, weak scaling):
@@ -75,6 +75,37 @@ def cpu_baseline(seconds_budget=25.0):
             "sample": f"{n} optimizer steps of MMDiT-B (fp32 weights, reference CPU attention branch), batch {bs}, fwd+bwd+clip+AdamW, torch CPU {threads} threads"}
 
 
+def self_launch(n):
+    """Start one bench.py process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, what
+    torch.distributed.run would set) and wait for them; rank 0's JSON line goes to this process's stdout.  Returns the exit
+    code: 0, or the first non-zero child status (the remaining ranks are then terminated so that nobody hangs in a collective)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    code = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0 and code == 0:
+                code = rc
+                for q in alive:
+                    q.terminate()
+        time.sleep(0.05)
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -85,13 +116,31 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true", help="development A/B: torch's multi-tensor unscale/clip/AdamW kernels instead of the three HIP launches")
     ap.add_argument("--force-dist", action="store_true", help="development: run the N>1 code path (RCCL group + gradient reducer) with one rank")
+    ap.add_argument("--check-launch", action="store_true", help="rendezvous check only (gloo, no GPU): every rank joins the group, one all-reduce, rank 0 prints the world size")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher.  Nothing in this process has touched the GPU yet (no torch import,
+        # no HIP call), the N ranks are CHILD processes (one per GPU, env:// rendezvous on 127.0.0.1) and this process only waits.
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.check_launch:
+        assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if world > 1:
+            dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
+        tsum = torch.tensor([float(rank + 1)])
+        if world > 1:
+            dist.all_reduce(tsum)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"launch_ok": float(tsum) == world * (world + 1) / 2, "n_gpus": world, "local_rank": local_rank}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs an MI355X: the MMDiT hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)

@@ -37,6 +37,13 @@ Rounding modes (OracleConfig):
             = "bf16":  operands (weights and GEMM inputs) rounded to bf16 at the
               same points as the HIP fast path, fp32 accumulation; intermediate
               GEMM outputs that the fast path stores as bf16 are rounded too.
+            = "fp8":   "bf16", and the four big GEMMs of every block (QKV, attention
+              out-projection, MLP up / down; both streams) take OCP e4m3 operands with
+              per-tensor scales exactly as the HIP fp8 inference mode does on the first
+              call of a site: s = amax / 448, q = e4m3_rne(clamp(x / s)), the packed
+              weight ([Wq; Wk; Wv], w12, ...) shares ONE scale, C = s_a s_b (A_q B_q^T).
+              This is test infrastructure for BASELINE config 5; the reference itself
+              has no fp8 path.
 """
 from __future__ import annotations
 
@@ -82,16 +89,39 @@ def _rb(x: torch.Tensor) -> torch.Tensor:
 
 
 def _lin(cfg: OracleConfig, x, w, b=None):
-    """nn.Linear; in gemm=bf16 mode both operands are rounded to bf16 first."""
-    if cfg.gemm == "bf16":
+    """nn.Linear; in gemm=bf16 / fp8 mode both operands are rounded to bf16 first."""
+    if cfg.gemm in ("bf16", "fp8"):
         x = _rb(x)
         w = _rb(w)
     return F.linear(x, w, b)
 
 
+def _q8(x: torch.Tensor):
+    """Per-tensor OCP e4m3 quantisation as csrc/rowops.hip fp8_quant_kernel does it: returns (values of the e4m3 codes as
+    fp32, dequantisation scale amax/448)."""
+    a = x.detach().abs().amax().clamp_min(1e-12)
+    q = (x * (448.0 / a)).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+    return q, a / 448.0
+
+
+def _lin8(cfg: OracleConfig, x, ws, b=None):
+    """One of the fp8 GEMM sites of a block: `ws` are the weights the HIP path packs row-wise into ONE operand (so they share
+    one e4m3 scale); returns the list of outputs.  Outside fp8 mode (or K % 128 != 0, which the HIP path keeps in bf16) these
+    are plain _lin calls."""
+    if cfg.gemm != "fp8" or x.shape[-1] % 128:
+        assert b is None or len(ws) == 1
+        return [_lin(cfg, x, w, b) for w in ws]      # (bias inside F.linear: the reference's op, bit for bit)
+    xq, sa = _q8(_rb(x))
+    wq, sb = _q8(_rb(torch.cat(list(ws), dim=0)))
+    out = F.linear(xq, wq) * (sa * sb)
+    if b is not None:
+        out = out + b
+    return list(out.split([w.shape[0] for w in ws], dim=-1))
+
+
 def _act(cfg: OracleConfig, x):
     """Activation tensor that the HIP fast path stores as bf16."""
-    return _rb(x) if cfg.gemm == "bf16" else x
+    return _rb(x) if cfg.gemm in ("bf16", "fp8") else x
 
 
 # ----------------------------------------------------------------------------
@@ -191,10 +221,10 @@ def mlp(x, sd, prefix: str, cfg: OracleConfig):
     """MLP.forward (blocks/MLP.py:25-40).  swiglu = xformers SwiGLU eager
     semantics: w3(silu(x W1^T + b1) * (x W2^T + b2)) + b3, [W1;W2] = w12."""
     if cfg.MLP_type == "swiglu":
-        gu = _act(cfg, _lin(cfg, x, sd[prefix + "MLP.w12.weight"], sd[prefix + "MLP.w12.bias"]))
+        gu = _act(cfg, _lin8(cfg, x, [sd[prefix + "MLP.w12.weight"]], sd[prefix + "MLP.w12.bias"])[0])
         g, u = gu.chunk(2, dim=-1)
         h = _act(cfg, F.silu(g) * u)
-        return _lin(cfg, h, sd[prefix + "MLP.w3.weight"], sd[prefix + "MLP.w3.bias"])
+        return _lin8(cfg, h, [sd[prefix + "MLP.w3.weight"]], sd[prefix + "MLP.w3.bias"])[0]
     if cfg.MLP_type == "gelu":
         u = _act(cfg, _lin(cfg, x, sd[prefix + "lin_up.weight"], sd[prefix + "lin_up.bias"]))
         h = _act(cfg, F.gelu(u))
@@ -211,12 +241,14 @@ def attention(x, c, sd, prefix: str, cfg: OracleConfig, hw, last: bool, taps: Op
     def heads(t, L):
         return t.reshape(B, L, H, hd).permute(0, 2, 1, 3)
 
-    q_x = rms_norm(heads(_act(cfg, _lin(cfg, x, sd[prefix + "query_proj_x.weight"])), N), sd[prefix + "q_norm_x.weight"])
-    k_x = rms_norm(heads(_act(cfg, _lin(cfg, x, sd[prefix + "key_proj_x.weight"])), N), sd[prefix + "k_norm_x.weight"])
-    v_x = heads(_act(cfg, _lin(cfg, x, sd[prefix + "value_proj_x.weight"])), N)
-    q_c = rms_norm(heads(_act(cfg, _lin(cfg, c, sd[prefix + "query_proj_c.weight"])), M), sd[prefix + "q_norm_c.weight"])
-    k_c = rms_norm(heads(_act(cfg, _lin(cfg, c, sd[prefix + "key_proj_c.weight"])), M), sd[prefix + "k_norm_c.weight"])
-    v_c = heads(_act(cfg, _lin(cfg, c, sd[prefix + "value_proj_c.weight"])), M)
+    qkv_x = _lin8(cfg, x, [sd[prefix + n + "_proj_x.weight"] for n in ("query", "key", "value")])
+    qkv_c = _lin8(cfg, c, [sd[prefix + n + "_proj_c.weight"] for n in ("query", "key", "value")])
+    q_x = rms_norm(heads(_act(cfg, qkv_x[0]), N), sd[prefix + "q_norm_x.weight"])
+    k_x = rms_norm(heads(_act(cfg, qkv_x[1]), N), sd[prefix + "k_norm_x.weight"])
+    v_x = heads(_act(cfg, qkv_x[2]), N)
+    q_c = rms_norm(heads(_act(cfg, qkv_c[0]), M), sd[prefix + "q_norm_c.weight"])
+    k_c = rms_norm(heads(_act(cfg, qkv_c[1]), M), sd[prefix + "k_norm_c.weight"])
+    v_c = heads(_act(cfg, qkv_c[2]), M)
 
     # RoPE2d on image tokens only; patch size hard-coded to 2 (Attention.py:178-179)
     h2, w2 = hw[0] // 2, hw[1] // 2
@@ -234,8 +266,8 @@ def attention(x, c, sd, prefix: str, cfg: OracleConfig, hw, last: bool, taps: Op
         taps["attn_core"] = o.detach()
     o_x = o[:, :, :N].permute(0, 2, 1, 3).reshape(B, N, -1)
     o_c = o[:, :, N:].permute(0, 2, 1, 3).reshape(B, M, -1)
-    a_x = _lin(cfg, o_x, sd[prefix + "out_proj_x.weight"])
-    a_c = o_c if last else _lin(cfg, o_c, sd[prefix + "out_proj_c.weight"])
+    a_x = _lin8(cfg, o_x, [sd[prefix + "out_proj_x.weight"]])[0]
+    a_c = o_c if last else _lin8(cfg, o_c, [sd[prefix + "out_proj_c.weight"]])[0]
     return a_x, a_c
 
 

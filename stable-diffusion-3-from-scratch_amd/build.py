@@ -1,5 +1,10 @@
 """Build libmmdit_hip.so (gfx950) in-tree with hipcc.  No torch involvement: the
-library is a plain C-ABI shared object (include/mmdit_hip.h)."""
+library is a plain C-ABI shared object (include/mmdit_hip.h).
+
+Up-to-date checks are by CONTENT, not by mtime: every object records the sha256 of its source, of every header it can include
+and of the compiler flags (csrc/<name>.o.sha), the library the hashes of its objects (libmmdit_hip.so.sha).  build(force=True)
+(what __graft_entry__.build() calls) recompiles everything regardless."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -8,39 +13,67 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdit_hip.so")
+HEADER = os.path.join(HERE, "..", "include", "mmdit_hip.h")
 SOURCES = ["gemm.hip", "gemm_dma.hip", "rowops.hip", "attention.hip", "vae.hip", "optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
 
 
-def _newer(src_list, target):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(s) > t for s in src_list)
+def _sha(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def source_hash(src):
+    """Content hash of everything object `src` depends on."""
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [HEADER]
+    return _sha([os.path.join(CSRC, src)] + headers, " ".join([HIPCC] + FLAGS))
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "mmdit_hip.h")]
-    if not force and not _newer(deps, LIB):
-        return LIB
-    objs = []
+    want = {src: source_hash(src) for src in SOURCES}
 
     def cc(src):
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if not force and os.path.exists(obj) and _read(obj + ".sha") == want[src]:
+            return obj, False
         cmd = [HIPCC] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-        return obj
+        with open(obj + ".sha", "w") as f:
+            f.write(want[src])
+        return obj, True
 
     with ThreadPoolExecutor(max_workers=6) as ex:
-        objs = list(ex.map(cc, SOURCES))
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+        res = list(ex.map(cc, SOURCES))
+    objs = [o for o, _ in res]
+    libsha = hashlib.sha256("".join(want[s] for s in SOURCES).encode()).hexdigest()
+    if force or any(c for _, c in res) or not os.path.exists(LIB) or _read(LIB + ".sha") != libsha:
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        with open(LIB + ".sha", "w") as f:
+            f.write(libsha)
     return LIB
+
+
+def is_current() -> bool:
+    """True when the in-tree library was built from exactly the sources that are in the tree now."""
+    libsha = hashlib.sha256("".join(source_hash(s) for s in SOURCES).encode()).hexdigest()
+    return os.path.exists(LIB) and _read(LIB + ".sha") == libsha
 
 
 if __name__ == "__main__":

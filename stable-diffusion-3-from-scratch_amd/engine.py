@@ -395,9 +395,21 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
 # ----------------------------------------------------------------------------------------------
 # whole model
 # ----------------------------------------------------------------------------------------------
-def model_fwd(m, W, x_t, t, c, c_pooled, rope, keep=True):
+def text_fwd(m, W, c):
+    """Text tokens entering the blocks (diff_model.py:164-172, 323-326): cat[c_proj(s1 RMSNorm(c[:, :77])), c_proj2(s2 RMSNorm(c[:, 77:]))]
+    as one (B*tokens, d) fp32 buffer.  Independent of the timestep: the sampler computes it once for all its steps.  Returns C and the two normalised operands (saved for backward)."""
+    B, Mt = c.shape[0], c.shape[1]
+    d = W.dim
+    cn1, cn2 = ops.text_rmsnorm_fwd(c, W.wn1, W.wn2, W.s1, W.s2, W.split, m.T)
+    c1, c2 = _group(m, [dict(A=cn1, B=W.Wc1, out_dtype=F32), dict(A=cn2, B=W.Wc2, out_dtype=F32)])
+    C = torch.cat([c1.view(B, W.split, d), c2.view(B, Mt - W.split, d)], dim=1).view(B * Mt, d)
+    return C, cn1, cn2
+
+
+def model_fwd(m, W, x_t, t, c, c_pooled, rope, keep=True, C=None):
     """W: packed weights (see models/diff_model.py).  x_t (B,Cin,H,W); t (B,) fp32;
-    c (B,tokens,2304); c_pooled (B,class_dim).  Returns v (B,Cin,H,W) fp32 and the saved state."""
+    c (B,tokens,2304); c_pooled (B,class_dim).  Returns v (B,Cin,H,W) fp32 and the saved state.
+    C: the text tokens from text_fwd() when the caller already has them (inference only: nothing is saved for their backward)."""
     B, Cin, Hh, Ww = x_t.shape
     d, H = W.dim, W.heads
     N, Mt = (Hh // 2) * (Ww // 2), c.shape[1]
@@ -408,9 +420,8 @@ def model_fwd(m, W, x_t, t, c, c_pooled, rope, keep=True):
     sv.cp = m.act(c_pooled)
     sv.y = _gemm(m, sv.cp, W.Wcond, residual=temb, out_dtype=m.T)
 
-    sv.cn1, sv.cn2 = ops.text_rmsnorm_fwd(c, W.wn1, W.wn2, W.s1, W.s2, W.split, m.T)
-    c1, c2 = _group(m, [dict(A=sv.cn1, B=W.Wc1, out_dtype=F32), dict(A=sv.cn2, B=W.Wc2, out_dtype=F32)])
-    C = torch.cat([c1.view(B, W.split, d), c2.view(B, Mt - W.split, d)], dim=1).view(B * Mt, d)
+    if C is None:
+        C, sv.cn1, sv.cn2 = text_fwd(m, W, c)
 
     sv.patches = ops.patchify(x_t, m.T)
     sv.X0 = _gemm(m, sv.patches, W.Wpatch, out_dtype=m.T)

@@ -191,11 +191,16 @@ class model_trainer:
                 batch_x_0 = unpad_latents(batch_x_0)
             t_vals, n_pooled, n_gemma, n_bert = self._sample_conditioning(batch_x_0.shape[0])
             batch_x_t, epsilon_t = self.model.noise_batch(batch_x_0, t_vals)
-        # Hook path (post-accumulate hooks see the ACCUMULATED gradient): reduce on the final micro-step only (DDP no_sync).
-        # Engine path (the backward schedule hands over each micro-step's own gradients): every micro-step is averaged,
-        # which sums to the same mean and is what plain DDP does on every backward (reference model_trainer.py:467).
+        # Gradient accumulation = DDP.no_sync (reference model_trainer.py:463-480): nothing is reduced on non-final micro-steps.
+        #  * hook path (post-accumulate hooks see the ACCUMULATED gradient): the hooks reduce on the final micro-step only;
+        #  * engine path, accumulation_steps == 1: the backward schedule hands each block's gradients to the reducer as soon as
+        #    they are final (overlapped with the rest of the backward);
+        #  * engine path, accumulation_steps > 1: the schedule only ever sees the current micro-step's own gradients, so it is
+        #    told to skip, and after the final backward the ACCUMULATED .grad tensors are averaged in flat buckets (one
+        #    reduction per optimizer step instead of one per micro-step).
         engine_path = getattr(self.model, "grad_reducer", None) is self.reducer and self.reducer.enabled
-        self.reducer.skip = (not final) and not engine_path
+        late = engine_path and self.accumulation_steps > 1
+        self.reducer.skip = (not final) or late
         v_pred = self.model(batch_x_t.detach(), t_vals, batch_txt, batch_txt_pooled, n_pooled, n_gemma, n_bert)
         labels = epsilon_t - batch_x_0.to(epsilon_t.device)
         loss = nn.MSELoss(reduction="none")(v_pred, labels.detach().to(v_pred.dtype)).flatten(1, -1).mean()
@@ -204,7 +209,10 @@ class model_trainer:
             self.grad_scaler.scale(loss).backward()
         else:
             loss.backward()
-        if final or engine_path:
+        if final:
+            self.reducer.skip = False
+            if late:
+                self.reducer.add([p.grad for p in self.model.parameters() if p.grad is not None])
             self.reducer.finish()
         return loss.detach()
 

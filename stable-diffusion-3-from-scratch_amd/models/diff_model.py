@@ -237,51 +237,77 @@ class diff_model(nn.Module):
     @torch.no_grad()
     def sample_imgs(self, batchSize, num_steps, text_input, cfg_scale=0.0, width=256, height=256, save_intermediate=False, use_tqdm=False,
                     sampler="euler", generator=None):
-        """Euler / stochastic-Euler / Heun rectified-flow sampler with batched CFG (diff_model.py:367-480)."""
-        use_vae = True
+        """Rectified-flow sampler with classifier-free guidance; public contract of diff_model.py:367-480 (arguments, `generator`
+        semantics -- initial and per-step noise are drawn on the CPU from it --, "euler" | "euler_stochastic" | "heun", return
+        value, error for an unknown sampler).
+
+        Device-resident loop: everything that does not depend on the step is built ONCE -- the (2B, ...) guidance batch buffer whose
+        two halves hold the same latents, the conditional | null text operands (the null half is what the reference's in-place
+        null-masking produces: zeros), their projection into the blocks' text stream (engine.text_fwd: RMSNorm + c_proj of
+        2B x 154 x 2304 values, timestep-independent), the packed weights and RoPE tables -- and a step is one engine.model_fwd on the
+        resident buffers plus three small torch ops; no host synchronisation inside the loop."""
+        if sampler not in ("euler", "euler_stochastic", "heun"):
+            raise ValueError("Invalid sampler specified. Choose 'euler', 'euler_stochastic', or 'heun'.")
         self.eval()
-        h, w = width, height
+        dev, B = self.device, batchSize
         VAE = self.text_encoders.VAE
-        output = torch.randn((batchSize, VAE.config.latent_channels if use_vae else 3, h // 8 if use_vae else h, w // 8 if use_vae else w), generator=generator).to(self.device)
-        text_hidden, text_pooled = self.text_encoders.text_to_embedding(text_input)
-        nullCls = torch.tensor([0] * batchSize + [1] * batchSize).bool().to(self.device)
-        text_hidden = text_hidden.repeat(2 * batchSize, 1, 1).to(self.device)
-        text_pooled = text_pooled.repeat(2 * batchSize, 1).to(self.device)
-        imgs = []
+        lat = (B, VAE.config.latent_channels, width // 8, height // 8)
+        if lat[2] % 2 or lat[3] % 2:
+            raise RuntimeError(f"shape '{[2 * B, lat[2] // 2, lat[3] // 2, self.inCh, 2, 2]}' is invalid: latent height and width must be even")
+        m = self._mode()
+        W = self.weights(m)
+        rope = self.blocks[0].attn.rotary_emb.tables(lat[2] // 2, lat[3] // 2, dev)
+
+        # guidance batch: rows [0, B) conditional, rows [B, 2B) unconditional
+        xx = torch.empty((2 * B,) + lat[1:], dtype=torch.float32, device=dev)
+        x = xx[:B]
+        x.copy_(torch.randn(lat, generator=generator))
+        xx[B:].copy_(x)
+        tt = torch.empty((2 * B,), dtype=torch.float32, device=dev)
+        hidden, pooled = self.text_encoders.text_to_embedding(text_input)
+        c = torch.zeros((2 * B,) + tuple(hidden.shape[1:]), dtype=hidden.dtype if hidden.dtype in (torch.float32, torch.bfloat16) else torch.float32, device=dev)
+        cp = torch.zeros((2 * B, pooled.shape[-1]), dtype=c.dtype, device=dev)
+        c[:B] = hidden.to(dev)
+        cp[:B] = pooled.to(dev)
+        C_text = engine.text_fwd(m, W, c)[0]
+
+        def velocity(t_now):
+            tt.fill_(t_now)
+            v = engine.model_fwd(m, W, xx, tt, c, cp, rope, keep=False, C=C_text)[0]
+            return (1 + cfg_scale) * v[:B] - cfg_scale * v[B:]
 
         def decode(z):
             return VAE.decode((z.to(VAE.dtype) - VAE.config.shift_factor) / VAE.config.scaling_factor).sample.clamp(-1, 1)
 
-        timesteps = torch.linspace(1, 0 + (1.0 / num_steps), num_steps).to(self.device)
-        it = timesteps
+        def first_image():
+            return decode(x)[0].float().cpu().detach()
+
+        dt = 1 / num_steps
+        times = torch.linspace(1, 0 + (1.0 / num_steps), num_steps).tolist()     # host scalars (fp32 values of the reference's linspace)
         if use_tqdm:
             from tqdm import tqdm
-            it = tqdm(timesteps, total=num_steps)
-        for i, t in enumerate(it):
-            t = t.repeat(2 * batchSize).to(self.device)
-            velocity = self.forward(output.repeat(2, 1, 1, 1), t, text_hidden, text_pooled, nullCls, nullCls, nullCls)
-            velocity = (1 + cfg_scale) * velocity[:batchSize] - cfg_scale * velocity[batchSize:]
-            dt = 1 / num_steps
+            times = tqdm(times, total=num_steps)
+        imgs = []
+        for t_now in times:
+            v1 = velocity(t_now)
             if sampler == "euler":
-                output = output - velocity * dt
+                x.sub_(v1, alpha=dt)
             elif sampler == "euler_stochastic":
-                sigma = (t * (1 - t) / (1 - t + 0.008))[:batchSize, None, None, None]
-                noise = torch.randn(velocity.shape, generator=generator).to(output.device)
-                output = output - velocity * dt + sigma * noise * np.sqrt(dt)
-            elif sampler == "heun":
-                velocity_1 = velocity
-                x_pred = output - velocity_1 * dt
-                t_next = t - dt
-                velocity_2 = self.forward(x_pred.repeat(2, 1, 1, 1), t_next, text_hidden, text_pooled, nullCls, nullCls, nullCls)
-                velocity_2 = (1 + cfg_scale) * velocity_2[:batchSize] - cfg_scale * velocity_2[batchSize:]
-                output = output - (dt / 2) * (velocity_1 + velocity_2)
-            else:
-                raise ValueError("Invalid sampler specified. Choose 'euler', 'euler_stochastic', or 'heun'.")
+                sigma = t_now * (1 - t_now) / (1 - t_now + 0.008)
+                noise = torch.randn(v1.shape, generator=generator).to(dev)
+                x.sub_(v1, alpha=dt).add_(noise, alpha=sigma * np.sqrt(dt))
+            else:   # heun: trapezoidal corrector on the Euler prediction, second evaluation at t - dt
+                x_keep = x.clone()
+                x.sub_(v1, alpha=dt)
+                xx[B:].copy_(x)
+                v2 = velocity(t_now - dt)
+                torch.sub(x_keep, v1 + v2, alpha=dt / 2, out=x)
+            xx[B:].copy_(x)
             if save_intermediate:
-                imgs.append(decode(output)[0].float().cpu().detach() if use_vae else output[0].cpu().detach())
+                imgs.append(first_image())
         if save_intermediate:
-            imgs.append(decode(output)[0].float().cpu().detach() if use_vae else output[0].cpu().detach())
-        output = decode(output).float() if use_vae else output
+            imgs.append(first_image())
+        output = decode(x).float()
         return (output, imgs) if save_intermediate else output
 
     # ------------------------------------------------------------------------------------------
