@@ -135,6 +135,17 @@ int mmdit_ln_modulate_bwd(const void* dout, int dout_dtype, const float* x, cons
                           const float* scale, int64_t ld_mod, const float* dres,
                           int rows, int d, int rows_per_batch,
                           float* dx, float* dscale, float* dshift, int64_t ld_dmod, mmdit_stream_t stream);
+/* The same, fused with the backward of the gated residual update that consumes dx next in the backward order
+ * (X_out = acc * gate[b,:] + X_in, blocks/Transformer_Block_Dual.py:64-76; dx = d(X_out)):
+ *   dacc = dx * gate[b,:]  (acc's dtype = dout's dtype),  dgate[b,:] += sum_rows dx * acc,
+ *   dbias[b,:] += sum_rows dacc  (optional: per-batch partial rows of the producing projection's bias gradient).
+ * Replaces ln_modulate_bwd followed by gate_residual_bwd on the same rows. */
+int mmdit_ln_modulate_bwd_gated(const void* dout, int dout_dtype, const float* x, const float* mean, const float* rstd,
+                                const float* scale, int64_t ld_mod, const float* dres,
+                                int rows, int d, int rows_per_batch,
+                                float* dx, float* dscale, float* dshift, int64_t ld_dmod,
+                                const void* acc, int acc_dtype, const float* gate, int64_t ld_gate,
+                                void* dacc, float* dgate, int64_t ld_dgate, float* dbias, int64_t ld_dbias, mmdit_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Text pre-norm: out = scalar * RMSNorm_w(x), eps = FLT_EPSILON (nn.RMSNorm(eps=None) on fp32)

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),
+    "mmdit_ln_modulate_bwd_gated": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], _i),
     "mmdit_text_rmsnorm_fwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),
     "mmdit_text_rmsnorm_bwd": ([_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "mmdit_qk_norm_rope_fwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),

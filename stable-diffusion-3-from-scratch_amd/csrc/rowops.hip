@@ -59,23 +59,35 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
 }
 
 // adaLN backward: block = (batch b, chunk of RCH rows); wave w takes rows w, w+4, ...
+// GATED: the kernel also runs the backward of the gated residual update that CONSUMES dx in the backward order
+// (X_out = acc * gate[b] + X_in, Transformer_Block_Dual.py:64-76: dx is d(X_out)): dacc = dx * gate[b] for the producing GEMM's
+// dgrad / wgrad, dgate[b] += sum_rows dx * acc, dbias[b] += sum_rows dacc (per-batch partial rows of the projection's bias
+// gradient) -- dx is in registers here, so the separate pass over it (mmdit_gate_residual_bwd) disappears.
 constexpr int LN_BWD_RCH = 16;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
-template <int NIT, typename TG>
+template <int NIT, typename TG, typename TA, bool GATED>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
                                                          const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
                                                          const float* __restrict__ dres, int d, int rpb, int nchunk,
-                                                         float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod) {
+                                                         float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod,
+                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, TA* __restrict__ dacc,
+                                                         float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
   const int nch = d >> 2;
   const float* sc = scale + (int64_t)b * ld_mod;
   float a1[NIT][4], ds[NIT][4], dh[NIT][4];
+  float gt[GATED ? NIT : 1][4], sg[GATED ? NIT : 1][4], sb[GATED ? NIT : 1][4];
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     int ch = lane + 64 * it;
     if (ch < nch) { ld4(sc + ch * 4, a1[it]); } else { a1[it][0] = a1[it][1] = a1[it][2] = a1[it][3] = 0.f; }
 #pragma unroll
     for (int e = 0; e < 4; e++) { a1[it][e] += 1.f; ds[it][e] = 0.f; dh[it][e] = 0.f; }
+    if constexpr (GATED) {
+      if (ch < nch) { ld4(gate + (int64_t)b * ld_gate + ch * 4, gt[it]); } else { gt[it][0] = gt[it][1] = gt[it][2] = gt[it][3] = 0.f; }
+#pragma unroll
+      for (int e = 0; e < 4; e++) { sg[it][e] = 0.f; sb[it][e] = 0.f; }
+    }
   }
   const int rend = min(rpb, (chunk + 1) * LN_BWD_RCH);
   for (int rl = chunk * LN_BWD_RCH + wave; rl < rend; rl += 4) {
@@ -109,31 +121,50 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 4; e++) o[e] += rstd * (g[it][e] - c1 - xh[it][e] * c2);
         st4(dx + row * d + ch * 4, o);
+        if constexpr (GATED) {
+          float av[4], da[4];
+          ld4(acc + row * d + ch * 4, av);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { da[e] = o[e] * gt[it][e]; sg[it][e] += o[e] * av[e]; sb[it][e] += da[e]; }
+          st4(dacc + row * d + ch * 4, da);
+        }
       }
     }
   }
-  float* dsb = dscale + (int64_t)b * ld_dmod;
-  float* dhb = dshift + (int64_t)b * ld_dmod;
   if constexpr (NIT <= 6) {
-    // combine the 4 waves in LDS (<= 48 KB), then one atomic per column per block
-    __shared__ float red[2][4][NIT * 256];
+    // combine the 4 waves in LDS (one quantity at a time: <= 24 KB), then one atomic per column per block
+    __shared__ float red[4][NIT * 256];
+    auto flush = [&](const float (&v)[NIT][4], float* dst) {
 #pragma unroll
-    for (int it = 0; it < NIT; it++)
+      for (int it = 0; it < NIT; it++)
 #pragma unroll
-      for (int e = 0; e < 4; e++) { red[0][wave][(it * 64 + lane) * 4 + e] = ds[it][e]; red[1][wave][(it * 64 + lane) * 4 + e] = dh[it][e]; }
-    __syncthreads();
-    for (int c = threadIdx.x; c < d; c += 256) {
-      atomicAdd(dsb + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
-      atomicAdd(dhb + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+        for (int e = 0; e < 4; e++) red[wave][(it * 64 + lane) * 4 + e] = v[it][e];
+      __syncthreads();
+      for (int c = threadIdx.x; c < d; c += 256) atomicAdd(dst + c, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
+      __syncthreads();
+    };
+    flush(ds, dscale + (int64_t)b * ld_dmod);
+    flush(dh, dshift + (int64_t)b * ld_dmod);
+    if constexpr (GATED) {
+      flush(sg, dgate + (int64_t)b * ld_dgate);
+      if (dbias) flush(sb, dbias + (int64_t)b * ld_dbias);   // uniform
     }
   } else {
+    auto flush = [&](const float (&v)[NIT][4], float* dst) {
 #pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      int ch = lane + 64 * it;
-      if (ch < nch) {
+      for (int it = 0; it < NIT; it++) {
+        int ch = lane + 64 * it;
+        if (ch < nch) {
 #pragma unroll
-        for (int e = 0; e < 4; e++) { atomicAdd(dsb + ch * 4 + e, ds[it][e]); atomicAdd(dhb + ch * 4 + e, dh[it][e]); }
+          for (int e = 0; e < 4; e++) atomicAdd(dst + ch * 4 + e, v[it][e]);
+        }
       }
+    };
+    flush(ds, dscale + (int64_t)b * ld_dmod);
+    flush(dh, dshift + (int64_t)b * ld_dmod);
+    if constexpr (GATED) {
+      flush(sg, dgate + (int64_t)b * ld_dgate);
+      if (dbias) flush(sb, dbias + (int64_t)b * ld_dbias);
     }
   }
 }
@@ -708,16 +739,36 @@ extern "C" int mmdit_ln_modulate_fwd(const float* x, const float* scale, const f
   return mmdit_launch_status();
 }
 
+template <typename TG, typename TA, bool GATED>
+static int ln_mod_bwd_launch(const void* dout, const float* x, const float* mean, const float* rstd, const float* scale, int64_t ld_mod, const float* dres,
+                             int rows, int d, int rpb, float* dx, float* dscale, float* dshift, int64_t ld_dmod, const void* acc, const float* gate,
+                             int64_t ld_gate, void* dacc, float* dgate, int64_t ld_dgate, float* dbias, int64_t ld_dbias, hipStream_t s) {
+  const int nit = nit_for(d), nchunk = (rpb + LN_BWD_RCH - 1) / LN_BWD_RCH;
+  dim3 grid((rows / rpb) * nchunk);
+  NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_kernel<NIT, TG, TA, GATED>), grid, dim3(256), 0, s, (const TG*)dout, x, mean, rstd, scale, ld_mod, dres, d, rpb, nchunk,
+                                     dx, dscale, dshift, ld_dmod, (const TA*)acc, gate, ld_gate, (TA*)dacc, dgate, ld_dgate, dbias, ld_dbias));
+  return mmdit_launch_status();
+}
+
 extern "C" int mmdit_ln_modulate_bwd(const void* dout, int dout_dtype, const float* x, const float* mean, const float* rstd, const float* scale, int64_t ld_mod,
                                      const float* dres, int rows, int d, int rpb, float* dx, float* dscale, float* dshift, int64_t ld_dmod, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(dout && x && mean && rstd && scale && dx && dscale && dshift && rows > 0 && d % 4 == 0 && d <= 4096 && rpb > 0 && rows % rpb == 0 && ld_mod % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
-  const int nit = nit_for(d), nchunk = (rpb + LN_BWD_RCH - 1) / LN_BWD_RCH;
-  dim3 grid((rows / rpb) * nchunk);
-  if (dout_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_kernel<NIT, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)dout, x, mean, rstd, scale, ld_mod, dres, d, rpb, nchunk, dx, dscale, dshift, ld_dmod)); }
-  else if (dout_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_kernel<NIT, float>), grid, dim3(256), 0, s, (const float*)dout, x, mean, rstd, scale, ld_mod, dres, d, rpb, nchunk, dx, dscale, dshift, ld_dmod)); }
-  else return MMDIT_ERR_DTYPE;
-  return mmdit_launch_status();
+  if (dout_dtype == MMDIT_BF16) return ln_mod_bwd_launch<bf16_t, bf16_t, false>(dout, x, mean, rstd, scale, ld_mod, dres, rows, d, rpb, dx, dscale, dshift, ld_dmod, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s);
+  if (dout_dtype == MMDIT_F32) return ln_mod_bwd_launch<float, float, false>(dout, x, mean, rstd, scale, ld_mod, dres, rows, d, rpb, dx, dscale, dshift, ld_dmod, nullptr, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, s);
+  return MMDIT_ERR_DTYPE;
+}
+
+extern "C" int mmdit_ln_modulate_bwd_gated(const void* dout, int dout_dtype, const float* x, const float* mean, const float* rstd, const float* scale, int64_t ld_mod,
+                                           const float* dres, int rows, int d, int rpb, float* dx, float* dscale, float* dshift, int64_t ld_dmod,
+                                           const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, void* dacc, float* dgate, int64_t ld_dgate,
+                                           float* dbias, int64_t ld_dbias, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(dout && x && mean && rstd && scale && dx && dscale && dshift && rows > 0 && d % 4 == 0 && d <= 4096 && rpb > 0 && rows % rpb == 0 && ld_mod % 4 == 0);
+  MMDIT_CHECK_ARG(acc && gate && dacc && dgate && ld_gate % 4 == 0 && acc_dtype == dout_dtype);
+  hipStream_t s = (hipStream_t)stream;
+  if (dout_dtype == MMDIT_BF16) return ln_mod_bwd_launch<bf16_t, bf16_t, true>(dout, x, mean, rstd, scale, ld_mod, dres, rows, d, rpb, dx, dscale, dshift, ld_dmod, acc, gate, ld_gate, dacc, dgate, ld_dgate, dbias, ld_dbias, s);
+  if (dout_dtype == MMDIT_F32) return ln_mod_bwd_launch<float, float, true>(dout, x, mean, rstd, scale, ld_mod, dres, rows, d, rpb, dx, dscale, dshift, ld_dmod, acc, gate, ld_gate, dacc, dgate, ld_dgate, dbias, ld_dbias, s);
+  return MMDIT_ERR_DTYPE;
 }
 
 extern "C" int mmdit_text_rmsnorm_fwd(const void* x, int x_dtype, const float* w1, const float* w2, const float* s1, const float* s2,

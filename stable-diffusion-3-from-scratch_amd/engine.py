@@ -302,13 +302,15 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True):
     return X2, C2, sv
 
 
-def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
-    """dX2 (B*N,d) fp32, dC2 (B*M,d) fp32 or None, dy_acc (B,d) fp32 or None.
-    Returns dX, dC, dy_acc', grads (NS keyed like the packed weights).
-    defer_cond: leave the backward of y' = SiLU(W_y y + b) to cond_bwd_all (one launch set for all blocks): the third
-    return value is then this block's modulation gradient in the activation dtype, and grads has no Wy / by."""
+_FUSE_GATE = _os.environ.get("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
+
+
+def block_bwd_begin(m, w, sv, dims, dev, defer_cond=False):
+    """First half of a block's backward set-up: the zeroed arena of its small gradients and its modulation-gradient buffer.
+    Split from block_bwd so that the PRODUCER of this block's incoming residual gradients (the adaLN backward of the following
+    block, or of the output head) can already run the backward of this block's MLP gated-residual update, fused
+    (st.req_x / st.req_c are the operands it needs: see ops.ln_modulate_bwd(gated=...))."""
     B, N, Mt, H, d = dims
-    S, dev = N + Mt, dX2.device
     both = not w.last
     ms = _mod_views(sv.mod, d, w.last)
     g = NS(mlp_x=NS(), mlp_c=NS() if both else None)
@@ -320,24 +322,44 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
     npar = len(shapes)
     shapes += [tuple(sv.mod.shape), (B, nb * d)]
     zs, small_arena = _zeros_views(shapes, dev, prefix=npar)
-    bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c = zs[:6]
+    st = NS(g=g, ms=ms, zs=zs, npar=npar, small_arena=small_arena, both=both)
+    st.bdown, g.mlp_x.bup, g.wq_x, g.wk_x, g.wq_c, g.wk_c = zs[:6]
     if not defer_cond:
         g.by = zs[npar - 1]
-    dmod, bpart = zs[npar], zs[npar + 1]   # bpart: per-batch partial rows of the down-proj bias grads
-    g.mlp_x.bdown = bdown[:d]
+    st.dmod, st.bpart = zs[npar], zs[npar + 1]   # bpart: per-batch partial rows of the down-proj bias grads
+    g.mlp_x.bdown = st.bdown[:d]
     if both:
-        g.mlp_c.bdown, g.mlp_c.bup = bdown[d:], zs[6]
-    dms = _mod_views(dmod, d, w.last)
+        g.mlp_c.bdown, g.mlp_c.bup = st.bdown[d:], zs[6]
+    st.dms = _mod_views(st.dmod, d, w.last)
+    st.req_x = (sv.acc_mx, ms.gate2x, st.dms.gate2x, st.bpart[:, :d])
+    st.req_c = (sv.acc_mc, ms.gate2c, st.dms.gate2c, st.bpart[:, d:]) if both else None
+    return st
+
+
+def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None, dacc=None, nxt=None):
+    """dX2 (B*N,d) fp32, dC2 (B*M,d) fp32 or None, dy_acc (B,d) fp32 or None.
+    Returns dX, dC, dy_acc', grads (NS keyed like the packed weights).
+    defer_cond: leave the backward of y' = SiLU(W_y y + b) to cond_bwd_all (one launch set for all blocks): the third
+    return value is then this block's modulation gradient in the activation dtype, and grads has no Wy / by.
+    Fused gate chain (model_bwd): st = block_bwd_begin(...) of this block, dacc = (dacc_x, dacc_c) already formed by the producer of
+    dX2 / dC2, nxt = the begin-state of the block that consumes dX / dC; a fifth value, that block's (dacc_x, dacc_c), is returned."""
+    B, N, Mt, H, d = dims
+    S, dev = N + Mt, dX2.device
+    both = not w.last
+    if st is None:
+        st = block_bwd_begin(m, w, sv, dims, dev, defer_cond)
+    g, ms, dms, bpart, bdown, dmod = st.g, st.ms, st.dms, st.bpart, st.bdown, st.dmod
     pending = []   # deferred weight-gradient GEMMs: (setter, descriptor)
+    fuse = _FUSE_GATE
 
     def defer(ns, name, dY, Xa):
         pending.append((lambda o, ns=ns, name=name: setattr(ns, name, o), _wg(dY, Xa)))
 
     # ---- MLP: gated residual -> down-proj -> activation -> up-proj -> adaLN
-    dacc_x = ops.gate_residual_bwd(dX2, sv.acc_mx, ms.gate2x, N, dms.gate2x, bpart[:, :d], m.T)
+    dacc_x = dacc[0] if dacc is not None else ops.gate_residual_bwd(dX2, sv.acc_mx, ms.gate2x, N, dms.gate2x, bpart[:, :d], m.T)
     probs = [dict(A=dacc_x, B=w.mlp_x.Wdown, b_kmajor=True, out_dtype=m.T)]
     if both:
-        dacc_c = ops.gate_residual_bwd(dC2, sv.acc_mc, ms.gate2c, Mt, dms.gate2c, bpart[:, d:], m.T)
+        dacc_c = dacc[1] if dacc is not None else ops.gate_residual_bwd(dC2, sv.acc_mc, ms.gate2c, Mt, dms.gate2c, bpart[:, d:], m.T)
         probs.append(dict(A=dacc_c, B=w.mlp_c.Wdown, b_kmajor=True, out_dtype=m.T))
     ops.colsum(bpart, bdown)   # finish both bias gradients: sum the per-batch partial rows
     dh = _group(m, probs)
@@ -351,15 +373,24 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
         probs.append(dict(A=dgu_c, B=w.mlp_c.Wup, b_kmajor=True, out_dtype=m.T))
         defer(g.mlp_c, "Wup", dgu_c, sv.ln2c)
     dln2 = _group(m, probs)
-    dX1 = ops.ln_modulate_bwd(dln2[0], sv.X1, sv.mu2x, sv.rs2x, ms.scale2x, dX2, N, dms.scale2x, dms.shift2x)
-    dC1 = ops.ln_modulate_bwd(dln2[1], sv.C1, sv.mu2c, sv.rs2c, ms.scale2c, dC2, Mt, dms.scale2c, dms.shift2c) if both else dC2
 
-    # ---- attention output projections (gated residual)
-    dacc_x = ops.gate_residual_bwd(dX1, sv.acc_ox, ms.gate1x, N, dms.gate1x, None, m.T)
+    # ---- adaLN backward (fused with the backward of the attention-output gated residual) -> attention output projections
+    if fuse:
+        dX1, dacc_x = ops.ln_modulate_bwd(dln2[0], sv.X1, sv.mu2x, sv.rs2x, ms.scale2x, dX2, N, dms.scale2x, dms.shift2x,
+                                          gated=(sv.acc_ox, ms.gate1x, dms.gate1x, None))
+    else:
+        dX1 = ops.ln_modulate_bwd(dln2[0], sv.X1, sv.mu2x, sv.rs2x, ms.scale2x, dX2, N, dms.scale2x, dms.shift2x)
+        dacc_x = ops.gate_residual_bwd(dX1, sv.acc_ox, ms.gate1x, N, dms.gate1x, None, m.T)
     probs = [dict(A=dacc_x, B=w.Wo_x, b_kmajor=True, out_dtype=BF16)]
     defer(g, "Wo_x", dacc_x, sv.Oxa)
+    dC1 = dC2
     if both:
-        dacc_c = ops.gate_residual_bwd(dC1, sv.acc_oc, ms.gate1c, Mt, dms.gate1c, None, m.T)
+        if fuse:
+            dC1, dacc_c = ops.ln_modulate_bwd(dln2[1], sv.C1, sv.mu2c, sv.rs2c, ms.scale2c, dC2, Mt, dms.scale2c, dms.shift2c,
+                                              gated=(sv.acc_oc, ms.gate1c, dms.gate1c, None))
+        else:
+            dC1 = ops.ln_modulate_bwd(dln2[1], sv.C1, sv.mu2c, sv.rs2c, ms.scale2c, dC2, Mt, dms.scale2c, dms.shift2c)
+            dacc_c = ops.gate_residual_bwd(dC1, sv.acc_oc, ms.gate1c, Mt, dms.gate1c, None, m.T)
         probs.append(dict(A=dacc_c, B=w.Wo_c, b_kmajor=True, out_dtype=BF16))
         defer(g, "Wo_c", dacc_c, sv.Oca)
     dO = _group(m, probs)
@@ -372,8 +403,15 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
     dln1 = _group(m, [dict(A=dqkv_x, B=w.Wqkv_x, b_kmajor=True, out_dtype=m.T), dict(A=dqkv_c, B=w.Wqkv_c, b_kmajor=True, out_dtype=m.T)])
     defer(g, "Wqkv_x", dqkv_x, sv.ln1x)
     defer(g, "Wqkv_c", dqkv_c, sv.ln1c)
-    dX = ops.ln_modulate_bwd(dln1[0], sv.X, sv.mu1x, sv.rs1x, ms.scale1x, dX1, N, dms.scale1x, dms.shift1x)
-    dC = ops.ln_modulate_bwd(dln1[1], sv.C, sv.mu1c, sv.rs1c, ms.scale1c, dC1, Mt, dms.scale1c, dms.shift1c)
+    # the adaLN backward that produces dX / dC also runs the gated-residual backward of the block that consumes them
+    nacc = None
+    if nxt is not None and fuse:
+        dX, nax = ops.ln_modulate_bwd(dln1[0], sv.X, sv.mu1x, sv.rs1x, ms.scale1x, dX1, N, dms.scale1x, dms.shift1x, gated=nxt.req_x)
+        dC, nac = ops.ln_modulate_bwd(dln1[1], sv.C, sv.mu1c, sv.rs1c, ms.scale1c, dC1, Mt, dms.scale1c, dms.shift1c, gated=nxt.req_c)
+        nacc = (nax, nac)
+    else:
+        dX = ops.ln_modulate_bwd(dln1[0], sv.X, sv.mu1x, sv.rs1x, ms.scale1x, dX1, N, dms.scale1x, dms.shift1x)
+        dC = ops.ln_modulate_bwd(dln1[1], sv.C, sv.mu1c, sv.rs1c, ms.scale1c, dC1, Mt, dms.scale1c, dms.shift1c)
 
     # ---- modulation vectors and y_proj
     dmod_a = m.act(dmod)
@@ -388,7 +426,9 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False):
 
     wg_arena = _wgrad_flush(m, pending)   # all weight gradients of the block in one grouped launch
     # every parameter gradient of the block lives in one of these two flat buffers (None: not the case, e.g. overlap off)
-    g.arenas = [wg_arena, small_arena] if wg_arena is not None else None
+    g.arenas = [wg_arena, st.small_arena] if wg_arena is not None else None
+    if nxt is not None:
+        return dX, dC, dy_acc, g, nacc
     return dX, dC, dy_acc, g
 
 
@@ -483,17 +523,32 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     dlnf = _dgrad(m, dZ, W.Wout, m.T)
     defer("Wout", dZ, sv.lnf)
     dmodo = ops.zeros(sv.modo.shape, dev) if sv.modo.dtype == F32 else torch.zeros_like(sv.modo)
-    dX = ops.ln_modulate_bwd(dlnf, sv.Xf, sv.muf, sv.rsf, sv.modo[:, d:], None, N, dmodo[:, d:], dmodo[:, :d])
+    nblk = len(W.blocks)
+    # fused gate chain: every adaLN backward that produces a residual-stream gradient also runs the gated-residual backward of
+    # its consumer (block_bwd_begin / block_bwd): the output head's for the last block's MLP update, block i's for block i-1's
+    sts = [None] * nblk
+    sts[nblk - 1] = block_bwd_begin(m, W.blocks[-1], sv.blocks[-1], sv.dims, dev, defer_cond=True)
+    dacc = None
+    if _FUSE_GATE:
+        dX, dax = ops.ln_modulate_bwd(dlnf, sv.Xf, sv.muf, sv.rsf, sv.modo[:, d:], None, N, dmodo[:, d:], dmodo[:, :d], gated=sts[-1].req_x)
+        dacc = (dax, None)
+    else:
+        dX = ops.ln_modulate_bwd(dlnf, sv.Xf, sv.muf, sv.rsf, sv.modo[:, d:], None, N, dmodo[:, d:], dmodo[:, :d])
     dmodo_a = m.act(dmodo)
     dy_acc = _dgrad(m, dmodo_a, W.Wmod_out, F32, **({"split_k": 4} if m.fast else {}))
     defer("Wmod_out", dmodo_a, sv.y)
 
     dC = None
-    nblk = len(W.blocks)
     g.blocks = [None] * nblk
     dmods = [None] * nblk
     for i in range(nblk - 1, -1, -1):
-        dX, dC, dmods[i], g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, None, sv.dims, rope, defer_cond=True)
+        if i > 0:
+            sts[i - 1] = block_bwd_begin(m, W.blocks[i - 1], sv.blocks[i - 1], sv.dims, dev, defer_cond=True)
+            dX, dC, dmods[i], g.blocks[i], dacc = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, None, sv.dims, rope, defer_cond=True,
+                                                            st=sts[i], dacc=dacc, nxt=sts[i - 1])
+        else:
+            dX, dC, dmods[i], g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, None, sv.dims, rope, defer_cond=True, st=sts[i], dacc=dacc)
+        sts[i] = None
         sv.blocks[i] = None  # free saved activations as we go
         if on_grads is not None:
             # the reducer may hand back views of its flat bucket (zero copy-back): use them as this block's gradients

@@ -249,13 +249,23 @@ def ln_modulate_fwd(x, scale, shift, rows_per_batch, out_dtype):
     return out, mean, rstd
 
 
-def ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rows_per_batch, dscale, dshift):
-    """Returns dx (fp32) = dres + LN-backward; accumulates into the dscale / dshift views (same leading dim)."""
+def ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rows_per_batch, dscale, dshift, gated=None):
+    """Returns dx (fp32) = dres + LN-backward; accumulates into the dscale / dshift views (same leading dim).
+    gated = (acc, gate, dgate, dbias | None): also run the backward of the gated residual update that consumes dx
+    (mmdit_ln_modulate_bwd_gated) and return (dx, dacc) with dacc = dx * gate in acc's dtype."""
     rows, d = x.shape
     dx = torch.empty((rows, d), dtype=torch.float32, device=x.device)
-    check(_lib.lib().mmdit_ln_modulate_bwd(_p(_c(dout)), _dt(dout), _p(x), _p(mean), _p(rstd), _p(scale), scale.stride(0), _p(dres),
-                                           rows, d, rows_per_batch, _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _s()), "mmdit_ln_modulate_bwd")
-    return dx
+    if gated is None:
+        check(_lib.lib().mmdit_ln_modulate_bwd(_p(_c(dout)), _dt(dout), _p(x), _p(mean), _p(rstd), _p(scale), scale.stride(0), _p(dres),
+                                               rows, d, rows_per_batch, _p(dx), _p(dscale), _p(dshift), dscale.stride(0), _s()), "mmdit_ln_modulate_bwd")
+        return dx
+    acc, gate, dgate, dbias = gated
+    dacc = torch.empty((rows, d), dtype=acc.dtype, device=x.device)
+    check(_lib.lib().mmdit_ln_modulate_bwd_gated(_p(_c(dout)), _dt(dout), _p(x), _p(mean), _p(rstd), _p(scale), scale.stride(0), _p(dres),
+                                                 rows, d, rows_per_batch, _p(dx), _p(dscale), _p(dshift), dscale.stride(0),
+                                                 _p(_c(acc)), _dt(acc), _p(gate), gate.stride(0), _p(dacc), _p(dgate), dgate.stride(0),
+                                                 _p(dbias), dbias.stride(0) if dbias is not None else 0, _s()), "mmdit_ln_modulate_bwd_gated")
+    return dx, dacc
 
 
 def text_rmsnorm_fwd(x, w1, w2, s1, s2, split, out_dtype):

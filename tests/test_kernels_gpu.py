@@ -212,6 +212,28 @@ def test_mlp_act(ops, dt, gelu):
     assert rel(db, gr.grad.sum(0)) < (2e-5 if dt == torch.float32 else 5e-3)
 
 
+@pytest.mark.parametrize("d,rpb,Bt", [(768, 256, 3), (256, 154, 2), (1024, 77, 2)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_ln_modulate_bwd_gated_equals_unfused_pair(ops, d, rpb, Bt, dt):
+    """mmdit_ln_modulate_bwd_gated == mmdit_ln_modulate_bwd followed by mmdit_gate_residual_bwd on its dx: dx, dacc bit-identical
+    (same fp32 expressions, same rounding to the activation dtype); the atomically accumulated column sums to fp32 round-off."""
+    rows = Bt * rpb
+    x = rnd(rows, d, seed=1) * 2 + 0.5
+    mod = rnd(Bt, 6 * d, seed=2, scale=0.3)
+    scale, shift, gate = mod[:, d:2 * d], mod[:, 3 * d:4 * d], mod[:, 5 * d:]
+    _, mean, rstd = ops.ln_modulate_fwd(x, scale, shift, rpb, dt)
+    dout, dres, acc = rnd(rows, d, seed=3).to(dt), rnd(rows, d, seed=4), rnd(rows, d, seed=5).to(dt)
+    dm0, dg0, db0 = torch.zeros((Bt, 2 * d), device="cuda"), torch.zeros((Bt, 2 * d), device="cuda"), torch.zeros((Bt, d), device="cuda")
+    dx0 = ops.ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rpb, dm0[:, :d], dm0[:, d:])
+    dacc0 = ops.gate_residual_bwd(dx0, acc, gate, rpb, dg0[:, d:], db0, dt)
+    for with_bias in (True, False):
+        dm1, dg1, db1 = torch.zeros((Bt, 2 * d), device="cuda"), torch.zeros((Bt, 2 * d), device="cuda"), torch.zeros((Bt, d), device="cuda")
+        dx1, dacc1 = ops.ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rpb, dm1[:, :d], dm1[:, d:], gated=(acc, gate, dg1[:, d:], db1 if with_bias else None))
+        assert torch.equal(dx1, dx0) and torch.equal(dacc1, dacc0) and dacc1.dtype == dt
+        assert rel(dm1, dm0) < 1e-6 and rel(dg1, dg0) < 2e-6 and float(dg1[:, :d].abs().max()) == 0.0
+        assert rel(db1, db0) < 2e-6 if with_bias else float(db1.abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_gate_residual_bwd_colsum_silu(ops, dt):
     Bt, rpb, d = 3, 154, 768
