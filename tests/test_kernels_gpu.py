@@ -215,8 +215,9 @@ def test_mlp_act(ops, dt, gelu):
 @pytest.mark.parametrize("d,rpb,Bt", [(768, 256, 3), (256, 154, 2), (1024, 77, 2)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_ln_modulate_bwd_gated_equals_unfused_pair(ops, d, rpb, Bt, dt):
-    """mmdit_ln_modulate_bwd_gated == mmdit_ln_modulate_bwd followed by mmdit_gate_residual_bwd on its dx: dx, dacc bit-identical
-    (same fp32 expressions, same rounding to the activation dtype); the atomically accumulated column sums to fp32 round-off."""
+    """mmdit_ln_modulate_bwd_gated == mmdit_ln_modulate_bwd followed by mmdit_gate_residual_bwd on its dx, to fp32 round-off (the
+    compiler contracts a*b+c differently in the two instantiations, so dx may differ in the last bit and dacc by one rounding of
+    the activation dtype on a few elements); the atomically accumulated column sums likewise."""
     rows = Bt * rpb
     x = rnd(rows, d, seed=1) * 2 + 0.5
     mod = rnd(Bt, 6 * d, seed=2, scale=0.3)
@@ -229,7 +230,8 @@ def test_ln_modulate_bwd_gated_equals_unfused_pair(ops, d, rpb, Bt, dt):
     for with_bias in (True, False):
         dm1, dg1, db1 = torch.zeros((Bt, 2 * d), device="cuda"), torch.zeros((Bt, 2 * d), device="cuda"), torch.zeros((Bt, d), device="cuda")
         dx1, dacc1 = ops.ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rpb, dm1[:, :d], dm1[:, d:], gated=(acc, gate, dg1[:, d:], db1 if with_bias else None))
-        assert torch.equal(dx1, dx0) and torch.equal(dacc1, dacc0) and dacc1.dtype == dt
+        assert dacc1.dtype == dt and rel(dx1, dx0) < 1e-6 and rel(dacc1, dacc0) < (1e-6 if dt == torch.float32 else 5e-4)
+        assert float((dacc1.float() - dacc0.float()).abs().max()) <= 2.0 ** -7 * float(dacc0.float().abs().max())     # at most one bf16 ulp anywhere
         assert rel(dm1, dm0) < 1e-6 and rel(dg1, dg0) < 2e-6 and float(dg1[:, :d].abs().max()) == 0.0
         assert rel(db1, db0) < 2e-6 if with_bias else float(db1.abs().max()) == 0.0
 
