@@ -185,7 +185,8 @@ def test_l_train_step_with_vae_encode_in_the_loop():
     imgs = torch.rand((B, 3, 512, 512), generator=g, device=dev) * 2 - 1
     text = torch.randn((B, 154, 2304), generator=g, device=dev).to(torch.bfloat16)
     pooled = torch.randn((B, 768), generator=g, device=dev).to(torch.bfloat16)
-    vae = VAE_inference(dev)
+    from oracle import vae_oracle as V
+    vae = VAE_inference(dev, state_dict=V.make_state_dict(0, V.VAEConfig()))     # seeded synthetic FLUX-VAE weights (the real ones are not on this box)
 
     def images():
         return imgs, text.clone(), pooled.clone()
