@@ -131,6 +131,16 @@ int mmdit_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t
 int mmdit_ln_modulate_fwd(const float* x, const float* scale, const float* shift, int64_t ld_mod,
                           int rows, int d, int rows_per_batch,
                           void* out, int out_dtype, float* mean, float* rstd, mmdit_stream_t stream);
+/* adaLN forward fused with the gated residual update that PRODUCES its input (blocks/Transformer_Block_Dual.py:64-76):
+ *   x_out = x + gate[b,:] * acc   (acc = the projection GEMM's output in the activation dtype, gate fp32 (batch, ld_gate));
+ *   out = LayerNorm(x_out) * (1 + scale[b,:]) + shift[b,:].
+ * The projection GEMM then needs no fp32 gate/residual epilogue.  mmdit_gate_residual_fwd is the update on its own. */
+int mmdit_ln_modulate_fwd_res(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, float* x_out,
+                              const float* scale, const float* shift, int64_t ld_mod,
+                              int rows, int d, int rows_per_batch,
+                              void* out, int out_dtype, float* mean, float* rstd, mmdit_stream_t stream);
+int mmdit_gate_residual_fwd(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate,
+                            int rows, int d, int rows_per_batch, float* out, mmdit_stream_t stream);
 int mmdit_ln_modulate_bwd(const void* dout, int dout_dtype, const float* x, const float* mean, const float* rstd,
                           const float* scale, int64_t ld_mod, const float* dres,
                           int rows, int d, int rows_per_batch,

@@ -287,15 +287,17 @@ def block(X, c, y, sd, i: int, cfg: OracleConfig, hw, taps: Optional[dict] = Non
     a_x, a_c = attention(n1x, n1c, sd, p + "attn.", cfg, hw, last, taps)
     if taps is not None:
         taps.update(y_proj=y.detach(), norm1_x=n1x.detach(), norm1_c=n1c.detach(), attn_x=a_x.detach(), attn_c=a_c.detach())
-    X = a_x * gate("scale1_x") + X
+    # (_act: in the bf16 / fp8 rounding-matched modes the HIP fast path stores the projection outputs in bf16 and forms the gated
+    #  residual update from the stored value, in the consumer's adaLN kernel; identity in the reference-exact fp32 mode)
+    X = _act(cfg, a_x) * gate("scale1_x") + X
     if not last:
-        c = a_c * gate("scale1_c") + c
+        c = _act(cfg, a_c) * gate("scale1_c") + c
     m_x = mlp(nrm(X, "norm2_x"), sd, p + "MLP_x.", cfg)
     if taps is not None:
         taps["mlp_x"] = m_x.detach()
-    X = m_x * gate("scale2_x") + X
+    X = _act(cfg, m_x) * gate("scale2_x") + X
     if not last:
-        c = mlp(nrm(c, "norm2_c"), sd, p + "MLP_c.", cfg) * gate("scale2_c") + c
+        c = _act(cfg, mlp(nrm(c, "norm2_c"), sd, p + "MLP_c.", cfg)) * gate("scale2_c") + c
     return X, c
 
 

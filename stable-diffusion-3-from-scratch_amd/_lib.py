@@ -51,6 +51,8 @@ _SIGNATURES = {
     "mmdit_fp8_quantize_delayed": ([_vp, _i, _i64, _vp, _i, ctypes.c_float, _vp, _vp], _i),
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
+    "mmdit_ln_modulate_fwd_res": ([_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
+    "mmdit_gate_residual_fwd": ([_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp], _i),
     "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),
     "mmdit_ln_modulate_bwd_gated": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], _i),
     "mmdit_text_rmsnorm_fwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp], _i),

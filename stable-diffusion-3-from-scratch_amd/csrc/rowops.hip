@@ -13,20 +13,37 @@ constexpr float RMS_EPS = FLT_EPSILON;    // nn.RMSNorm(eps=None) on fp32 input
 // -------------------------------------------------------------------------------------------
 // adaLN forward: one wave per row, the row is kept in registers (NIT float4 per lane).
 // -------------------------------------------------------------------------------------------
-template <int NIT, typename TO>
+// RES: the row entering the norm is x + gate[b] * acc -- the gated residual update that PRODUCES the normed tensor
+// (X_out = acc * gate + X_in, Transformer_Block_Dual.py:64-76) is formed here, where the row is in registers anyway, instead of
+// in the fp32 epilogue of the projection GEMM (which then only writes acc in the activation dtype); the updated residual
+// stream row is written to xo (it is the next residual input and the x of the backward pass).
+template <int NIT, typename TO, typename TA, bool RES>
 __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                          int64_t ld_mod, int rows, int d, int rpb, TO* __restrict__ out,
-                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o) {
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, float* __restrict__ xo) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = d >> 2;
+  const int b = row / rpb;
   const float* xr = x + (int64_t)row * d;
   float v[NIT][4];
   float s = 0.f;
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
     int ch = lane + 64 * it;
-    if (ch < nch) { ld4(xr + ch * 4, v[it]); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
+    if (ch < nch) {
+      ld4(xr + ch * 4, v[it]);
+      if constexpr (RES) {
+        float av[4], g[4];
+        ld4(acc + (int64_t)row * d + ch * 4, av);
+        ld4(gate + (int64_t)b * ld_gate + ch * 4, g);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[it][e] = v[it][e] + g[e] * av[e];
+        st4(xo + (int64_t)row * d + ch * 4, v[it]);
+      }
+      s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+    }
     else { v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f; }
   }
   const float mean = wave_sum(s) / d;
@@ -41,7 +58,6 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
   }
   const float rstd = rsqrtf(wave_sum(q) / d + LN_EPS);
   if (lane == 0) { mean_o[row] = mean; rstd_o[row] = rstd; }
-  const int b = row / rpb;
   const float* sc = scale + (int64_t)b * ld_mod;
   const float* sh = shift + (int64_t)b * ld_mod;
   TO* orow = out + (int64_t)row * d;
@@ -55,6 +71,23 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
       for (int e = 0; e < 4; e++) o[e] = (v[it][e] - mean) * rstd * (1.f + a[e]) + h[e];
       st4(orow + ch * 4, o);
     }
+  }
+}
+
+// out = x + gate[b] * acc (the gated residual update on its own: used where no norm consumes the result)
+template <typename TA>
+__global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __restrict__ x, const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate,
+                                                                int rows, int d, int rpb, float* __restrict__ out) {
+  const int nch = d >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)rows * nch; i += (int64_t)gridDim.x * 256) {
+    const int row = (int)(i / nch), ch = (int)(i - (int64_t)row * nch);
+    float xv[4], av[4], g[4];
+    ld4(x + (int64_t)row * d + ch * 4, xv);
+    ld4(acc + (int64_t)row * d + ch * 4, av);
+    ld4(gate + (int64_t)(row / rpb) * ld_gate + ch * 4, g);
+#pragma unroll
+    for (int e = 0; e < 4; e++) xv[e] = xv[e] + g[e] * av[e];
+    st4(out + (int64_t)row * d + ch * 4, xv);
   }
 }
 
@@ -733,8 +766,33 @@ extern "C" int mmdit_ln_modulate_fwd(const float* x, const float* scale, const f
   hipStream_t s = (hipStream_t)stream;
   const int nit = nit_for(d);
   dim3 grid((rows + 3) / 4);
-  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, bf16_t>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd)); }
-  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, float>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd)); }
+  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, bf16_t, bf16_t, false>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd, nullptr, nullptr, 0, nullptr)); }
+  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, float, float, false>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd, nullptr, nullptr, 0, nullptr)); }
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_ln_modulate_fwd_res(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, float* x_out,
+                                         const float* scale, const float* shift, int64_t ld_mod, int rows, int d, int rpb,
+                                         void* out, int out_dtype, float* mean, float* rstd, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && acc && gate && x_out && scale && shift && out && mean && rstd && rows > 0 && d > 0 && d % 4 == 0 && d <= 4096 && rpb > 0 && ld_mod % 4 == 0 && ld_gate % 4 == 0);
+  MMDIT_CHECK_ARG(acc_dtype == out_dtype);
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d);
+  dim3 grid((rows + 3) / 4);
+  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, bf16_t, bf16_t, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd, (const bf16_t*)acc, gate, ld_gate, x_out)); }
+  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, float, float, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd, (const float*)acc, gate, ld_gate, x_out)); }
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_gate_residual_fwd(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, int rows, int d, int rpb,
+                                       float* out, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && acc && gate && out && rows > 0 && d > 0 && d % 4 == 0 && rpb > 0 && ld_gate % 4 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(grid_cap((int64_t)rows * (d / 4), 256));
+  if (acc_dtype == MMDIT_BF16) hipLaunchKernelGGL((gate_residual_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, x, (const bf16_t*)acc, gate, ld_gate, rows, d, rpb, out);
+  else if (acc_dtype == MMDIT_F32) hipLaunchKernelGGL((gate_residual_fwd_kernel<float>), grid, dim3(256), 0, s, x, (const float*)acc, gate, ld_gate, rows, d, rpb, out);
   else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }

@@ -230,14 +230,36 @@ def cond_fwd_all(m, blocks, y):
     return [(pres[i], yps[i], mods[i]) for i in range(nb)], pre_all
 
 
-def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True):
-    """X (B*N,d) fp32, C (B*M,d) fp32, y (B,d) in m.T.  cond: this block's (pre, yp, mod) from cond_fwd_all.
-    keep=False (inference): the backward-only GEMM side outputs (pre-gate accumulators, SwiGLU pre-activations) are not written.
+class Pending:
+    """A residual stream whose last gated update is still pending: value = x + gate[b] * acc (acc None: value = x).  The update is
+    formed inside the next adaLN forward kernel that reads the stream (ops.ln_modulate_fwd_res), not in the fp32 epilogue of the
+    projection GEMM that produced acc."""
+    __slots__ = ("x", "acc", "gate", "rpb")
+
+    def __init__(self, x, acc=None, gate=None, rpb=0):
+        self.x, self.acc, self.gate, self.rpb = x, acc, gate, rpb
+
+    def value(self):
+        return self.x if self.acc is None else ops.gate_residual_fwd(self.x, self.acc, self.gate, self.rpb)
+
+
+def _norm(m, P, scale, shift, rpb):
+    """adaLN of a (possibly pending) residual stream: returns (materialised stream fp32, normed, mean, rstd)."""
+    if isinstance(P, Pending) and P.acc is not None:
+        return ops.ln_modulate_fwd_res(P.x, P.acc, P.gate, scale, shift, rpb, m.T)
+    x = P.x if isinstance(P, Pending) else P
+    return (x,) + ops.ln_modulate_fwd(x, scale, shift, rpb, m.T)
+
+
+def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
+    """X (B*N,d) fp32, C (B*M,d) fp32 (or Pending streams), y (B,d) in m.T.  cond: this block's (pre, yp, mod) from cond_fwd_all.
+    keep=False (inference): the backward-only GEMM side outputs (SwiGLU pre-activations) are not written.
+    lazy=True: return the outputs as Pending streams (their MLP residual update is left to the consumer's adaLN kernel).
     Returns X2, C2, saved."""
     B, N, Mt, H, d = dims
-    S, dev = N + Mt, X.device
+    S, dev = N + Mt, (X.x if isinstance(X, Pending) else X).device
     both = not w.last
-    sv = NS(X=X, C=C, y=y)
+    sv = NS(y=y)
     if cond is not None:
         sv.pre, sv.yp, sv.mod = cond
     else:
@@ -246,8 +268,8 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True):
         sv.mod = _gemm(m, sv.yp, w.Wmod, out_dtype=F32)
     ms = _mod_views(sv.mod, d, w.last)
 
-    sv.ln1x, sv.mu1x, sv.rs1x = ops.ln_modulate_fwd(X, ms.scale1x, ms.shift1x, N, m.T)
-    sv.ln1c, sv.mu1c, sv.rs1c = ops.ln_modulate_fwd(C, ms.scale1c, ms.shift1c, Mt, m.T)
+    sv.X, sv.ln1x, sv.mu1x, sv.rs1x = _norm(m, X, ms.scale1x, ms.shift1x, N)
+    sv.C, sv.ln1c, sv.mu1c, sv.rs1c = _norm(m, C, ms.scale1c, ms.shift1c, Mt)
     sv.qkv_x, sv.qkv_c = _group(m, [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T)], fp8=True)
     sv.Q = torch.empty((B, H, S, 64), dtype=BF16, device=dev)
     sv.K, sv.V = torch.empty_like(sv.Q), torch.empty_like(sv.Q)
@@ -255,18 +277,15 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True):
     ops.qk_norm_rope_fwd(sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, sv.Q, sv.K, sv.V)
     sv.Ox, sv.Oc, sv.lse = ops.attn_fwd(sv.Q, sv.K, sv.V, N, 64 ** -0.5, m.attn_mode)
 
+    # attention output projections: the GEMM writes acc in the activation dtype; X1 = X + gate1 * acc is formed by norm2's kernel
     sv.Oxa = m.act(sv.Ox.view(B * N, d))
-    sv.acc_ox = torch.empty((B * N, d), dtype=m.T, device=dev) if keep else None
-    probs = [dict(A=sv.Oxa, B=w.Wo_x, gate=ms.gate1x, rows_per_batch=N, residual=X, aux=sv.acc_ox, out_dtype=F32)]
+    probs = [dict(A=sv.Oxa, B=w.Wo_x, out_dtype=m.T)]
     if both:
         sv.Oca = m.act(sv.Oc.view(B * Mt, d))
-        sv.acc_oc = torch.empty((B * Mt, d), dtype=m.T, device=dev) if keep else None
-        probs.append(dict(A=sv.Oca, B=w.Wo_c, gate=ms.gate1c, rows_per_batch=Mt, residual=C, aux=sv.acc_oc, out_dtype=F32))
+        probs.append(dict(A=sv.Oca, B=w.Wo_c, out_dtype=m.T))
     outs = _group(m, probs, fp8=True)
-    X1, C1 = outs[0], (outs[1] if both else C)
-    sv.X1, sv.C1 = X1, C1
-
-    sv.ln2x, sv.mu2x, sv.rs2x = ops.ln_modulate_fwd(X1, ms.scale2x, ms.shift2x, N, m.T)
+    sv.acc_ox = outs[0]
+    sv.X1, sv.ln2x, sv.mu2x, sv.rs2x = ops.ln_modulate_fwd_res(sv.X, sv.acc_ox, ms.gate1x, ms.scale2x, ms.shift2x, N, m.T)
     # SwiGLU in the up-projection's epilogue (bf16 mode, hidden % 128 == 0, K % 64 == 0): the GEMM writes the pre-activations and
     # the activation; otherwise (GELU, parity / fp8 mode, odd sizes) the activation is a row kernel over the GEMM output
     fuse = _FUSE_SWIGLU and m.fast and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % (128 if m.fp8 else 64) == 0
@@ -277,8 +296,10 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True):
         return dict(A=xn, B=mw.Wup, bias=mw.bup, out_dtype=m.T)
 
     probs = [up(sv.ln2x, w.mlp_x, B * N)]
+    sv.C1 = sv.C
     if both:
-        sv.ln2c, sv.mu2c, sv.rs2c = ops.ln_modulate_fwd(C1, ms.scale2c, ms.shift2c, Mt, m.T)
+        sv.acc_oc = outs[1]
+        sv.C1, sv.ln2c, sv.mu2c, sv.rs2c = ops.ln_modulate_fwd_res(sv.C, sv.acc_oc, ms.gate1c, ms.scale2c, ms.shift2c, Mt, m.T)
         probs.append(up(sv.ln2c, w.mlp_c, B * Mt))
     outs = _group(m, probs, fp8=True)
     pre = [p.get("aux") for p in probs]
@@ -287,18 +308,24 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True):
     else:
         sv.gu_x = outs[0]
         sv.h_x = ops.mlp_act_fwd(sv.gu_x, w.mlp_x.hidden, w.mlp_x.gelu)
-    sv.acc_mx = torch.empty((B * N, d), dtype=m.T, device=dev) if keep else None
-    probs = [dict(A=sv.h_x, B=w.mlp_x.Wdown, bias=w.mlp_x.bdown, gate=ms.gate2x, rows_per_batch=N, residual=X1, aux=sv.acc_mx, out_dtype=F32)]
+    probs = [dict(A=sv.h_x, B=w.mlp_x.Wdown, bias=w.mlp_x.bdown, out_dtype=m.T)]
     if both:
         if fuse:
             sv.gu_c, sv.h_c = pre[1], outs[1]
         else:
             sv.gu_c = outs[1]
             sv.h_c = ops.mlp_act_fwd(sv.gu_c, w.mlp_c.hidden, w.mlp_c.gelu)
-        sv.acc_mc = torch.empty((B * Mt, d), dtype=m.T, device=dev) if keep else None
-        probs.append(dict(A=sv.h_c, B=w.mlp_c.Wdown, bias=w.mlp_c.bdown, gate=ms.gate2c, rows_per_batch=Mt, residual=C1, aux=sv.acc_mc, out_dtype=F32))
+        probs.append(dict(A=sv.h_c, B=w.mlp_c.Wdown, bias=w.mlp_c.bdown, out_dtype=m.T))
     outs = _group(m, probs, fp8=True)
-    X2, C2 = outs[0], (outs[1] if both else C1)
+    sv.acc_mx = outs[0]
+    X2 = Pending(sv.X1, sv.acc_mx, ms.gate2x, N)
+    if both:
+        sv.acc_mc = outs[1]
+        C2 = Pending(sv.C1, sv.acc_mc, ms.gate2c, Mt)
+    else:
+        C2 = Pending(sv.C1)
+    if not lazy:
+        X2, C2 = X2.value(), C2.value()
     return X2, C2, sv
 
 
@@ -470,12 +497,11 @@ def model_fwd(m, W, x_t, t, c, c_pooled, rope, keep=True, C=None):
     sv.blocks = []
     conds, sv.pre_all = cond_fwd_all(m, W.blocks, sv.y)
     for wb, cond in zip(W.blocks, conds):
-        X, C, bs = block_fwd(m, wb, X, C, sv.y, dims, rope, cond, keep)
+        X, C, bs = block_fwd(m, wb, X, C, sv.y, dims, rope, cond, keep, lazy=True)   # (Pending streams between the blocks)
         sv.blocks.append(bs)
 
-    sv.Xf = X
     sv.modo = _gemm(m, sv.y, W.Wmod_out, out_dtype=F32)  # [shift | scale]
-    sv.lnf, sv.muf, sv.rsf = ops.ln_modulate_fwd(X, sv.modo[:, d:], sv.modo[:, :d], N, m.T)
+    sv.Xf, sv.lnf, sv.muf, sv.rsf = _norm(m, X, sv.modo[:, d:], sv.modo[:, :d], N)
     Z = _gemm(m, sv.lnf, W.Wout, bias=W.bout, out_dtype=F32)
     v = ops.unpatchify(Z, B, Cin, Hh, Ww, F32)
     return v, sv

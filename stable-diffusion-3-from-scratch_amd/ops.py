@@ -249,6 +249,26 @@ def ln_modulate_fwd(x, scale, shift, rows_per_batch, out_dtype):
     return out, mean, rstd
 
 
+def ln_modulate_fwd_res(x, acc, gate, scale, shift, rows_per_batch, out_dtype):
+    """x1 = x + gate[b] * acc, then adaLN of x1: returns (x1 fp32, out, mean, rstd) -- mmdit_ln_modulate_fwd_res."""
+    rows, d = x.shape
+    x1 = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    out = torch.empty((rows, d), dtype=out_dtype, device=x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmdit_ln_modulate_fwd_res(_p(_c(x)), _p(_c(acc)), _dt(acc), _p(gate), gate.stride(0), _p(x1), _p(scale), _p(shift), scale.stride(0),
+                                               rows, d, rows_per_batch, _p(out), _dt(out), _p(mean), _p(rstd), _s()), "mmdit_ln_modulate_fwd_res")
+    return x1, out, mean, rstd
+
+
+def gate_residual_fwd(x, acc, gate, rows_per_batch):
+    """x + gate[b] * acc (fp32)."""
+    rows, d = x.shape
+    out = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+    check(_lib.lib().mmdit_gate_residual_fwd(_p(_c(x)), _p(_c(acc)), _dt(acc), _p(gate), gate.stride(0), rows, d, rows_per_batch, _p(out), _s()), "mmdit_gate_residual_fwd")
+    return out
+
+
 def ln_modulate_bwd(dout, x, mean, rstd, scale, dres, rows_per_batch, dscale, dshift, gated=None):
     """Returns dx (fp32) = dres + LN-backward; accumulates into the dscale / dshift views (same leading dim).
     gated = (acc, gate, dgate, dbias | None): also run the backward of the gated residual update that consumes dx

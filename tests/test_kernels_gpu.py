@@ -214,6 +214,25 @@ def test_mlp_act(ops, dt, gelu):
 
 @pytest.mark.parametrize("d,rpb,Bt", [(768, 256, 3), (256, 154, 2), (1024, 77, 2)])
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_ln_modulate_fwd_res_equals_residual_then_norm(ops, d, rpb, Bt, dt):
+    """mmdit_ln_modulate_fwd_res == (x + gate[b] * acc) followed by mmdit_ln_modulate_fwd, and both against torch fp32;
+    mmdit_gate_residual_fwd is the update on its own."""
+    rows = Bt * rpb
+    x = rnd(rows, d, seed=1) * 2 + 0.5
+    acc = rnd(rows, d, seed=2).to(dt)
+    mod = rnd(Bt, 6 * d, seed=3, scale=0.3)
+    scale, shift, gate = mod[:, d:2 * d], mod[:, 3 * d:4 * d], mod[:, 5 * d:]
+    x1_ref = x + gate.repeat_interleave(rpb, 0) * acc.float()
+    x1, out, mean, rstd = ops.ln_modulate_fwd_res(x, acc, gate, scale, shift, rpb, dt)
+    assert rel(x1, x1_ref) < 1e-6 and rel(ops.gate_residual_fwd(x, acc, gate, rpb), x1_ref) < 1e-6
+    out0, mean0, rstd0 = ops.ln_modulate_fwd(x1, scale, shift, rpb, dt)
+    assert rel(mean, mean0) < 1e-6 and rel(rstd, rstd0) < 1e-6 and rel(out, out0) < (1e-6 if dt == torch.float32 else 5e-4)
+    ref = F.layer_norm(x1_ref, (d,)) * (1 + scale.repeat_interleave(rpb, 0)) + shift.repeat_interleave(rpb, 0)
+    assert rel(out, ref) < (1e-5 if dt == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("d,rpb,Bt", [(768, 256, 3), (256, 154, 2), (1024, 77, 2)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_ln_modulate_bwd_gated_equals_unfused_pair(ops, d, rpb, Bt, dt):
     """mmdit_ln_modulate_bwd_gated == mmdit_ln_modulate_bwd followed by mmdit_gate_residual_bwd on its dx, to fp32 round-off (the
     compiler contracts a*b+c differently in the two instantiations, so dx may differ in the last bit and dacc by one rounding of
