@@ -305,8 +305,11 @@ def test_trainer_step_and_reducer_path_single_rank():
         dist.destroy_process_group()
     assert all(np.isfinite(l0)) and l0[0] > 0
     assert np.allclose(l0, l1, rtol=1e-5)
+    # not bitwise: fp32 atomic column sums (adaLN / gate gradients) are order-dependent at the 1e-7 level and the bf16 rounding of
+    # their results downstream turns that into a few 2^-9 flips (tools/probes/determinism.py: the SAME code run twice differs by
+    # up to 4e-4 of a parameter's range after two steps; the forced reducer run is bit-identical to a plain rerun)
     for a, b in zip(p0, p1):
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+        assert rel(a, b) < 1e-3 and float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6
 
 
 def test_fused_unscale_clip_matches_two_pass_path():
