@@ -100,8 +100,9 @@ int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream);
 /* Which kernel mmdit_gemm_grouped would launch for these problems (no launch): 64 = register-staged kernel (gemm.hip);
  * otherwise the LDS-DMA kernel (gemm_dma.hip) with tile configuration (value & 15): 0 = 128x128, 1 = 256x128,
- * 2 = 256x256, plus 16 if the stream-K decomposition is used, plus 32 for the full-rounds + split-K-tail schedule
- * (the default K decomposition of stream_k launches).  Negative = the MMDIT_ERR_* the launch would return.
+ * 2 = 256x256, 3 = 320x256 (lean kernel only), plus 16 if the stream-K decomposition is used, plus 32 for the full-rounds +
+ * split-K-tail schedule (the default K decomposition of stream_k launches), plus 128 when the lean hot-path kernel
+ * (csrc/gemm_lean.hip: bf16 in / bf16 out, bias / SiLU only) takes the launch.  Negative = the MMDIT_ERR_* the launch would return.
  * Lets profilers / benchmarks attribute timings to the exact kernel symbol. */
 int mmdit_gemm_plan(const mmdit_gemm_args* args, int count);
 

@@ -251,9 +251,9 @@ int check_problem(const mmdit_gemm_args* a) {
 
 // Tile-configuration heuristic of the LDS-DMA path.  Bigger tiles halve the L2->CU traffic per FLOP (a 128x128
 // tile needs ~64 B/clk/CU at full MFMA rate, about what the L2 can deliver) but need enough tiles to fill 256 CUs.
-static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k) {
+static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k, bool lean_ok) {
   static const char* force = getenv("MMDIT_GEMM_CFG");
-  if (force) return atoi(force);
+  if (force) return atoi(force) == CFG_320x256 && !lean_ok ? CFG_256x256 : atoi(force);
   static const char* force_epi = getenv("MMDIT_GEMM_CFG_EPI");   // experiments: tile configuration of the gated-residual (fp32 C) launches only
   if (force_epi && args[0].gate) return atoi(force_epi);
   if (stream_k) return CFG_256x256;   // no quantisation with stream-K: take the fewest bytes per FLOP
@@ -265,6 +265,13 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
     t256 += (long)((args[i].M + 255) / 256) * ((args[i].N + 255) / 256);
   }
   const double c128 = (double)((t128 * split_k + 511) / 512), c256 = 1.58 * (double)((t256 * split_k + 255) / 256);
+  if (lean_ok) {
+    // 320x256 tiles (lean kernel): a round costs 1.25x a 256x256 round (tile area); MMDiT-B's N = 768 GEMMs at batch 64 fit ONE round
+    long t320 = 0;
+    for (int i = 0; i < count; i++) t320 += (long)((args[i].M + 319) / 320) * ((args[i].N + 255) / 256);
+    const double c320 = 1.25 * 1.58 * (double)((t320 + 255) / 256);
+    if (c320 < c256 && c320 < c128) return CFG_320x256;
+  }
   return c256 < c128 ? CFG_256x256 : CFG_128x128;
 }
 
@@ -337,7 +344,18 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   // stream-K for the weight gradients (k-major A): fp32 C must be pre-zeroed by the caller (a0->stream_k)
   static const bool no_sk = getenv("MMDIT_GEMM_NO_STREAMK") != nullptr;
   const bool stream_k = dma && !no_sk && a0->stream_k && a0->c_dtype == MMDIT_F32 && split_k == 1 && a0->act == MMDIT_ACT_NONE && !a0->accumulate;
-  if (dma) { cfg = swiglu ? CFG_256x256 : pick_dma_cfg(args, count, split_k, stream_k); dma_cfg_tile(cfg, bm, bn); }
+  // lean hot-path kernel (gemm_lean.hip): bf16 row-major A, bf16 output, bias / SiLU epilogue only.  MMDIT_GEMM_LEAN=0: never;
+  // 2: only where it offers the 320x256 tile; 1 (default): also for 256x256 launches
+  static const char* lean_env = getenv("MMDIT_GEMM_LEAN");
+  static const int lean_mode = lean_env ? atoi(lean_env) : 1;
+  bool lean_ok = dma && lean_mode > 0 && !fp8 && !conv && !swiglu && !stream_k && split_k == 1 && !a0->a_kmajor && a0->c_dtype == MMDIT_BF16 &&
+                 (a0->act == MMDIT_ACT_NONE || a0->act == MMDIT_ACT_SILU) && !a0->accumulate;
+  for (int i = 0; i < count && lean_ok; i++) {
+    const mmdit_gemm_args* a = &args[i];
+    lean_ok = !a->aux && !a->gate && !a->residual && a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) && (!a->b_kmajor || a->N >= 8);
+  }
+  if (dma) { cfg = swiglu ? CFG_256x256 : pick_dma_cfg(args, count, split_k, stream_k, lean_ok); dma_cfg_tile(cfg, bm, bn); }
+  const bool lean = lean_ok && (cfg == CFG_320x256 || (cfg == CFG_256x256 && lean_mode == 1));
   int tiles = 0, units = 0;
   // K-decomposed launches take the problems longest-K first: the tiles of the first round are then ordered long -> short and the
   // balanced tail below can hand the split leftovers to the workgroups that finish their first tile early
@@ -431,8 +449,9 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     MMDIT_CHECK_ARG(dma && a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE && !a0->accumulate && split_k <= 64);
     for (int i = 0; i < count; i++) MMDIT_CHECK_ARG(!args[i].aux && !args[i].gate);
   }
-  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0)) : 64;   // see mmdit_gemm_plan
+  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean ? 128 : 0)) : 64;   // see mmdit_gemm_plan
   hipStream_t s = (hipStream_t)stream;
+  if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, fp8, gp, s);
   if (a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a0, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_SPLIT && a0->a_dtype == MMDIT_F32 && a0->b_dtype == MMDIT_F32) return dispatch_out<float, float, true>(a0, aux_dt, gp, s);

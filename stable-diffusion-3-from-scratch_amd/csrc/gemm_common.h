@@ -229,8 +229,10 @@ __device__ __forceinline__ void epilogue_direct(const f32x16 (&acc)[MI][NJ], con
 
 
 // tile configurations of the LDS-DMA kernel (gemm_dma.hip)
-enum DmaCfg { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2 };
-inline void dma_cfg_tile(int cfg, int& bm, int& bn) { bm = cfg == CFG_128x128 ? 128 : 256; bn = cfg == CFG_256x256 ? 256 : 128; }
+enum DmaCfg { CFG_128x128 = 0, CFG_256x128 = 1, CFG_256x256 = 2, CFG_320x256 = 3 };   // 320x256: lean kernel only (gemm_lean.hip)
+inline void dma_cfg_tile(int cfg, int& bm, int& bn) { bm = cfg == CFG_128x128 ? 128 : cfg == CFG_320x256 ? 320 : 256; bn = cfg >= CFG_256x256 ? 256 : 128; }
 int launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s);
+// lean hot-path kernel: bf16 row-major A, bf16 B (row- or k-major), bf16 C, bias / SiLU only; cfg CFG_256x256 or CFG_320x256
+int launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t s);
 
 }  // namespace gemm

@@ -1,0 +1,205 @@
+// Device helpers shared by the LDS-DMA GEMM kernels (gemm_dma.hip: general kernel; gemm_lean.hip: lean hot-path kernel):
+// DMA piece addressing, the LDS-DMA issue, swizzled fragment reads and the staged epilogues.  See gemm_dma.hip for the layout notes.
+#pragma once
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace gemm {
+namespace {
+
+constexpr int BKH = 32;              // K extent of one ring slot (half of the 64-wide K-tile the host plans in)
+#ifndef MMDIT_GEMM_RING
+#define MMDIT_GEMM_RING 4
+#endif
+constexpr int RING = MMDIT_GEMM_RING;   // slots; DMA distance = RING - 1 halves.  5 slots (all 160 KB for the 256x256 tile) measured equal to 4:
+                                       // the LDS-DMA path saturates near 46 GB/s per CU, it is not latency-bound
+constexpr int EP32_WAVE_BYTES = 4096;
+
+// byte offset (from the operand's half-tile base pointer) of the 16 B this lane sources for 1-KiB piece c
+template <bool KM, int R, int ESZ = 2>
+__device__ __forceinline__ uint32_t piece_voff(int c, int lane, int64_t ld, int row0, int rows) {
+  if (!KM) {
+    const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);   // (r>>2)&3 == (lane>>4)&3
+    return (uint32_t)((int64_t)min(row0 + r, rows - 1) * ld * ESZ + piece * 16);
+  } else {
+    constexpr int PPR = R / 8;       // 16-B pieces per k-row
+    const int k = c * (64 / PPR) + lane / PPR, slot = lane % PPR, piece = slot ^ ((k & 3) << 2);
+    return (uint32_t)((int64_t)k * ld * 2 + (int64_t)min(row0 + piece * 8, rows - 8) * 2);
+  }
+}
+
+// implicit-GEMM convolution: byte offset (from the tensor base) of the 16 B this lane sources for piece c of an A half-tile;
+// the tap / channel part of the address is wave-uniform and lives in the cursor's base pointer
+__device__ __forceinline__ uint32_t conv_voff(int c, int lane, const Problem& q, int row0) {
+  const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);
+  const int m = min(row0 + r, q.M - 1), hw = q.cHo * q.cWo;
+  const int b = m / hw, rem = m - b * hw, yo = rem / q.cWo, xo = rem - yo * q.cWo;
+  const int s = q.conv_mode == 2 ? 2 : 1;
+  return (uint32_t)((((int64_t)b * q.cHp + s * yo) * q.cWp + s * xo) * q.cC * 2 + piece * 16);
+}
+
+// Issued as inline asm on purpose: the compiler's waitcnt pass treats the global_load_lds builtin as a FLAT access
+// that is pending on both counters and then degrades every LDS-read wait of the main loop to lgkmcnt(0); hidden from
+// it, the fragment reads get counted waits.  Completion is tracked by hand (s_waitcnt vmcnt + s_barrier in half_sync).
+__device__ __forceinline__ void glds16(uint32_t voff, const char* sbase_, uint32_t lds_dst_) {
+  const uint64_t a = (uint64_t)(uintptr_t)sbase_;   // wave-uniform by construction; make that explicit for the "s" operands
+  const char* sbase = (const char*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a));
+  const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+  // s_nop 4: the SGPR base may come straight from v_readfirstlane (VALU-written SGPR -> VMEM address needs 5 wait states)
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
+
+template <bool KM, int R>
+__device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int r0, int ks, int lane) {
+  if (!KM) {
+    const int r = r0 + (lane & 31), kp = ks * 2 + (lane >> 5);
+    return *LDS_PTR(const bf16x8, tile + r * 64 + ((kp ^ ((r >> 2) & 3)) << 4));
+  } else {
+    const int kr = ks * 16 + (lane >> 5) * 8 + ((lane & 15) >> 2);
+    const int bcol = (r0 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
+    const char* p = tile + kr * (2 * R) + ((((bcol >> 4) ^ ((kr & 3) << 2)) << 4) | (bcol & 15));
+    s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * (2 * R));   // (kr + 4) & 3 == kr & 3: same swizzle
+    s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, r);
+  }
+}
+
+// fp8 (e4m3) row-major half-tile [R][64] (64 B rows, same byte geometry as the bf16 half-tile): the fragment of k-step ks
+// (16 values) is the 16-B piece ks of the row, each lane half takes 8 of them -> one ds_read_b64
+__device__ __forceinline__ long load_frag8(const char* tile, int r0, int ks, int lane) {
+  const int r = r0 + (lane & 31);
+  return *LDS_PTR(const long, tile + r * 64 + ((ks ^ ((r >> 2) & 3)) << 4) + (lane >> 5) * 8);
+}
+
+// Epilogue (see gemm_common.h for the arithmetic).  acc[i][j] holds a C^T fragment (lane = output row); each
+// 32x32 block goes through the wave's 4-KiB staging block (16-B chunk c of row r at chunk c ^ (r&7): conflict-free
+// ds_write_b128 / ds_read_b128) and leaves as 8 rows x 128 B (fp32) / 64 B (bf16) per wave instruction.
+template <typename TC, typename TAUX, int MI, int NJ>
+__device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
+                                           int lane, int sk, char* stage, bool atomic_out, float alpha = 1.f) {
+  TC* C = (TC*)p.C;
+  TAUX* AUX = (TAUX*)p.aux;
+  const bool first = sk == 0;
+  const float* bias = first ? p.bias : nullptr;
+  const float* gate = p.gate;
+  const float* res = first ? p.residual : nullptr;
+  const int wr = lane & 31, wc = lane >> 5;          // write side: row, 16-B chunk parity
+  const int rr = lane >> 3, rc = lane & 7;           // read side: row within the 8-row pass, 16-B chunk
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int col = n0 + wn * (NJ * 32) + j * 32 + rc * 4;
+      const int row0 = m0 + wm * (MI * 32) + i * 32 + rr;
+      // the residual rows of all four passes are requested before the staging round trip, so that the block
+      // pays one memory latency instead of four load -> wait -> store chains
+      float r4[4][4];   // (the gate rows are a few KB shared by 256 output rows each: L1/L2-hot, loaded in place)
+      if (res) {
+#pragma unroll
+        for (int it = 0; it < 4; it++) {
+          const int row = row0 + it * 8;
+          if (row < p.M && col < p.N) {
+            ld4(res + (int64_t)row * p.ld_res + col, r4[it]);
+          }
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *LDS_PTR(f32x4, stage + wr * 128 + (((2 * g + wc) ^ (wr & 7)) << 4)) =
+            (f32x4){acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+      float b4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (bias && col < p.N) ld4(bias + col, b4);
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = row0 + it * 8;
+        if (row >= p.M || col >= p.N) continue;
+        float v[4] = {t[0] * alpha + b4[0], t[1] * alpha + b4[1], t[2] * alpha + b4[2], t[3] * alpha + b4[3]};   // alpha == 1 exactly unless fp8
+        if (AUX) st4(AUX + (int64_t)row * p.ld_aux + col, v);
+        if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        if (res) {
+          if (gate) {
+            float g4[4];
+            ld4(gate + (int64_t)(row / p.rows_per_batch) * p.ld_gate + col, g4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = r4[it][e] + g4[e] * v[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += r4[it][e];
+          }
+        }
+        TC* cp = C + (int64_t)row * p.ldc + col;
+        if constexpr (sizeof(TC) == 4) {
+          if (atomic_out) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) atomicAdd((float*)cp + e, v[e]);
+            continue;
+          }
+        }
+        if (gp.accumulate) {
+          float c4v[4];
+          ld4(cp, c4v);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += c4v[e];
+        }
+        st4(cp, v);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+    }
+  }
+}
+
+// bf16 output without residual / gate / aux (QKV, up-projection, every dgrad): bias and activation are applied in the
+// accumulator layout, the block pair (i, j = 0..NJ-1... two 32-column blocks) is converted to bf16 FIRST and staged as a
+// 32-row x 64-column bf16 block (4 KiB, 16-B chunk c of row r at chunk c ^ (r&7)), so a wave store instruction writes
+// 8 rows x 128 B (full lines, 16 B per lane): half the LDS bytes and half the store instructions of the fp32 staging.
+template <int MI, int NJ>
+__device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
+                                              int lane, char* stage, float alpha = 1.f) {
+  static_assert(NJ == 2, "wave sub-tile must be 64 columns wide");
+  bf16_t* C = (bf16_t*)p.C;
+  const float* bias = p.bias;
+  const int wr = lane & 31, wc = lane >> 5;          // write side: row, 8-B half of the 16-B chunk
+  const int rr = lane >> 3, rc = lane & 7;           // read side: row within the 8-row pass, 16-B chunk (8 columns)
+  const int colw = n0 + wn * 64;                     // first column of this wave
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float v[4] = {acc[i][j][g * 4] * alpha, acc[i][j][g * 4 + 1] * alpha, acc[i][j][g * 4 + 2] * alpha, acc[i][j][g * 4 + 3] * alpha};
+        if (bias) {
+          const int c = colw + j * 32 + 8 * g + 4 * wc;
+          float b4[4] = {0.f, 0.f, 0.f, 0.f};
+          if (c < p.N) ld4(bias + c, b4);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] += b4[e];
+        }
+        if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+        }
+        const u32x2 pk = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+        *LDS_PTR(u32x2, stage + wr * 128 + (((j * 4 + g) ^ (wr & 7)) << 4) + wc * 8) = pk;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+    const int col = colw + rc * 8;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+      const int row = m0 + wm * (MI * 32) + i * 32 + r;
+      if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+}
+
+}  // namespace
+}  // namespace gemm

@@ -138,7 +138,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     return out
 
 
-_CFG = {0: "2,2,2,2", 1: "4,2,2,2", 2: "2,4,4,2"}
+_CFG = {0: "2,2,2,2", 1: "4,2,2,2", 2: "2,4,4,2", 3: "2,4,5,2"}
 
 
 def _variant(arr, n, outs):
@@ -152,6 +152,8 @@ def _variant(arr, n, outs):
     if plan == 64:
         ab = "t,t" if a.precision == PREC_BF16 else "f,f"
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
+    if plan & 128:
+        return f"gemm_lean_kernel<{_CFG[plan & 15]},{int(bool(a.b_kmajor))}>"
     return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "") + ("+swiglu" if a.act == ACT_SWIGLU else "")
 
 

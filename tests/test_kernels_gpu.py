@@ -359,6 +359,32 @@ def test_attention_oracle_mode_matches_cpu_oracle(ops):
     assert r < 3e-4
 
 
+@pytest.mark.parametrize("kmajor", [False, True])
+def test_gemm_lean_kernel_320x256_and_256x256(ops, kmajor):
+    """The lean hot-path kernel (csrc/gemm_lean.hip) on the shapes it is chosen for: image + text rows grouped, N = 768 (320x256 tiles:
+    one round; ragged last row tiles 16384 = 51.2 x 320, 9856 = 30.8 x 320) and N = 2304, forward (row-major weight, bias + SiLU) and
+    data-gradient (k-major weight) layouts, against torch on the same bf16 operands (fp32 accumulate; bf16 output rounding 4e-3)."""
+    from sd3_amd._lib import ACT_SILU
+    for N, K in ((768, 768), (2304, 768), (768, 3072)):
+        Ax, Ac = rnd(16384, K, seed=1, dtype=torch.bfloat16), rnd(9856, K, seed=2, dtype=torch.bfloat16)
+        W = rnd(K, N, seed=3, scale=0.05, dtype=torch.bfloat16) if kmajor else rnd(N, K, seed=3, scale=0.05, dtype=torch.bfloat16)
+        bias = None if kmajor else rnd(N, seed=4)
+        kw = dict(b_kmajor=True) if kmajor else dict(bias=bias, act=ACT_SILU)
+        probs = [dict(A=Ax, B=W, out_dtype=torch.bfloat16, **kw), dict(A=Ac, B=W, out_dtype=torch.bfloat16, **kw)]
+        arr = (ops.GemmArgs * 2)()
+        for i in range(2):
+            ops._fill_gemm(arr[i], **probs[i])
+        plan = ops._lib.lib().mmdit_gemm_plan(arr, 2)
+        assert plan & 128 and (plan & 15) == (3 if N == 768 else plan & 15), plan      # lean kernel; 320x256 tiles for N = 768
+        ox, oc = ops.gemm_grouped(probs)
+        for o, A in ((ox, Ax), (oc, Ac)):
+            ref = A.float() @ (W.float() if kmajor else W.float().T)
+            if not kmajor:
+                ref = F.silu(ref + bias)
+            assert rel(o, ref) < 4e-3
+            assert float((o.float() - ref).abs().max()) < 3e-2 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("layout", ["nt", "dgrad", "wgrad"])
 def test_gemm_dma_path_and_split_k(ops, layout):
     """K % 64 == 0 takes the global_load_lds kernel; ragged M/N are clamped; split-K slices add atomically."""
