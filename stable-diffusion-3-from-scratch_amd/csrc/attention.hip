@@ -45,21 +45,22 @@ __device__ __forceinline__ bf16x8 row_frag(const char* tile, int pitch, int rb, 
   return *LDS_PTR(const bf16x8, tile + (rb + (lane & 31)) * pitch + (ks * 16 + (lane >> 5) * 8) * 2);
 }
 
-// copy a [64 rows][64] bf16 tile global -> LDS, rows >= nvalid zero-filled.  NT threads.
+// copy a [64 rows][64] bf16 tile global -> LDS (512 16-byte chunks), rows >= nvalid zero-filled.  NT threads (any multiple of 64).
+template <int NT> constexpr int tile_chunks() { return (512 + NT - 1) / NT; }
 template <int NT>
-__device__ __forceinline__ void tile_g2r(u32x4 (&st)[512 / NT], const bf16_t* g, int row0, int nrows_total, int tid) {
+__device__ __forceinline__ void tile_g2r(u32x4 (&st)[tile_chunks<NT>()], const bf16_t* g, int row0, int nrows_total, int tid) {
 #pragma unroll
-  for (int i = 0; i < 512 / NT; i++) {
+  for (int i = 0; i < tile_chunks<NT>(); i++) {
     const int c = tid + i * NT, row = c >> 3, kc = c & 7;
-    st[i] = (row0 + row < nrows_total) ? *(const u32x4*)(g + (int64_t)(row0 + row) * HD + kc * 8) : (u32x4){0, 0, 0, 0};
+    st[i] = (c < 512 && row0 + row < nrows_total) ? *(const u32x4*)(g + (int64_t)(row0 + row) * HD + kc * 8) : (u32x4){0, 0, 0, 0};
   }
 }
 template <int NT>
-__device__ __forceinline__ void tile_r2s(const u32x4 (&st)[512 / NT], char* tile, int pitch, int tid) {
+__device__ __forceinline__ void tile_r2s(const u32x4 (&st)[tile_chunks<NT>()], char* tile, int pitch, int tid) {
 #pragma unroll
-  for (int i = 0; i < 512 / NT; i++) {
+  for (int i = 0; i < tile_chunks<NT>(); i++) {
     const int c = tid + i * NT, row = c >> 3, kc = c & 7;
-    *LDS_PTR(u32x4, tile + row * pitch + kc * 16) = st[i];
+    if (512 % NT == 0 || c < 512) *LDS_PTR(u32x4, tile + row * pitch + kc * 16) = st[i];
   }
 }
 
@@ -119,12 +120,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
     for (int r = 0; r < 16; r++) o[db][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   const int nkv = (S + KT - 1) / KT;
-  u32x4 sk[512 / NT], sv[512 / NT];
+  u32x4 sk[tile_chunks<NT>()], sv[tile_chunks<NT>()];
 
   // scores of tile j from LDS buffer kb_ -> s[2] (masked keys = -inf).  fast: log2 domain; oracle: natural, bf16-rounded
   auto scores = [&](int j, const char* ktile, f32x16 (&s)[2]) {
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
+      if (j * KT + kb * 32 >= S) {   // (wave-uniform) the whole 32-key block is padding: no MFMAs, all scores masked
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[kb][r] = -INFINITY;
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
 #pragma unroll
@@ -148,9 +154,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
     return fmaxf(mx, __shfl_xor(mx, 32, 64));
   };
-  auto pv = [&](const f32x16 (&p)[2], const char* vtile) {
+  auto pv = [&](int j, const f32x16 (&p)[2], const char* vtile) {
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
+      if (j * KT + kb * 32 < S)   // (the probabilities of a padding block are all zero)
 #pragma unroll
       for (int h8 = 0; h8 < 2; h8++) {
         const bf16x8 pf = pack_frag(p[kb], h8);
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         for (int db = 0; db < 2; db++)
 #pragma unroll
           for (int r = 0; r < 16; r++) o[db][r] *= alpha;
-        pv(s, vt(cur));
+        pv(j, s, vt(cur));
       } else if (pass == 0) {
         const float mn = fmaxf(m, tile_max(s));
         float rs = 0.f;
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
         for (int kb = 0; kb < 2; kb++)
 #pragma unroll
           for (int r = 0; r < 16; r++) s[kb][r] = expf(s[kb][r] - m) / l;   // softmax output, rounded to bf16 by pack_frag
-        pv(s, vt(cur));
+        pv(j, s, vt(cur));
       }
       if (j + 1 < nkv) {
         tile_r2s<NT>(sk, kt(cur ^ 1), P144, tid);
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
     for (int r = 0; r < 16; r++) acc[db][r] = 0.f;
 
   const int nkv = (S + KT - 1) / KT;
-  u32x4 sk[512 / NT], sv[512 / NT];
+  u32x4 sk[tile_chunks<NT>()], sv[tile_chunks<NT>()];
   for (int j = 0; j < nkv; j++) {
     tile_g2r<NT>(sk, Kb, j * KT, S, tid);
     tile_g2r<NT>(sv, Vb, j * KT, S, tid);
@@ -301,6 +308,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
     if (!active) continue;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
+      if (j * KT + kb * 32 >= S) continue;   // (wave-uniform) 32 padding keys contribute nothing
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
@@ -379,12 +387,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 
   const int nq = (S + KT - 1) / KT;
   for (int jq = 0; jq < nq; jq++) {
-    u32x4 sq[512 / NT], sd[512 / NT];
+    u32x4 sq[tile_chunks<NT>()], sd[tile_chunks<NT>()];
     tile_g2r<NT>(sq, Qb, jq * KT, S, tid);
 #pragma unroll
-    for (int i = 0; i < 512 / NT; i++) {
+    for (int i = 0; i < tile_chunks<NT>(); i++) {
       const int c = tid + i * NT, row = c >> 3, kc = c & 7, s = jq * KT + row;
-      const bf16_t* p = s < S ? tok_ptr(dOx, dOc, b, s, n_img, n_txt, D, h) : nullptr;
+      const bf16_t* p = (c < 512 && s < S) ? tok_ptr(dOx, dOc, b, s, n_img, n_txt, D, h) : nullptr;
       sd[i] = p ? *(const u32x4*)(p + kc * 8) : (u32x4){0, 0, 0, 0};
     }
     float lv = 0.f, dl = 0.f;
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
     if (!active) continue;
 #pragma unroll
     for (int qb = 0; qb < 2; qb++) {
+      if (jq * KT + qb * 32 >= S) continue;   // (wave-uniform) 32 padding queries contribute nothing
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
@@ -448,11 +457,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 
 // waves (32 queries / keys each) per workgroup: all waves of a workgroup share one stream of 64-row K/V (or Q/dO) tiles, so
 // 8 waves cut the tile copies and barriers per (batch, head) from 7x to 2x (measured at S = 410: forward 115 -> 70 us,
-// backward 372 -> 271 us).  MMDIT_ATTN_NW = 2 | 4 | 8 overrides for A/B runs.
-int attn_waves() {
+// backward 372 -> 271 us).  The count is chosen among 8 / 7 / 6 to minimise the padded rows: S = 410 is 13 waves of 32 = two
+// workgroups of 7 (448 rows, 8.5 % padding) instead of two of 8 (512 rows, 20 %); S = 1178 stays at 8 (5 x 256 = 1280).
+// MMDIT_ATTN_NW = 2 | 4 | 6 | 7 | 8 overrides for A/B runs.
+int attn_waves(int S) {
   static const char* e = getenv("MMDIT_ATTN_NW");
-  static const int nw = e ? atoi(e) : 8;
-  return nw;
+  if (e) return atoi(e);
+  int best = 8, best_rows = 1 << 30;
+  for (int nw = 8; nw >= 6; nw--) {
+    const int rows = (S + 32 * nw - 1) / (32 * nw) * 32 * nw;
+    if (rows < best_rows) { best = nw; best_rows = rows; }
+  }
+  return best;
 }
 
 }  // namespace
@@ -462,12 +478,14 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   MMDIT_CHECK_ARG(Q && K && V && Ox && lse && batch > 0 && heads > 0 && S > 0 && n_img > 0 && n_img <= S);
   MMDIT_CHECK_ARG(Oc || n_img == S);
   hipStream_t s = (hipStream_t)stream;
-  const int nw = attn_waves();
+  const int nw = attn_waves(S);
 #define MMDIT_FWD(NW, OR) hipLaunchKernelGGL((attn_fwd_kernel<NW, OR>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                                              (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse)
   if (mode == 1) MMDIT_FWD(2, true);
   else if (mode != 0) return MMDIT_ERR_ARG;
   else if (nw == 8) MMDIT_FWD(8, false);
+  else if (nw == 7) MMDIT_FWD(7, false);
+  else if (nw == 6) MMDIT_FWD(6, false);
   else if (nw == 4) MMDIT_FWD(4, false);
   else MMDIT_FWD(2, false);
 #undef MMDIT_FWD
@@ -481,16 +499,20 @@ extern "C" int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const
   MMDIT_CHECK_ARG(Oc || n_img == S);
   hipStream_t s = (hipStream_t)stream;
   // (delta = rowsum(dO * O) is produced by the dQ kernel, which runs first)
-  const int nw = attn_waves();
+  const int nw = attn_waves(S);
 #define MMDIT_DKV(NW, TG) hipLaunchKernelGGL((attn_bwd_dkv_kernel<NW, TG>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                                              (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (TG*)dK, (TG*)dV)
 #define MMDIT_DQ(NW, TG) hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, TG>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                                             (const bf16_t*)V, (const bf16_t*)Ox, (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (TG*)dQ)
   if (dq_dtype == MMDIT_BF16) {
     if (nw == 8) MMDIT_DQ(8, bf16_t);
+    else if (nw == 7) MMDIT_DQ(7, bf16_t);
+    else if (nw == 6) MMDIT_DQ(6, bf16_t);
     else if (nw == 4) MMDIT_DQ(4, bf16_t);
     else MMDIT_DQ(2, bf16_t);
     if (nw == 8) MMDIT_DKV(8, bf16_t);
+    else if (nw == 7) MMDIT_DKV(7, bf16_t);
+    else if (nw == 6) MMDIT_DKV(6, bf16_t);
     else if (nw == 4) MMDIT_DKV(4, bf16_t);
     else MMDIT_DKV(2, bf16_t);
   } else if (dq_dtype == MMDIT_F32) {

@@ -1,6 +1,6 @@
 """List every dispatch of the kernels matching a substring in a rocprofv3 rocpd database: start offset, duration, grid, and
 the kernel dispatched just before it (to spot in-situ slowdowns a micro-benchmark does not show).
-Usage: python tools/rocpd_calls.py <results.db> <substring> [max_rows]"""
+Usage: python tools/rocpd_calls.py <results.db> <substring> [max_rows]     (max_rows < 0: the LAST |max_rows| matching dispatches)"""
 import sqlite3
 import sys
 
@@ -17,8 +17,14 @@ def main():
                           order by d.start""").fetchall()
     t0 = rows[0][1]
     shown = 0
+    if limit < 0:
+        hits = [i for i, r in enumerate(rows) if sub in r[0]]
+        skip = set(hits[:limit])
+        limit = -limit
+    else:
+        skip = set()
     for i, (name, st, en, g, w) in enumerate(rows):
-        if sub in name and shown < limit:
+        if sub in name and shown < limit and i not in skip:
             prev = rows[i - 1] if i else None
             gap = (st - prev[2]) / 1e3 if prev else 0.0
             print(f"{(st - t0) / 1e6:10.3f} ms  dur {(en - st) / 1e3:9.2f} us  grid {g:>8} wg {w:>5}  gap_after_prev {gap:8.2f} us  prev {prev[0][:60] if prev else ''}")
