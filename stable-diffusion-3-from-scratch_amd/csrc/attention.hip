@@ -239,6 +239,150 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, LDS-DMA variant (fast mode): K/V tiles go global -> LDS with global_load_lds (no VGPR staging, no ds_write) into a
+// 4-stage ring, three tiles ahead of the MFMAs -- with one tile of look-ahead the loop was bound by the L2 latency of the
+// tile copy, not by MFMA or VALU work.  The LDS image of a DMA is lane-linear, so tiles are unpadded [64 keys][128 B] and the
+// bank swizzle is applied to the per-lane SOURCE address and mirrored by the fragment reads:
+//   K (ds_read_b128 row fragments):      16-B piece p of key row r lives at slot p ^ ((r >> 1) & 7)
+//   V (ds_read_b64_tr_b16 fragments):    16-B piece p of key row r lives at slot p ^ (4 * ((r >> 1) & 1))
+// Rows beyond S are clamped to the last valid row (their scores are masked / their probabilities are zero).
+// One s_waitcnt vmcnt + one s_barrier per tile; every wave issues exactly two pieces per tile (8 waves = 8 + 8 KiB).
+// ------------------------------------------------------------------------------------------------
+constexpr int ANS = 4;   // ring stages
+
+__device__ __forceinline__ void attn_glds16(const void* gptr, uint32_t lds_dst_) {
+  const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_dst) : "memory", "m0");
+}
+// fragments of the swizzled unpadded tiles
+__device__ __forceinline__ bf16x8 row_frag_sw(const char* tile, int rb, int ks, int lane) {
+  const int r = rb + (lane & 31), kp = ks * 2 + (lane >> 5);
+  return *LDS_PTR(const bf16x8, tile + r * 128 + ((kp ^ ((r >> 1) & 7)) << 4));
+}
+__device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int rb, int h8, int cb, int lane) {
+  const int row = rb + 16 * h8 + 4 * (lane >> 5) + ((lane & 15) >> 2);
+  const int cbyte = (cb * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
+  const char* p = tile + row * 128 + ((((cbyte >> 4) ^ (4 * ((row >> 1) & 1))) << 4) | (cbyte & 15));
+  s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 8 * 128);     // row + 8: same swizzle bit
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                           int BH, int H, int S, int n_img, float scale,
+                                                           bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse) {
+  constexpr int NW = 8;
+  __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  int qtile, bh;
+  map_block((S + 32 * NW - 1) / (32 * NW), BH, qtile, bh);
+  const int h = bh % H;
+  const int64_t b = bh / H;
+  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
+  const bf16_t* Kb = K + (int64_t)bh * S * HD;
+  const bf16_t* Vb = V + (int64_t)bh * S * HD;
+  const int q = qtile * 32 * NW + wave * 32 + (lane & 31);
+  const int qc = min(q, S - 1);
+  const bool active = qtile * 32 * NW + wave * 32 < S;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q loads are the only compiler-visible loads: retire them before the DMA stream starts
+
+  const int nkv = (S + KT - 1) / KT;
+  // this lane's part of a tile: key row 8 * wave + (lane >> 3), 16-byte slot lane & 7
+  const int rl = 8 * wave + (lane >> 3), slot = lane & 7;
+  const int kcol = (slot ^ ((rl >> 1) & 7)) * 8, vcol = (slot ^ (4 * ((rl >> 1) & 1))) * 8;
+  auto issue = [&](int j, int stage) {
+    const int row = min(min(j, nkv - 1) * KT + rl, S - 1);
+    attn_glds16(Kb + (int64_t)row * HD + kcol, lds0 + stage * (2 * KT * 128) + wave * 1024);
+    attn_glds16(Vb + (int64_t)row * HD + vcol, lds0 + stage * (2 * KT * 128) + KT * 128 + wave * 1024);
+  };
+#pragma unroll
+  for (int st = 0; st < ANS - 1; st++) issue(st, st);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[db][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+  const float c = scale * LOG2E;
+  int stage = 0;
+  for (int j = 0; j < nkv; j++) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ANS - 2)) : "memory");   // tile j has landed (ANS-2 younger tiles may be in flight)
+    __builtin_amdgcn_s_barrier();                                          // ... for every wave; and everyone has left tile j-1
+    issue(j + ANS - 1, stage == 0 ? ANS - 1 : stage - 1);                  // refill the stage of tile j-1
+    const char* ktile = smem + stage * (2 * KT * 128);
+    const char* vtile = ktile + KT * 128;
+    stage = stage + 1 == ANS ? 0 : stage + 1;
+    if (!active) continue;
+    f32x16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      if (j * KT + kb * 32 >= S) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[kb][r] = -INFINITY;
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_sw(ktile, kb * 32, ks, lane), qf[ks], s[kb], 0, 0, 0);
+      if ((j + 1) * KT > S) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+          if (j * KT + kb * 32 + acc_row(r, lane) >= S) s[kb][r] = -INFINITY;
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx * c);
+    const float alpha = fast_exp2(m - mn);
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -mn)); s[kb][r] = p; rs += p; }
+    rs += __shfl_xor(rs, 32, 64);
+    l = l * alpha + rs; m = mn;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[db][r] *= alpha;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+      if (j * KT + kb * 32 < S)
+#pragma unroll
+        for (int h8 = 0; h8 < 2; h8++) {
+          const bf16x8 pf = pack_frag(s[kb], h8);
+#pragma unroll
+          for (int db = 0; db < 2; db++) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_sw(vtile, kb * 32, h8, db, lane), pf, o[db], 0, 0, 0);
+        }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is released
+  if (q < S) {
+    const float inv = 1.f / l;
+    const int n_txt = S - n_img, D = H * HD;
+    bf16_t* dst = q < n_img ? Ox + ((b * n_img + q) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (q - n_img)) * (int64_t)D + h * HD);
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float v4[4] = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
+        st4(dst + db * 32 + 8 * g + 4 * (lane >> 5), v4);
+      }
+    if (lane < 32) lse[(int64_t)bh * S + q] = m * LN2 + logf(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
 template <int NW, typename TG>
@@ -457,17 +601,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 
 // waves (32 queries / keys each) per workgroup: all waves of a workgroup share one stream of 64-row K/V (or Q/dO) tiles, so
 // 8 waves cut the tile copies and barriers per (batch, head) from 7x to 2x (measured at S = 410: forward 115 -> 70 us,
-// backward 372 -> 271 us).  The count is chosen among 8 / 7 / 6 to minimise the padded rows: S = 410 is 13 waves of 32 = two
-// workgroups of 7 (448 rows, 8.5 % padding) instead of two of 8 (512 rows, 20 %); S = 1178 stays at 8 (5 x 256 = 1280).
-// MMDIT_ATTN_NW = 2 | 4 | 6 | 7 | 8 overrides for A/B runs.
+// backward 372 -> 271 us).  7-wave workgroups would pad S = 410 less (448 instead of 512 rows) but measured slower (forward 96 vs
+// 70 us: 448 threads copy a 512-chunk tile in two unbalanced passes).  MMDIT_ATTN_NW = 2 | 4 | 6 | 7 | 8 overrides for A/B runs.
 int attn_waves(int S) {
   static const char* e = getenv("MMDIT_ATTN_NW");
   if (e) return atoi(e);
   int best = 8, best_rows = 1 << 30;
-  for (int nw = 8; nw >= 6; nw--) {
-    const int rows = (S + 32 * nw - 1) / (32 * nw) * 32 * nw;
-    if (rows < best_rows) { best = nw; best_rows = rows; }
-  }
+  (void)best_rows;
   return best;
 }
 
@@ -481,8 +621,13 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   const int nw = attn_waves(S);
 #define MMDIT_FWD(NW, OR) hipLaunchKernelGGL((attn_fwd_kernel<NW, OR>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                                              (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse)
+  static const char* dma_env = getenv("MMDIT_ATTN_DMA");
+  static const bool use_dma = !dma_env || atoi(dma_env) != 0;
   if (mode == 1) MMDIT_FWD(2, true);
   else if (mode != 0) return MMDIT_ERR_ARG;
+  else if (use_dma && !getenv("MMDIT_ATTN_NW"))
+    hipLaunchKernelGGL(attn_fwd_dma_kernel, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
+                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
   else if (nw == 8) MMDIT_FWD(8, false);
   else if (nw == 7) MMDIT_FWD(7, false);
   else if (nw == 6) MMDIT_FWD(6, false);
