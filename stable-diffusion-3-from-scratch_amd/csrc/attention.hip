@@ -310,15 +310,30 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
     for (int r = 0; r < 16; r++) o[db][r] = 0.f;
   float m = -INFINITY, l = 0.f;
   const float c = scale * LOG2E;
+  // Per-lane LDS byte offsets of the fragment reads, computed ONCE: everything that depends on the tile / key block / k-step is
+  // a compile-time constant added as the ds_read immediate (the swizzles only involve lane bits), so a tile costs 6 address
+  // adds instead of one per read.
+  //   K row fragment (kb, ks): row 32 kb + (lane & 31), piece (2 ks + (lane >> 5)) ^ ((row >> 1) & 7)  =  [(ks ^ f) << 5] + per-lane part
+  //   V^T fragment (kb, h8, db): row 32 kb + 16 h8 + 4 (lane >> 5) + rr, piece ^ 4 ((rr >> 1) & 1)      =  [(db ^ b) << 6] + per-lane part
+  uint32_t kofs[4], vofs[2];
+  {
+    const int l31 = lane & 31, hi5 = lane >> 5, swz = (l31 >> 1) & 7, f = swz >> 1, e = hi5 ^ (swz & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) kofs[ks] = l31 * 128 + ((ks ^ f) << 5) + (e << 4);
+    const int rr = (lane & 15) >> 2, x = (lane >> 4) & 1, y = lane & 3, bb = (rr >> 1) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; db++) vofs[db] = KT * 128 + (4 * hi5 + rr) * 128 + ((db ^ bb) << 6) + (x << 5) + ((y >> 1) << 4) + ((y & 1) << 3);
+  }
   int stage = 0;
   for (int j = 0; j < nkv; j++) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ANS - 2)) : "memory");   // tile j has landed (ANS-2 younger tiles may be in flight)
     __builtin_amdgcn_s_barrier();                                          // ... for every wave; and everyone has left tile j-1
     issue(j + ANS - 1, stage == 0 ? ANS - 1 : stage - 1);                  // refill the stage of tile j-1
-    const char* ktile = smem + stage * (2 * KT * 128);
-    const char* vtile = ktile + KT * 128;
+    const char* tile = smem + stage * (2 * KT * 128);
     stage = stage + 1 == ANS ? 0 : stage + 1;
     if (!active) continue;
+    const char* kp[4] = {tile + kofs[0], tile + kofs[1], tile + kofs[2], tile + kofs[3]};
+    const char* vp[2] = {tile + vofs[0], tile + vofs[1]};
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
@@ -330,7 +345,8 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++) s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_sw(ktile, kb * 32, ks, lane), qf[ks], s[kb], 0, 0, 0);
+      for (int ks = 0; ks < 4; ks++)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*LDS_PTR(const bf16x8, kp[ks] + kb * 32 * 128), qf[ks], s[kb], 0, 0, 0);
       if ((j + 1) * KT > S) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
@@ -342,20 +358,26 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx * c);
-    const float alpha = fast_exp2(m - mn);
+    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false)[0])) * c;
+    // the accumulators are rescaled only when some query's running maximum grows (exact: alpha == 1 otherwise); after the first
+    // tiles that is rare, and it takes 32 multiplies per lane out of most iterations
+    if (!__all(mx <= m)) {
+      const float mn = fmaxf(m, mx);
+      const float alpha = fast_exp2(m - mn);
+      l *= alpha;
+      m = mn;
+#pragma unroll
+      for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[db][r] *= alpha;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -mn)); s[kb][r] = p; rs += p; }
-    rs += __shfl_xor(rs, 32, 64);
-    l = l * alpha + rs; m = mn;
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) o[db][r] *= alpha;
+      for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -m)); s[kb][r] = p; rs += p; }
+    rs += __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, rs), __builtin_bit_cast(unsigned, rs), false, false)[0]);
+    l += rs;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
       if (j * KT + kb * 32 < S)
@@ -363,7 +385,12 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
         for (int h8 = 0; h8 < 2; h8++) {
           const bf16x8 pf = pack_frag(s[kb], h8);
 #pragma unroll
-          for (int db = 0; db < 2; db++) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_sw(vtile, kb * 32, h8, db, lane), pf, o[db], 0, 0, 0);
+          for (int db = 0; db < 2; db++) {
+            const char* q0 = vp[db] + (kb * 32 + 16 * h8) * 128;
+            const s16x4 lo = lds_tr16(q0), hi = lds_tr16(q0 + 8 * 128);
+            const s16x8 vr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vr), pf, o[db], 0, 0, 0);
+          }
         }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is released
