@@ -254,6 +254,13 @@ __device__ __forceinline__ void attn_glds16(const void* gptr, uint32_t lds_dst_)
   const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_dst) : "memory", "m0");
 }
+// value of lane ^ 32 without an LDS round trip: v_permlane32_swap exchanges the upper half of its first operand with the lower
+// half of the second; whichever way the compiler allocates the two copies of x (one register: both results are the partner's
+// value; two registers: [own | partner] and [partner | own]), the select below picks the partner
+__device__ __forceinline__ float partner32(float x, int lane) {
+  const auto pr = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, x), false, false);
+  return __builtin_bit_cast(float, lane < 32 ? pr[1] : pr[0]);
+}
 // fragments of the swizzled unpadded tiles
 __device__ __forceinline__ bf16x8 row_frag_sw(const char* tile, int rb, int ks, int lane) {
   const int r = rb + (lane & 31), kp = ks * 2 + (lane >> 5);
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-    mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false)[0])) * c;
+    mx = fmaxf(mx, partner32(mx, lane)) * c;   // the two lanes of a query (l, l + 32)
     // the accumulators are rescaled only when some query's running maximum grows (exact: alpha == 1 otherwise); after the first
     // tiles that is rare, and it takes 32 multiplies per lane out of most iterations
     if (!__all(mx <= m)) {
@@ -376,8 +383,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -m)); s[kb][r] = p; rs += p; }
-    rs += __builtin_bit_cast(float, __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, rs), __builtin_bit_cast(unsigned, rs), false, false)[0]);
-    l += rs;
+    l += rs + partner32(rs, lane);
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
       if (j * KT + kb * 32 < S)
