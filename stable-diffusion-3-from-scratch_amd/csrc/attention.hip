@@ -416,6 +416,184 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward, 64 queries per wave (fast mode): 4 waves per workgroup (one per SIMD) = 256 queries, two workgroups per CU.
+// The 32-query-per-wave kernels above spend their time in dependent chains (PMC: waves 25 % issuing, 42 % parked at waits /
+// barriers, 33 % issue-stalled; MFMA 20 % busy): every MFMA of a wave waits for the previous one on the same accumulator and for
+// an LDS fragment read issued just before it.  Here a wave owns TWO 32-query blocks: each K / V^T fragment read from LDS feeds two
+// MFMAs (half the LDS reads per FLOP), four accumulators are in flight per phase (s[qb][kb], then o[qb][db]) so consecutive
+// MFMAs are independent, and the two waves that share a SIMD belong to different workgroups (independent barriers), so one is
+// in its MFMA phase while the other runs its softmax.  K/V tiles: the LDS-DMA ring of attn_fwd_dma_kernel (swizzles as there).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                           int BH, int H, int S, int n_img, float scale,
+                                                           bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse) {
+  constexpr int NW = 4, QW = 64;     // waves, queries per wave
+  __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  int qtile, bh;
+  map_block((S + QW * NW - 1) / (QW * NW), BH, qtile, bh);
+  const int h = bh % H;
+  const int64_t b = bh / H;
+  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
+  const bf16_t* Kb = K + (int64_t)bh * S * HD;
+  const bf16_t* Vb = V + (int64_t)bh * S * HD;
+  const int q0 = qtile * QW * NW + wave * QW;                 // first query of this wave
+  const int nqb = q0 >= S ? 0 : (q0 + 32 >= S ? 1 : 2);       // (wave-uniform) 32-query blocks of this wave that hold real queries
+
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    const int qc = min(q0 + qb * 32 + (lane & 31), S - 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) qf[qb][ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q loads are the only compiler-visible loads: retire them before the DMA stream starts
+
+  const int nkv = (S + KT - 1) / KT;
+  // this lane's part of a tile: every wave moves two 1-KiB pieces (8 key rows each) of K and two of V
+  uint32_t krow[2];
+  int kcol[2], vcol[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int rl = 8 * (wave * 2 + i) + (lane >> 3), slot = lane & 7;
+    krow[i] = rl;
+    kcol[i] = (slot ^ ((rl >> 1) & 7)) * 8;
+    vcol[i] = (slot ^ (4 * ((rl >> 1) & 1))) * 8;
+  }
+  auto issue = [&](int j, int stage) {
+    const int t0 = min(j, nkv - 1) * KT;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int row = min(t0 + (int)krow[i], S - 1);
+      attn_glds16(Kb + (int64_t)row * HD + kcol[i], lds0 + stage * (2 * KT * 128) + (wave * 2 + i) * 1024);
+      attn_glds16(Vb + (int64_t)row * HD + vcol[i], lds0 + stage * (2 * KT * 128) + KT * 128 + (wave * 2 + i) * 1024);
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < ANS - 1; st++) issue(st, st);
+
+  f32x16 o[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[qb][db][r] = 0.f;
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  const float c = scale * LOG2E;
+  uint32_t kofs[4], vofs[2];   // per-lane LDS offsets of the fragment reads (see attn_fwd_dma_kernel)
+  {
+    const int l31 = lane & 31, hi5 = lane >> 5, swz = (l31 >> 1) & 7, f = swz >> 1, e = hi5 ^ (swz & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) kofs[ks] = l31 * 128 + ((ks ^ f) << 5) + (e << 4);
+    const int rr = (lane & 15) >> 2, x = (lane >> 4) & 1, y = lane & 3, bb = (rr >> 1) & 1;
+#pragma unroll
+    for (int db = 0; db < 2; db++) vofs[db] = KT * 128 + (4 * hi5 + rr) * 128 + ((db ^ bb) << 6) + (x << 5) + ((y >> 1) << 4) + ((y & 1) << 3);
+  }
+  int stage = 0;
+  for (int j = 0; j < nkv; j++) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ANS - 2)) : "memory");   // tile j has landed (ANS-2 younger tiles, 4 pieces each, may be in flight)
+    __builtin_amdgcn_s_barrier();
+    issue(j + ANS - 1, stage == 0 ? ANS - 1 : stage - 1);
+    const char* tile = smem + stage * (2 * KT * 128);
+    stage = stage + 1 == ANS ? 0 : stage + 1;
+    if (nqb == 0) continue;
+    const int nkb = j * KT + 32 >= S ? 1 : 2;                   // (wave-uniform) key blocks of this tile with real keys
+    const bool ragged = (j + 1) * KT > S;
+    // ---- S^T = K Q^T: four independent accumulators, every K fragment feeds both query blocks
+    f32x16 s[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[qb][kb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      const bf16x8 k0 = *LDS_PTR(const bf16x8, tile + kofs[ks]);
+      s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][ks], s[0][0], 0, 0, 0);
+      s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][ks], s[1][0], 0, 0, 0);
+      if (nkb == 2) {
+        const bf16x8 k1 = *LDS_PTR(const bf16x8, tile + kofs[ks] + 32 * 128);
+        s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][ks], s[0][1], 0, 0, 0);
+        s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][ks], s[1][1], 0, 0, 0);
+      }
+    }
+    // ---- online softmax per query block (the row statistics are lane-local up to the l / l+32 pair)
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+      if (ragged || nkb == 1) {
+#pragma unroll
+        for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (j * KT + kb * 32 + acc_row(r, lane) >= S) s[qb][kb][r] = -INFINITY;
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[qb][kb][r]);
+      mx = fmaxf(mx, partner32(mx, lane)) * c;
+      if (!__all(mx <= m[qb])) {     // rescale only when some running maximum grows (exact: alpha == 1 otherwise)
+        const float mn = fmaxf(m[qb], mx);
+        const float alpha = fast_exp2(m[qb] - mn);
+        l[qb] *= alpha;
+        m[qb] = mn;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[qb][db][r] *= alpha;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const float pz = fast_exp2(fmaf(s[qb][kb][r], c, -m[qb])); s[qb][kb][r] = pz; rs += pz; }
+      l[qb] += rs + partner32(rs, lane);
+    }
+    // ---- O^T += V^T P^T: every V^T fragment feeds both query blocks
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++) {
+      if (kb < nkb) {
+#pragma unroll
+        for (int h8 = 0; h8 < 2; h8++) {
+          const bf16x8 p0 = pack_frag(s[0][kb], h8), p1 = pack_frag(s[1][kb], h8);
+#pragma unroll
+          for (int db = 0; db < 2; db++) {
+            const char* a0 = tile + vofs[db] + (kb * 32 + 16 * h8) * 128;
+            const s16x4 lo = lds_tr16(a0), hi = lds_tr16(a0 + 8 * 128);
+            const s16x8 vr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            const bf16x8 vf = __builtin_bit_cast(bf16x8, vr);
+            o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, p0, o[0][db], 0, 0, 0);
+            o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, p1, o[1][db], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is released
+  const int n_txt = S - n_img, D = H * HD;
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    const int q = q0 + qb * 32 + (lane & 31);
+    if (q < S) {
+      const float inv = 1.f / l[qb];
+      bf16_t* dst = q < n_img ? Ox + ((b * n_img + q) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (q - n_img)) * (int64_t)D + h * HD);
+#pragma unroll
+      for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          float v4[4] = {o[qb][db][g * 4] * inv, o[qb][db][g * 4 + 1] * inv, o[qb][db][g * 4 + 2] * inv, o[qb][db][g * 4 + 3] * inv};
+          st4(dst + db * 32 + 8 * g + 4 * (lane >> 5), v4);
+        }
+      if (lane < 32) lse[(int64_t)bh * S + q] = m[qb] * LN2 + logf(l[qb]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
 template <int NW, typename TG>
@@ -658,6 +836,9 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   static const bool use_dma = !dma_env || atoi(dma_env) != 0;
   if (mode == 1) MMDIT_FWD(2, true);
   else if (mode != 0) return MMDIT_ERR_ARG;
+  else if (use_dma && !getenv("MMDIT_ATTN_NW") && (!dma_env || atoi(dma_env) == 2))   // (MMDIT_ATTN_DMA=1: the 32-queries-per-wave DMA kernel)
+    hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
+                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
   else if (use_dma && !getenv("MMDIT_ATTN_NW"))
     hipLaunchKernelGGL(attn_fwd_dma_kernel, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                        batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);

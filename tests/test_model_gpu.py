@@ -194,8 +194,13 @@ def test_gradients_parity_mode_vs_reference_golden(cname, h, w, golden_dir):
     print(f"[grads] {cname}: worst relative grad-norm error = {worst:.3e}")
 
 
-@pytest.mark.parametrize("cname,h,w", [("micro", 16, 16), ("xs", 64, 64)])
+@pytest.mark.parametrize("cname,h,w", [("micro", 16, 16), ("xs", 64, 64), ("b", 32, 32)])
 def test_gradients_fast_mode_vs_oracle_autograd(cname, h, w):
+    """Backward of the BENCHMARKED (bf16) mode against torch autograd through the CPU oracle run with the same rounding points
+    (bf16 GEMM operands and stored activations, flash-style attention), every parameter, at micro / XS / MMDiT-B depth (12 blocks,
+    d = 768, 32x32 latents, batch 2).  Bars: rel-L2 6e-2 per parameter through 2-3 blocks and 1e-1 through 12 blocks (bf16
+    gradients flip roundings chaotically through depth, as the forward does), 2e-1 for the three scalar parameters (heavily
+    cancelling sums); the per-parameter numbers are printed."""
     x, c, cp = make_inputs(6, 2, h, w, text_scale=30.0)
     t = torch.tensor([0.35, 0.8])
     net, sd = build(cname, precision="fast")
@@ -205,16 +210,20 @@ def test_gradients_fast_mode_vs_oracle_autograd(cname, h, w):
     sdr = {k: val.clone().requires_grad_(not k.endswith("freqs")) for k, val in sd.items()}
     vo = O.forward(sdr, O.OracleConfig(**CONFIGS[cname], attn_core="flash_bf16", gemm="bf16"), x, t, c, cp)
     vo.pow(2).mean().backward()
-    worst = 0.0
+    bar = 1e-1 if cname == "b" else 6e-2
+    res = []
     for n, p in net.named_parameters():
         if not p.requires_grad:
             assert p.grad is None
             continue
-        r = rel(p.grad, sdr[n].grad)
-        worst = max(worst, r)
-        # bf16 activations/gradients end to end; the scalar parameters are heavily cancelling sums (looser bar)
-        assert r < (2e-1 if p.numel() == 1 else 6e-2), (n, r)
-    print(f"[grads fast] {cname}: worst per-parameter rel-L2 = {worst:.3e}")
+        res.append((rel(p.grad, sdr[n].grad), n, p.numel()))
+    res.sort(reverse=True)
+    print(f"[grads fast] {cname}: {len(res)} parameters, worst per-parameter rel-L2 = {res[0][0]:.3e}, median {res[len(res) // 2][0]:.3e}")
+    for r, n, k in res[:6]:
+        print(f"    {r:.3e}  {n}  ({k} elements)")
+    for r, n, k in res:
+        assert r < (2e-1 if k == 1 else bar), (n, r)
+    net.zero_grad()
 
 
 def test_gelu_variant(golden_dir):
