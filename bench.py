@@ -116,6 +116,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true", help="development A/B: torch's multi-tensor unscale/clip/AdamW kernels instead of the three HIP launches")
     ap.add_argument("--force-dist", action="store_true", help="development: run the N>1 code path (RCCL group + gradient reducer) with one rank")
+    ap.add_argument("--graph", action="store_true", help="replay the optimizer step from a hipGraph captured after the warm-up (single rank)")
     ap.add_argument("--check-launch", action="store_true", help="rendezvous check only (gloo, no GPU): every rank joins the group, one all-reduce, rank 0 prints the world size")
     args = ap.parse_args()
 
@@ -177,6 +178,12 @@ def main():
     for _ in range(args.warmup):
         step += 1
         trainer.train_step(step)
+    if args.graph:
+        assert world == 1, "--graph: single rank only"
+        trainer.capture_graph(step + 1)
+        for _ in range(2):          # (the first replays also warm the graph's own memory)
+            step += 1
+            trainer.train_step(step)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -196,12 +203,14 @@ def main():
         # the gradient all-reduce, so a rank-0-only loop would leave the other ranks out of the collectives -- rank 0 reports.
         from sd3_amd import engine
         overlap, engine._WG_OVERLAP = engine._WG_OVERLAP, False   # serialise the side-stream wgrad launches: clean per-kernel durations
+        graph, trainer._graph = trainer._graph, None              # (eager: every launch is bracketed individually)
         ops.PROFILE = [] if rank == 0 else None
         for _ in range(3):
             step += 1
             trainer.train_step(step)
         torch.cuda.synchronize()
         engine._WG_OVERLAP = overlap
+        trainer._graph = graph
     if rank == 0 and not args.no_roofline:
         stats = {}
         for name, flops, e0, e1 in ops.PROFILE:
@@ -232,7 +241,8 @@ def main():
                                       "Gemma-2-2b-shaped text embeds (154x2304) + pooled (768); fwd+bwd+grad-allreduce+clip+AdamW (fp32 master weights)",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
                "mfma_roofline_frac_step": round(value * TRAIN_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16), 4), "final_loss": round(loss_val, 5),
-               "optimizer": "hip (unscale+clip+AdamW, 3 launches)" if trainer.hip_optimizer else "torch (multi-tensor)"}
+               "optimizer": "hip (unscale+clip+AdamW, 3 launches)" if trainer.hip_optimizer else "torch (multi-tensor)",
+               "launch": "hipGraph replay" if args.graph else "eager"}
         if trainer.hip_optimizer:
             out["optimizer_table_builds"] = trainer.optim.table_builds
         if roofline is not None:

@@ -303,6 +303,10 @@ int mmdit_clip_coef(const float* partials, int n_chunks, const float* loss_scale
  *   p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  t = step_count+1. */
 int mmdit_adamw_step(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, const float* coef_found,
                      const float* step_count, double lr, double beta1, double beta2, double eps, double weight_decay, mmdit_stream_t stream);
+/* The same with the learning rate read from DEVICE memory (one double): a launch captured into a hipGraph must not bake the
+ * scheduler's current value in (model_trainer.py:25-41, 496: the rate changes every step during warm-up / cosine decay). */
+int mmdit_adamw_step_dlr(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, const float* coef_found,
+                         const float* step_count, const double* lr_dev, double beta1, double beta2, double eps, double weight_decay, mmdit_stream_t stream);
 
 /* fp32 master weights -> bf16 GEMM operand copies for a whole parameter list in one launch (the reference gets its bf16 copies
  * from torch.autocast's weight cache, model_trainer.py:416).  Same chunk map as above: chunk c covers elements

@@ -81,6 +81,7 @@ _SIGNATURES = {
     "mmdit_grad_sumsq": ([_vp, _vp, _vp, _i, _vp, _vp], _i),
     "mmdit_clip_coef": ([_vp, _i, _vp, _f, _vp, _vp], _i),
     "mmdit_adamw_step": ([_vp, _vp, _vp, _i, _vp, _vp, _d, _d, _d, _d, _d, _vp], _i),
+    "mmdit_adamw_step_dlr": ([_vp, _vp, _vp, _i, _vp, _vp, _vp, _d, _d, _d, _d, _vp], _i),
     "mmdit_cast_multi": ([_vp, _vp, _vp, _i, _vp], _i),
 }
 ADAMW_CHUNK = 65536   # MMDIT_ADAMW_CHUNK

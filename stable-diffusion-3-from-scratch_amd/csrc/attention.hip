@@ -424,9 +424,19 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
 // MFMAs are independent, and the two waves that share a SIMD belong to different workgroups (independent barriers), so one is
 // in its MFMA phase while the other runs its softmax.  K/V tiles: the LDS-DMA ring of attn_fwd_dma_kernel (swizzles as there).
 // ------------------------------------------------------------------------------------------------
+// TRACE (tools/probes/attn_trace.hip): lane 0 of every wave of the first 2048 workgroups records s_memtime at the phase boundaries
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                            int BH, int H, int S, int n_img, float scale,
-                                                           bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse) {
+                                                           bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse, unsigned long long* __restrict__ trace) {
+  int tpos = 0;
+  auto stamp = [&]() {
+    if constexpr (TRACE) {
+      if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0 && tpos < 40) trace[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 40 + tpos] = __builtin_readcyclecounter();
+      tpos++;
+    }
+  };
+  stamp();
   constexpr int NW = 4, QW = 64;     // waves, queries per wave
   __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -449,6 +459,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
     for (int ks = 0; ks < 4; ks++) qf[qb][ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q loads are the only compiler-visible loads: retire them before the DMA stream starts
+  stamp();
 
   const int nkv = (S + KT - 1) / KT;
   // this lane's part of a tile: every wave moves two 1-KiB pieces (8 key rows each) of K and two of V
@@ -494,7 +505,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
   int stage = 0;
   for (int j = 0; j < nkv; j++) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ANS - 2)) : "memory");   // tile j has landed (ANS-2 younger tiles, 4 pieces each, may be in flight)
+    stamp();
     __builtin_amdgcn_s_barrier();
+    stamp();
     issue(j + ANS - 1, stage == 0 ? ANS - 1 : stage - 1);
     const char* tile = smem + stage * (2 * KT * 128);
     stage = stage + 1 == ANS ? 0 : stage + 1;
@@ -520,6 +533,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
         s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][ks], s[1][1], 0, 0, 0);
       }
     }
+    if constexpr (TRACE) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[1][0][0]), "v"(s[0][1][0]), "v"(s[1][1][0])); }
+    stamp();
     // ---- online softmax per query block (the row statistics are lane-local up to the l / l+32 pair)
 #pragma unroll
     for (int qb = 0; qb < 2; qb++) {
@@ -553,6 +568,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
         for (int r = 0; r < 16; r++) { const float pz = fast_exp2(fmaf(s[qb][kb][r], c, -m[qb])); s[qb][kb][r] = pz; rs += pz; }
       l[qb] += rs + partner32(rs, lane);
     }
+    if constexpr (TRACE) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[1][0][0]), "v"(s[0][1][0]), "v"(s[1][1][0])); }
+    stamp();
     // ---- O^T += V^T P^T: every V^T fragment feeds both query blocks
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
@@ -573,6 +590,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
       }
     }
   }
+  if constexpr (TRACE) { asm volatile("" :: "v"(o[0][0][0]), "v"(o[1][0][0]), "v"(o[0][1][0]), "v"(o[1][1][0])); }
+  stamp();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is released
   const int n_txt = S - n_img, D = H * HD;
 #pragma unroll
@@ -591,6 +610,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
       if (lane < 32) lse[(int64_t)bh * S + q] = m[qb] * LN2 + logf(l[qb]);
     }
   }
+  if constexpr (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -837,8 +858,8 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   if (mode == 1) MMDIT_FWD(2, true);
   else if (mode != 0) return MMDIT_ERR_ARG;
   else if (use_dma && !getenv("MMDIT_ATTN_NW") && (!dma_env || atoi(dma_env) == 2))   // (MMDIT_ATTN_DMA=1: the 32-queries-per-wave DMA kernel)
-    hipLaunchKernelGGL(attn_fwd_w64_kernel, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
-                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
+    hipLaunchKernelGGL(attn_fwd_w64_kernel<false>, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
+                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, nullptr);
   else if (use_dma && !getenv("MMDIT_ATTN_NW"))
     hipLaunchKernelGGL(attn_fwd_dma_kernel, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                        batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
@@ -848,6 +869,15 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   else if (nw == 4) MMDIT_FWD(4, false);
   else MMDIT_FWD(2, false);
 #undef MMDIT_FWD
+  return mmdit_launch_status();
+}
+
+// measurement aid (tools/probes/attn_trace.py; not declared in include/mmdit_hip.h): the 64-queries-per-wave forward with per-phase
+// s_memtime stamps, trace = 2048 workgroups x 4 waves x 40 slots of 8 bytes
+extern "C" int mmdit_probe_attn_fwd_trace(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
+                                          void* Ox, void* Oc, float* lse, void* trace, mmdit_stream_t stream) {
+  hipLaunchKernelGGL(attn_fwd_w64_kernel<true>, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K,
+                     (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, (unsigned long long*)trace);
   return mmdit_launch_status();
 }
 

@@ -85,7 +85,8 @@ struct AdamConst {
   float one_m_b1;     // 1 - beta1
   float b2, one_m_b2;
   float eps;
-  double lr, b1d, b2d;
+  double lr, b1d, b2d, wd;
+  const double* lr_dev;   // not NULL: the learning rate is read from device memory (a captured launch must not bake it in)
 };
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamConst& k, float step_size, float bc2_sqrt) {
@@ -98,13 +99,17 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
 }
 
 __global__ __launch_bounds__(TPB) void adamw_kernel(const mmdit_adamw_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor, const int64_t* __restrict__ chunk_off,
-                                                     const float* __restrict__ coef_found, const float* __restrict__ step_count, AdamConst k) {
+                                                     const float* __restrict__ coef_found, const float* __restrict__ step_count, AdamConst k) {   // (k is a by-value copy: lr / decay may be replaced below)
   float coef = 1.f;
   if (coef_found) {
     if (coef_found[1] != 0.f) return;   // inf/nan gradients: the whole step is skipped (GradScaler.step)
     coef = coef_found[0];
   }
   const double step = (double)step_count[0] + 1.0;
+  if (k.lr_dev) {
+    k.lr = k.lr_dev[0];
+    k.decay = (float)(1.0 - k.lr * k.wd);
+  }
   const float step_size = (float)(k.lr / (1.0 - pow(k.b1d, step)));
   const float bc2_sqrt = (float)sqrt(1.0 - pow(k.b2d, step));
   const int c = blockIdx.x;
@@ -200,7 +205,22 @@ extern "C" int mmdit_adamw_step(const mmdit_adamw_tensor* tensors, const int* ch
   k.b2 = (float)beta2;
   k.one_m_b2 = (float)(1.0 - beta2);
   k.eps = (float)eps;
-  k.lr = lr; k.b1d = beta1; k.b2d = beta2;
+  k.lr = lr; k.b1d = beta1; k.b2d = beta2; k.wd = weight_decay; k.lr_dev = nullptr;
+  hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, tensors, chunk_tensor, chunk_off, coef_found, step_count, k);
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_adamw_step_dlr(const mmdit_adamw_tensor* tensors, const int* chunk_tensor, const int64_t* chunk_off, int n_chunks, const float* coef_found,
+                                    const float* step_count, const double* lr_dev, double beta1, double beta2, double eps, double weight_decay, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(tensors && chunk_tensor && chunk_off && step_count && lr_dev && n_chunks > 0);
+  MMDIT_CHECK_ARG(beta1 >= 0.0 && beta1 < 1.0 && beta2 >= 0.0 && beta2 < 1.0 && eps >= 0.0 && weight_decay >= 0.0);
+  AdamConst k;
+  k.decay = 1.f;
+  k.one_m_b1 = (float)(1.0 - beta1);
+  k.b2 = (float)beta2;
+  k.one_m_b2 = (float)(1.0 - beta2);
+  k.eps = (float)eps;
+  k.lr = 0.0; k.b1d = beta1; k.b2d = beta2; k.wd = weight_decay; k.lr_dev = lr_dev;
   hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(TPB), 0, (hipStream_t)stream, tensors, chunk_tensor, chunk_off, coef_found, step_count, k);
   return mmdit_launch_status();
 }

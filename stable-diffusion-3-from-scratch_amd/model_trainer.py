@@ -165,6 +165,7 @@ class model_trainer:
         self._gen = torch.Generator(device=self.device).manual_seed(4321 + self.rank) if device_rng else None
         self.inf_padded_latents = bool(inf_padded_latents)
         self.last_loss = None
+        self._graph, self._graph_loss = None, None
         self.last_grad_norm = None   # hip_optimizer: device scalar, the unscaled gradient norm of the last step
         if is_main_process():
             total_params = sum(p.numel() for p in self.model.parameters()) / 1e6
@@ -275,6 +276,8 @@ class model_trainer:
 
     def train_step(self, step):
         """One optimizer step = accumulation_steps micro-steps + clip + AdamW."""
+        if self._graph is not None:
+            return self._replay(step)
         loss = None
         for k in range(self.accumulation_steps):
             l = self.micro_step(final=(k == self.accumulation_steps - 1))
@@ -282,6 +285,50 @@ class model_trainer:
         self.optimizer_step(step)
         self.last_loss = loss
         return loss
+
+    # ------------------------------------------------------------------------------------------
+    # hipGraph capture of the whole optimizer step.  The reference has nothing comparable; here a step is ~440 kernel launches
+    # issued through ctypes (~16 ms of host time per 33 ms step), and every launch already takes its stream explicitly, allocates
+    # nothing and never synchronises, so the step can be captured once and replayed with ONE host call.
+    def capture_graph(self, step):
+        """Capture data generation + forward + backward + (unscale, clip, AdamW) + GradScaler.update of one optimizer step into a
+        hipGraph; later train_step() calls replay it.  Call after a few eager steps (the bf16 weight copies, the zero pool,
+        the optimizer state and the scaler must be in their steady state).  Needs the HIP optimizer, the trainer's own device-side
+        data / conditioning generators (SyntheticData, device_rng=True) and a single rank."""
+        if self.device.type != "cuda" or not self.hip_optimizer or not self.device_rng or not isinstance(self.data_source, SyntheticData):
+            raise RuntimeError("capture_graph needs hip_optimizer=True, device_rng=True and the trainer's SyntheticData source on a GPU")
+        if self.reducer.enabled or self.ema_model_cpu is not None and self._ema_gpu is None:
+            raise RuntimeError("capture_graph: single-rank runs only (collectives are not captured), EMA on the GPU or off")
+        from . import engine
+        if engine._WG_OVERLAP:
+            engine._WG_OVERLAP = False     # one stream inside the capture (the side stream measured no gain: DESIGN.md 5)
+        torch.cuda.synchronize(self.device)
+        self.optim.sync_lr(self.device)
+        self.optim.prepare_capture()
+        g = torch.cuda.CUDAGraph()
+        for gen in (self._gen, self.data_source.g):
+            if gen is not None:
+                g.register_generator_state(gen)
+        self.optim.zero_grad()
+        with torch.cuda.graph(g):
+            loss = None
+            for k in range(self.accumulation_steps):
+                l = self.micro_step(final=(k == self.accumulation_steps - 1))
+                loss = l if loss is None else loss + l
+            self._hip_optimizer_step()
+            if self.grad_scaler is not None:
+                self.grad_scaler.update()
+            self._graph_loss = loss
+        self.optim.zero_grad()      # (host bookkeeping only: the graph owns the gradient buffers)
+        self._graph = g
+        return g
+
+    def _replay(self, step):
+        self.optim.sync_lr(self.device)     # the scheduler's current rate -> device (a fill only when it changed)
+        self._graph.replay()
+        self.scheduler.step(step)
+        self.last_loss = self._graph_loss
+        return self._graph_loss
 
     def update_ema(self):
         """ema = ema * decay + param * (1 - decay)  (model_trainer.py:537-541), on the GPU copy when there is one."""

@@ -28,6 +28,10 @@ class ClipAdamW(torch.optim.AdamW):
         self._steps_flat, self._step_views = None, None
         # the update kernel also rewrites the bf16 GEMM-operand copies (packing.shadow_targets); MMDIT_ADAMW_SHADOWS=0: A/B switch
         self.write_shadows = os.environ.get("MMDIT_ADAMW_SHADOWS", "1") != "0"
+        # learning rates as DEVICE doubles, one per param group (the update launch reads them: a launch captured into a hipGraph
+        # must not bake the scheduler's current value in); refreshed by one tiny fill only when a group's lr changed
+        self._lr_dev, self._lr_host = None, None
+        self._capture_staging = None
 
     # ------------------------------------------------------------------------------------------
     def _state_of(self, p):
@@ -83,15 +87,45 @@ class ClipAdamW(torch.optim.AdamW):
             self.table_builds += 1
             slot = t["slot"]
             t["slot"] = (slot + 1) % 4
-            if t["staged"][slot] is not None:
-                t["staged"][slot].synchronize()      # the copy that last used this staging buffer (4 uploads ago): long finished
-            rec = t["staging"][slot].numpy().view(_REC)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing:
+                # the captured copy node re-reads its pinned source at every replay: it gets a buffer of its own that nothing
+                # else ever writes (allocated by prepare_capture(): no allocation inside the capture)
+                if self._capture_staging is None or self._capture_staging.numel() != len(ptrs) * _REC.itemsize:
+                    raise RuntimeError("ClipAdamW: call prepare_capture() before capturing a step into a graph")
+                staging = self._capture_staging
+            else:
+                if t["staged"][slot] is not None:
+                    t["staged"][slot].synchronize()      # the copy that last used this staging buffer (4 uploads ago): long finished
+                staging = t["staging"][slot]
+            rec = staging.numpy().view(_REC)
             rec[:] = np.array(ptrs, dtype=np.int64).view(_REC).reshape(-1)
-            t["tensors"].copy_(t["staging"][slot], non_blocking=True)
-            t["staged"][slot] = torch.cuda.Event()
-            t["staged"][slot].record(torch.cuda.current_stream(dev))
+            t["tensors"].copy_(staging, non_blocking=True)
+            if not capturing:
+                t["staged"][slot] = torch.cuda.Event()
+                t["staged"][slot].record(torch.cuda.current_stream(dev))
             t["ptrs"] = ptrs
         return t
+
+    def prepare_capture(self):
+        """Call right before capturing step_clipped() into a graph: a pinned pointer-table source that belongs to the capture."""
+        n = sum(1 for g in self.param_groups for p in g["params"] if p.requires_grad)
+        self._capture_staging = torch.empty(n * _REC.itemsize, dtype=torch.uint8).pin_memory()
+
+    def sync_lr(self, dev):
+        """Bring the device copies of the learning rates up to date (outside any graph capture: the scheduler changes
+        `param_groups[i]["lr"]` on the host between steps)."""
+        lrs = [float(g["lr"]) for g in self.param_groups]
+        if self._lr_dev is None or self._lr_dev.device != dev or len(self._lr_host) != len(lrs):
+            self._lr_dev = torch.zeros(len(lrs), dtype=torch.float64, device=dev)
+            self._lr_host = [None] * len(lrs)
+        for i, lr in enumerate(lrs):
+            if self._lr_host[i] != lr:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("ClipAdamW: the learning rate changed inside a graph capture; call sync_lr() before capturing / replaying")
+                self._lr_dev[i].fill_(lr)
+                self._lr_host[i] = lr
+        return self._lr_dev
 
     @torch.no_grad()
     def step_clipped(self, loss_scale=None, max_norm=1.0):
@@ -126,14 +160,15 @@ class ClipAdamW(torch.optim.AdamW):
         _lib.check(L.mmdit_grad_sumsq(vp(t["tensors"]), vp(t["chunk_tensor"]), vp(t["chunk_off"]), t["n_chunks"], vp(t["partials"]), s), "mmdit_grad_sumsq")
         _lib.check(L.mmdit_clip_coef(vp(t["partials"]), t["n_chunks"], vp(loss_scale) if loss_scale is not None else None,
                                      float(max_norm) if max_norm is not None else 0.0, vp(t["out3"]), s), "mmdit_clip_coef")
-        for group, rows, (c0, c1) in zip(self.param_groups, groups, t["ranges"]):
+        lr_dev = self.sync_lr(dev)
+        for gi, (group, rows, (c0, c1)) in enumerate(zip(self.param_groups, groups, t["ranges"])):
             if not rows:
                 continue
             step0 = self.state[rows[0][0]]["step"]
             b1, b2 = group["betas"]
-            lr = group["lr"]
-            _lib.check(L.mmdit_adamw_step(vp(t["tensors"]), ctypes.c_void_p(t["chunk_tensor"].data_ptr() + 4 * c0), ctypes.c_void_p(t["chunk_off"].data_ptr() + 8 * c0), c1 - c0,
-                                          vp(t["out3"]), vp(step0), float(lr), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), s), "mmdit_adamw_step")
+            _lib.check(L.mmdit_adamw_step_dlr(vp(t["tensors"]), ctypes.c_void_p(t["chunk_tensor"].data_ptr() + 4 * c0), ctypes.c_void_p(t["chunk_off"].data_ptr() + 8 * c0), c1 - c0,
+                                              vp(t["out3"]), vp(step0), ctypes.c_void_p(lr_dev.data_ptr() + 8 * gi), float(b1), float(b2), float(group["eps"]),
+                                              float(group["weight_decay"]), s), "mmdit_adamw_step_dlr")
         steps_flat.add_(1.0 - t["out3"][1])
         packing.bump_epoch()     # the kernels wrote the parameters through raw pointers: the bf16 operand copies are stale now ...
         if shadow_packs:         # ... except the ones the update kernel has just rewritten
