@@ -669,17 +669,22 @@ def test_fp8_inference_mode():
 
 
 def test_graph_replay_matches_eager_steps():
-    """model_trainer.capture_graph: the optimizer step replayed from a hipGraph (one host call instead of ~440 launches) follows the
-    eager step: same seeds, three eager warm-up steps each, then three eager steps vs capture + three replays; the warm-up lr schedule
-    changes the learning rate between the replays (it is read from device memory).  Losses to 1e-5; parameters to the run-to-run
-    noise of the step itself (fp32 atomic column sums + bf16 rounding downstream make two EAGER runs differ by up to 4e-4 of a
-    parameter's range: tools/probes/determinism.py)."""
+    """model_trainer.capture_graph: the optimizer step replayed from a hipGraph (one host call instead of ~440 launches) IS the eager
+    step.  One trainer, three eager warm-up steps, snapshot of everything (parameters, AdamW state, loss scale, the three RNG
+    streams); steps 4-6 eager; restore the snapshot; capture; steps 4-6 replayed.  The warm-up schedule changes the learning rate
+    between the replays (it is read from device memory, not baked into the captured launch).
+    Asserted: the loss of step 4 bit-identical (same parameters, same generated batch, deterministic forward); later losses and the
+    final parameters to the run-to-run noise of the backward pass itself (fp32 atomic column sums are order-dependent and the bf16
+    rounding downstream turns that into a few 2^-9 flips: two EAGER runs differ by up to 4e-4 of a parameter's range,
+    tools/probes/determinism.py)."""
     import sd3_amd  # noqa: F401
-    from sd3_amd import engine
+    from sd3_amd import engine, packing
     from sd3_amd.model_trainer import model_trainer
     from sd3_amd.models.diff_model import diff_model
 
-    def run(graph):
+    overlap = engine._WG_OVERLAP
+    try:
+        engine._WG_OVERLAP = False
         torch.manual_seed(0)
         net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
                          device=torch.device("cuda:0"), positional_encoding="RoPE2d", **CONFIGS["micro"])
@@ -687,22 +692,43 @@ def test_graph_replay_matches_eager_steps():
         tr = model_trainer(net, batchSize=4, accumulation_steps=1, totalSteps=100, lr=1e-3, ema_update_freq=1, ema_decay=0.9, warmup_steps=8,
                            use_lr_scheduler=False, device=torch.device("cuda:0"), saveDir="/tmp/_t", numSaveSteps=100, null_prob_pooled=0.1,
                            null_prob_gemma=0.316, null_prob_bert=0.316, max_res=128, device_rng=True, use_ema=False)
-        losses = [float(tr.train_step(s)) for s in (1, 2, 3)]
-        if graph:
-            tr.capture_graph(4)
-            assert tr._graph is not None
-        losses += [float(tr.train_step(s)) for s in (4, 5, 6)]
+        for s in (1, 2, 3):
+            tr.train_step(s)
         torch.cuda.synchronize()
-        return losses, [p.detach().clone() for p in net.parameters()], tr.optim.param_groups[0]["lr"]
+        params = [p for p in net.parameters()]
+        snap_p = [p.detach().clone() for p in params]
+        snap_o = {id(p): {k: v.clone() for k, v in tr.optim.state[p].items()} for p in params if p in tr.optim.state}
+        snap_s = (tr.grad_scaler._scale.clone(), tr.grad_scaler._growth_tracker.clone())
+        snap_r = (torch.cuda.get_rng_state(), tr._gen.get_state(), tr.data_source.g.get_state())
 
-    overlap = engine._WG_OVERLAP
-    try:
-        l0, p0, lr0 = run(False)
-        l1, p1, lr1 = run(True)
+        def three_steps():
+            losses = [float(tr.train_step(s)) for s in (4, 5, 6)]
+            torch.cuda.synchronize()
+            return losses, [p.detach().clone() for p in params], tr.optim.param_groups[0]["lr"]
+
+        l0, p0, lr0 = three_steps()
+        with torch.no_grad():
+            for p, q in zip(params, snap_p):
+                p.copy_(q)
+                for k, v in snap_o.get(id(p), {}).items():
+                    tr.optim.state[p][k].copy_(v)
+            tr.grad_scaler._scale.copy_(snap_s[0])
+            tr.grad_scaler._growth_tracker.copy_(snap_s[1])
+        packing.bump_epoch()                       # the parameters were rewritten: their bf16 operand copies are stale
+        torch.cuda.set_rng_state(snap_r[0])
+        tr._gen.set_state(snap_r[1])
+        tr.data_source.g.set_state(snap_r[2])
+        tr.scheduler.step(3)
+        net(*[a.cuda() for a in make_inputs(3, 2, 16, 16)][:1], torch.tensor([0.3, 0.7]), *[a.cuda() for a in make_inputs(3, 2, 16, 16)][1:]).sum().backward()
+        tr.optim.zero_grad()                       # (one eager pass refreshes the bf16 copies outside the capture)
+        torch.cuda.set_rng_state(snap_r[0])
+        tr.capture_graph(4)
+        assert tr._graph is not None
+        l1, p1, lr1 = three_steps()
     finally:
         engine._WG_OVERLAP = overlap
     print(f"[graph] eager losses {l0}  replayed {l1}")
-    assert lr0 == lr1 and np.allclose(l0, l1, rtol=1e-5)
+    assert lr0 == lr1 and l0[0] == l1[0] and np.allclose(l0, l1, rtol=1e-3)
     for a, b in zip(p0, p1):
         assert rel(a, b) < 1e-3 and float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6
-    assert abs(l0[5] - l0[3]) > 1e-4 * abs(l0[3])      # (the steps do move the loss)
+    assert abs(l0[2] - l0[0]) > 1e-4 * abs(l0[0])      # (the steps do move the loss)
