@@ -107,12 +107,14 @@ def _dgrad(m, dY, W, out_dtype, **kw):
     return ops.gemm(dY, W, b_kmajor=True, out_dtype=out_dtype, precision=m.prec, **kw)
 
 
-# Weight gradients are off the critical path of the backward pass (only the optimizer consumes them), so the
-# deferred grouped wgrad launch of a block runs on a side HIP stream and fills the tail bubbles of the next
-# block's dgrad / row kernels on the main stream.  MMDIT_WGRAD_STREAM=0 disables it.
+# Weight gradients are off the critical path of the backward pass (only the optimizer consumes them): the deferred grouped
+# wgrad launch of a block CAN run on a side HIP stream (MMDIT_WGRAD_STREAM=1).  Measured in round 2 (same box, A/B): 37.45 vs
+# 37.41 ms/step before and 1909 vs 1922 img/s after the 320x256-tile kernel -- no gain: the persistent 256x256 wgrad kernel owns
+# every CU (128 KB LDS, 2 x 243 VGPRs per SIMD), so main-stream kernels queue behind it instead of overlapping with it (the row
+# kernels showed 17 -> 116 us in the profile).  Default: one stream (clean per-kernel durations, graph-capturable step).
 import os as _os
 _WG_MODE = _os.environ.get("MMDIT_WGRAD_MODE", "streamk")
-_WG_OVERLAP = _os.environ.get("MMDIT_WGRAD_STREAM", "1") != "0"
+_WG_OVERLAP = _os.environ.get("MMDIT_WGRAD_STREAM", "0") == "1"
 _FUSE_SWIGLU = _os.environ.get("MMDIT_FUSE_SWIGLU", "1") != "0"   # SwiGLU activation in the up-projection GEMM's epilogue (A/B switch)
 _wg_streams = {}
 

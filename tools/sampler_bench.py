@@ -1,0 +1,60 @@
+"""BASELINE.json config 5 on one GPU: 28-step rectified-flow sampler (Euler, CFG: a batch of 2B forwards per step) at MMDiT-L / 512^2
+(or --B: MMDiT-B / 256^2) through diff_model.sample_imgs, bf16 and fp8 operands; identity stand-ins for the text encoders / VAE
+decode (out of this build's scope).  Prints images/s = B / wall.  python tools/sampler_bench.py [--B] [--batch 32] [--steps 28]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sd3_amd  # noqa: E402,F401
+from sd3_amd.models.diff_model import diff_model  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--B", action="store_true")
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--steps", type=int, default=28)
+args = ap.parse_args()
+cfg = dict(dim=768, num_heads=12, num_blocks=12) if args.B else dict(dim=1024, num_heads=16, num_blocks=24)
+res = 256 if args.B else 512
+dev = torch.device("cuda:0")
+net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu", device=dev, positional_encoding="RoPE2d", **cfg)
+
+
+class _Dec:
+    def __init__(self, s):
+        self.sample = s
+
+
+class _Cfg:
+    latent_channels, shift_factor, scaling_factor = 16, 0.0, 8.0
+
+
+class _VAE:
+    config, dtype = _Cfg(), torch.float32
+
+    def decode(self, z):
+        return _Dec(z)
+
+
+class _Enc:
+    VAE = _VAE()
+
+    def text_to_embedding(self, text):
+        g = torch.Generator().manual_seed(1)
+        return torch.randn(1, 154, 2304, generator=g) * 3, torch.randn(1, 768, generator=g)
+
+
+net.text_encoders = _Enc()
+for prec in ("fast", "fp8"):
+    net.set_precision(prec)
+    net.sample_imgs(args.batch, 2, ["x"], cfg_scale=3.0, width=res, height=res, generator=torch.Generator().manual_seed(0))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = net.sample_imgs(args.batch, args.steps, ["x"], cfg_scale=3.0, width=res, height=res, generator=torch.Generator().manual_seed(0))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"{'MMDiT-B 256^2' if args.B else 'MMDiT-L 512^2'} sampler, {args.steps} Euler steps, CFG, batch {args.batch} [{'bf16' if prec == 'fast' else 'fp8'}]: "
+          f"{dt * 1e3:.1f} ms, {args.batch / dt:.2f} images/s, finite={bool(torch.isfinite(out).all())}")
