@@ -1,0 +1,21 @@
+cd $GRAFT_REPO_ROOT; R=$1
+python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench.err
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace -d gpurun_out/prof_$R -o run -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/${R}_prof.log 2>&1
+DB=$(find gpurun_out/prof_$R -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB 11 > gpurun_out/${R}_bench_kernel_stats.txt
+python tools/rocpd_gaps.py $DB > gpurun_out/${R}_step_gaps.txt 2>&1
+rm -rf gpurun_out/prof_$R
+bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
+( echo "== tools/gemm_bench.py"; python tools/gemm_bench.py 2>&1 | grep -v amdgpu
+  echo "== tools/attn_bench.py"; python tools/attn_bench.py 30 2>&1 | grep -v amdgpu
+  echo "== tools/row_bench.py"; python tools/row_bench.py 2>&1 | grep -v amdgpu
+  echo "== tools/optim_bench.py"; python tools/optim_bench.py 2>&1 | grep -v amdgpu
+  echo "== tools/probes/phase_times.py"; python tools/probes/phase_times.py 2>&1 | grep "GPU\|host"
+  echo "== tools/probes/l_config.py 16"; python tools/probes/l_config.py 16 2>&1 | tail -1
+  echo "== tools/probes/l_config.py 64"; python tools/probes/l_config.py 64 2>&1 | tail -1
+  echo "== tools/sampler_bench.py"; python tools/sampler_bench.py 2>&1 | grep sampler
+  echo "== tools/sampler_bench.py --B --batch 64"; python tools/sampler_bench.py --B --batch 64 2>&1 | grep sampler
+  echo "== tools/vae_bench.py"; python tools/vae_bench.py 2>&1 | grep -v amdgpu | tail -4
+  echo "== bench.py --graph"; python bench.py --no-cpu-baseline --no-roofline --graph 2>/dev/null | cut -c1-200
+) > gpurun_out/${R}_probe_outputs.txt 2>&1
