@@ -64,6 +64,33 @@ __device__ __forceinline__ void tile_r2s(const u32x4 (&st)[tile_chunks<NT>()], c
   }
 }
 
+// Unpadded [64 rows][128 B] tile that is read BOTH ways (ds_read_b128 row fragments and ds_read_b64_tr_b16 transposed fragments,
+// e.g. K in the dQ kernel, Q / dO in the dK/dV kernel): no single row pitch is conflict-free for both (144 B: 2-way conflicts on the
+// transposed reads, PMC: 21-23 % of the LDS cycles of the backward kernels; 192 B: 4-way on the row reads), an XOR swizzle is:
+// 16-byte piece p of row r lives at slot p ^ sw2(r), sw2(r) = ((r >> 1) & 7) ^ (((r >> 1) & 1) << 2).
+__device__ __forceinline__ int sw2(int r) { return ((r >> 1) & 7) ^ (((r >> 1) & 1) << 2); }
+template <int NT>
+__device__ __forceinline__ void tile_r2s_sw(const u32x4 (&st)[tile_chunks<NT>()], char* tile, int tid) {
+#pragma unroll
+  for (int i = 0; i < tile_chunks<NT>(); i++) {
+    const int c = tid + i * NT, row = c >> 3, kc = c & 7;
+    if (512 % NT == 0 || c < 512) *LDS_PTR(u32x4, tile + row * 128 + ((kc ^ sw2(row)) << 4)) = st[i];
+  }
+}
+__device__ __forceinline__ bf16x8 row_frag_d(const char* tile, int rb, int ks, int lane) {
+  const int r = rb + (lane & 31);
+  return *LDS_PTR(const bf16x8, tile + r * 128 + (((ks * 2 + (lane >> 5)) ^ sw2(r)) << 4));
+}
+__device__ __forceinline__ bf16x8 tr_frag_d(const char* tile, int rb, int h8, int cb, int lane) {
+  const int row = rb + 16 * h8 + 4 * (lane >> 5) + ((lane & 15) >> 2);
+  const int cbyte = (cb * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
+  const char* p0 = tile + row * 128 + ((((cbyte >> 4) ^ sw2(row)) << 4) | (cbyte & 15));
+  const char* p1 = tile + (row + 8) * 128 + ((((cbyte >> 4) ^ sw2(row + 8)) << 4) | (cbyte & 15));
+  s16x4 lo = lds_tr16(p0), hi = lds_tr16(p1);
+  s16x8 r = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 // pointer to the 64-wide head slice of token s (joint index) in the stream-split (B, L, H*64) tensors
 __device__ __forceinline__ const bf16_t* tok_ptr(const bf16_t* x_img, const bf16_t* x_txt, int64_t b, int s, int n_img, int n_txt, int D, int h) {
   if (s < n_img) return x_img + ((b * n_img + s) * (int64_t)D + h * HD);
@@ -626,9 +653,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
   // delta[q] = sum_d dO[q,d] O[q,d] is formed here from the query's own dO / O rows (each lane holds half of the 64 features of its
   // query) and written out for the dK/dV kernel that follows on the same stream -- no separate preparation pass.
   constexpr int NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * P144];
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128];
   char* ktile = smem;
-  char* vtile = smem + KT * P144;
+  char* vtile = smem + KT * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int qtile, bh;
   map_block((S + 32 * NW - 1) / (32 * NW), BH, qtile, bh);
@@ -678,8 +705,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
     tile_g2r<NT>(sk, Kb, j * KT, S, tid);
     tile_g2r<NT>(sv, Vb, j * KT, S, tid);
     __syncthreads();
-    tile_r2s<NT>(sk, ktile, P144, tid);
-    tile_r2s<NT>(sv, vtile, P144, tid);
+    tile_r2s_sw<NT>(sk, ktile, tid);
+    tile_r2s_sw<NT>(sv, vtile, tid);
     __syncthreads();
     if (!active) continue;
 #pragma unroll
@@ -690,8 +717,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
       for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(ktile, P144, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(vtile, P144, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(ktile, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(vtile, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
       }
       const bool ragged = (j + 1) * KT > S;
 #pragma unroll
@@ -704,7 +731,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
       for (int h8 = 0; h8 < 2; h8++) {
         const bf16x8 dsf = pack_frag(s, h8);
 #pragma unroll
-        for (int db = 0; db < 2; db++) acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(ktile, P144, kb * 32, h8, db, lane), dsf, acc[db], 0, 0, 0);
+        for (int db = 0; db < 2; db++) acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_d(ktile, kb * 32, h8, db, lane), dsf, acc[db], 0, 0, 0);
       }
     }
   }
@@ -731,10 +758,10 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV) {
   constexpr int NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * P144 + 2 * KT * 4];
+  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128 + 2 * KT * 4];
   char* qtile = smem;
-  char* dotile = smem + KT * P144;
-  float* lse_s = (float*)(smem + 2 * KT * P144);
+  char* dotile = smem + KT * 128;
+  float* lse_s = (float*)(smem + 2 * KT * 128);
   float* del_s = lse_s + KT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int ktile, bh;
@@ -774,8 +801,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
     float lv = 0.f, dl = 0.f;
     if (tid < KT && jq * KT + tid < S) { lv = lse[(int64_t)bh * S + jq * KT + tid] * LOG2E; dl = delta[(int64_t)bh * S + jq * KT + tid]; }
     __syncthreads();
-    tile_r2s<NT>(sq, qtile, P144, tid);
-    tile_r2s<NT>(sd, dotile, P144, tid);
+    tile_r2s_sw<NT>(sq, qtile, tid);
+    tile_r2s_sw<NT>(sd, dotile, tid);
     if (tid < KT) { lse_s[tid] = lv; del_s[tid] = dl; }
     __syncthreads();
     if (!active) continue;
@@ -787,8 +814,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
       for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(qtile, P144, qb * 32, ks, lane), kf[ks], s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(dotile, P144, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(qtile, qb * 32, ks, lane), kf[ks], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(dotile, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
       }
       f32x16 ds;
 #pragma unroll
@@ -810,8 +837,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
         const bf16x8 pf = pack_frag(s, h8), dsf = pack_frag(ds, h8);
 #pragma unroll
         for (int db = 0; db < 2; db++) {
-          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(dotile, P144, qb * 32, h8, db, lane), pf, dv[db], 0, 0, 0);
-          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(qtile, P144, qb * 32, h8, db, lane), dsf, dk[db], 0, 0, 0);
+          dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_d(dotile, qb * 32, h8, db, lane), pf, dv[db], 0, 0, 0);
+          dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_d(qtile, qb * 32, h8, db, lane), dsf, dk[db], 0, 0, 0);
         }
       }
     }
