@@ -302,6 +302,9 @@ __device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int rb, int h8, i
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// DBG (ablation builds, tools/probes/attn_ablate.py): 1 no exponentials (p = s), 2 no P V MFMAs, 4 no K Q^T MFMAs, 8 no LDS fragment reads
+// (constant operands), 16 no per-tile wait / barrier / DMA, 32 no rescale / row sums
+template <int DBG = 0>
 __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                            int BH, int H, int S, int n_img, float scale,
                                                            bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse) {
@@ -360,9 +363,11 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
   }
   int stage = 0;
   for (int j = 0; j < nkv; j++) {
+    if (!(DBG & 16) || j == 0) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ANS - 2)) : "memory");   // tile j has landed (ANS-2 younger tiles may be in flight)
     __builtin_amdgcn_s_barrier();                                          // ... for every wave; and everyone has left tile j-1
     issue(j + ANS - 1, stage == 0 ? ANS - 1 : stage - 1);                  // refill the stage of tile j-1
+    }
     const char* tile = smem + stage * (2 * KT * 128);
     stage = stage + 1 == ANS ? 0 : stage + 1;
     if (!active) continue;
@@ -379,8 +384,10 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
 #pragma unroll
       for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ks++)
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*LDS_PTR(const bf16x8, kp[ks] + kb * 32 * 128), qf[ks], s[kb], 0, 0, 0);
+      for (int ks = 0; ks < 4; ks++) {
+        if (DBG & 4) { s[kb][ks] += (float)qf[ks][0]; continue; }
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((DBG & 8) ? qf[(ks + 1) & 3] : *LDS_PTR(const bf16x8, kp[ks] + kb * 32 * 128), qf[ks], s[kb], 0, 0, 0);
+      }
       if ((j + 1) * KT > S) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
@@ -395,7 +402,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
     mx = fmaxf(mx, partner32(mx, lane)) * c;   // the two lanes of a query (l, l + 32)
     // the accumulators are rescaled only when some query's running maximum grows (exact: alpha == 1 otherwise); after the first
     // tiles that is rare, and it takes 32 multiplies per lane out of most iterations
-    if (!__all(mx <= m)) {
+    if (!(DBG & 32) && !__all(mx <= m)) {
       const float mn = fmaxf(m, mx);
       const float alpha = fast_exp2(m - mn);
       l *= alpha;
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -m)); s[kb][r] = p; rs += p; }
+      for (int r = 0; r < 16; r++) { const float p = (DBG & 1) ? fmaf(s[kb][r], c, 1.f) : fast_exp2(fmaf(s[kb][r], c, -m)); s[kb][r] = p; if (!(DBG & 32)) rs += p; }
     l += rs + partner32(rs, lane);
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
@@ -419,6 +426,8 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
           const bf16x8 pf = pack_frag(s[kb], h8);
 #pragma unroll
           for (int db = 0; db < 2; db++) {
+            if (DBG & 2) { o[db][h8] += (float)pf[0]; continue; }
+            if (DBG & 8) { o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[db + h8], pf, o[db], 0, 0, 0); continue; }
             const char* q0 = vp[db] + (kb * 32 + 16 * h8) * 128;
             const s16x4 lo = lds_tr16(q0), hi = lds_tr16(q0 + 8 * 128);
             const s16x8 vr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -888,7 +897,7 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
     hipLaunchKernelGGL(attn_fwd_w64_kernel<false>, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                        batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, nullptr);
   else if (use_dma && !getenv("MMDIT_ATTN_NW"))
-    hipLaunchKernelGGL(attn_fwd_dma_kernel, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
+    hipLaunchKernelGGL(attn_fwd_dma_kernel<0>, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                        batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
   else if (nw == 8) MMDIT_FWD(8, false);
   else if (nw == 7) MMDIT_FWD(7, false);
@@ -905,6 +914,19 @@ extern "C" int mmdit_probe_attn_fwd_trace(const void* Q, const void* K, const vo
                                           void* Ox, void* Oc, float* lse, void* trace, mmdit_stream_t stream) {
   hipLaunchKernelGGL(attn_fwd_w64_kernel<true>, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, (unsigned long long*)trace);
+  return mmdit_launch_status();
+}
+
+// measurement aid (tools/probes/attn_ablate.py; not part of include/mmdit_hip.h): the forward kernel with parts of its loop removed
+extern "C" int mmdit_probe_attn_fwd_dbg(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
+                                        void* Ox, void* Oc, float* lse, int dbg, mmdit_stream_t stream) {
+#define MMDIT_DBG(D) case D: hipLaunchKernelGGL(attn_fwd_dma_kernel<D>, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)Q, \
+                                                 (const bf16_t*)K, (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse); break;
+  switch (dbg) {
+    MMDIT_DBG(0) MMDIT_DBG(1) MMDIT_DBG(2) MMDIT_DBG(4) MMDIT_DBG(8) MMDIT_DBG(16) MMDIT_DBG(32) MMDIT_DBG(33) MMDIT_DBG(6) MMDIT_DBG(39) MMDIT_DBG(24) MMDIT_DBG(57) MMDIT_DBG(63)
+    default: return MMDIT_ERR_ARG;
+  }
+#undef MMDIT_DBG
   return mmdit_launch_status();
 }
 
