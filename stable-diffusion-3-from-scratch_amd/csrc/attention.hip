@@ -281,6 +281,12 @@ __device__ __forceinline__ void attn_glds16(const void* gptr, uint32_t lds_dst_)
   const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_dst) : "memory", "m0");
 }
+__device__ __forceinline__ void attn_glds16s(uint32_t voff, const char* sbase_, uint32_t lds_dst_) {   // wave-uniform base + 32-bit lane offset
+  const uint64_t a = (uint64_t)(uintptr_t)sbase_;
+  const char* sbase = (const char*)(uintptr_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(a >> 32)) << 32) | (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)a));
+  const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+  asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
+}
 // value of lane ^ 32 without an LDS round trip: v_permlane32_swap exchanges the upper half of its first operand with the lower
 // half of the second; whichever way the compiler allocates the two copies of x (one register: both results are the partner's
 // value; two registers: [own | partner] and [partner | own]), the select below picks the partner
@@ -323,11 +329,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
   const int qc = min(q, S - 1);
   const bool active = qtile * 32 * NW + wave * 32 < S;
 
-  bf16x8 qf[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q loads are the only compiler-visible loads: retire them before the DMA stream starts
-
+  if (DBG & 64) return;   // launch floor
   const int nkv = (S + KT - 1) / KT;
   // this lane's part of a tile: key row 8 * wave + (lane >> 3), 16-byte slot lane & 7
   const int rl = 8 * wave + (lane >> 3), slot = lane & 7;
@@ -339,6 +341,12 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
   };
 #pragma unroll
   for (int st = 0; st < ANS - 1; st++) issue(st, st);
+  // the Q fragments are requested BEHIND the first K/V tiles, so the two latencies overlap; the explicit wait that follows covers
+  // both (these are the only compiler-visible loads of the kernel: nothing else may make the compiler drain the DMA queue)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   f32x16 o[2];
 #pragma unroll
@@ -435,20 +443,273 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
           }
         }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is released
-  if (q < S) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is reused
+  __builtin_amdgcn_s_barrier();                      // ... everybody's, and every wave has left the last tile
+  if (DBG & 128) { if (o[0][0] + o[1][3] + l == 12345.f) lse[0] = 1.f; return; }
+  // Epilogue: the accumulators hold O^T fragments (lane = query, 4 consecutive features per register group): stored directly, every
+  // instruction would touch 32 different rows with 8 bytes each (16 instructions per wave, store-issue-bound: the empty-loop
+  // ablation of this kernel takes 32 of its 73 us).  Each wave stages its 32 x 64 bf16 block through a private 4 KB of the (now
+  // idle) ring -- 16-byte chunk c of row r at chunk c ^ (r & 7), conflict-free both ways -- and writes it as 8 rows x 128 B per
+  // instruction (whole lines).
+  {
     const float inv = 1.f / l;
-    const int n_txt = S - n_img, D = H * HD;
-    bf16_t* dst = q < n_img ? Ox + ((b * n_img + q) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (q - n_img)) * (int64_t)D + h * HD);
+    char* stg = smem + wave * 4096;
+    const int wr = lane & 31, wc = lane >> 5;
 #pragma unroll
     for (int db = 0; db < 2; db++)
 #pragma unroll
       for (int g = 0; g < 4; g++) {
-        float v4[4] = {o[db][g * 4] * inv, o[db][g * 4 + 1] * inv, o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv};
-        st4(dst + db * 32 + 8 * g + 4 * (lane >> 5), v4);
+        const u32x2 pk = {pack_bf2(o[db][g * 4] * inv, o[db][g * 4 + 1] * inv), pack_bf2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv)};
+        *LDS_PTR(u32x2, stg + wr * 128 + (((db * 4 + g) ^ (wr & 7)) << 4) + wc * 8) = pk;
       }
-    if (lane < 32) lse[(int64_t)bh * S + q] = m * LN2 + logf(l);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+    const int n_txt = S - n_img, D = H * HD;
+    const int rr = lane >> 3, rc = lane & 7;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr, qq = qtile * 32 * NW + wave * 32 + r;
+      const u32x4 t = *LDS_PTR(const u32x4, stg + r * 128 + ((rc ^ (r & 7)) << 4));
+      if (qq < S) {
+        bf16_t* dst = qq < n_img ? Ox + ((b * n_img + qq) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (qq - n_img)) * (int64_t)D + h * HD);
+        *(u32x4*)(dst + rc * 8) = t;
+      }
+    }
+    if (q < S && lane < 32) lse[(int64_t)bh * S + q] = m * LN2 + logf(l);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, persistent: the LDS-DMA kernel above as a loop over work items (q-tile, batch-head).  Ablations of that kernel at
+// S = 410 (tools/probes/attn_ablate.py): 69 us in full, 26 us with an EMPTY tile loop -- 7.6 us to launch 1536 workgroups, 12 us of
+// workgroups waiting for their first K/V tiles and Q rows (three rounds of HBM latency with nothing else resident to hide them),
+// 6.5-11 us of output stores.  Here 2 workgroups per CU stay resident and walk the items; the DMA cursor runs ahead across item
+// boundaries (the first three tiles of the next item land while the last tiles of this one are multiplied), the next item's Q
+// fragments are requested as soon as the last K Q^T of the current one has issued, and the output stores of an item drain under
+// the next item's MFMAs.
+// MEASURED (S = 410, 64 x 12 heads): 71.6 us against 69.7 us for the one-shot kernel on the same box -- the "fixed" costs of the
+// ablation are not additive: with two workgroups per CU they were already hidden behind the other workgroup's tiles.  What is left
+// is the per-wave dependent chain (fragment reads -> K Q^T -> max/exp/sum -> P V), which more residency does not shorten.  Kept
+// selectable (MMDIT_ATTN_DMA=3) as the record of that experiment; not the default.
+// ------------------------------------------------------------------------------------------------
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 4) void attn_fwd_pers_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                            int BH, int H, int S, int n_img, float scale,
+                                                            bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse) {
+  constexpr int NW = 8;
+  __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const int ntile = (S + 32 * NW - 1) / (32 * NW), items = ntile * BH, G = (int)gridDim.x;
+  const int nkv = (S + KT - 1) / KT;
+  // item v = blockIdx + k G -> (q-tile, batch-head): as map_block on the virtual index (G is a multiple of 8, so v keeps the block's
+  // XCD), with the q-tile rotated by the pass k and by the upper half of the grid: the last q-tile of a sequence is partial (S = 410:
+  // 5 of 8 waves busy), and a workgroup -- and the two workgroups of a CU -- should see full and partial tiles in turn
+  const bool rot = BH % 8 == 0 && (G & 15) == 0 && (G >> 4) % ntile == 0;
+  auto item_at = [&](int v, int& tile, int& bh) {
+    if (BH % 8 == 0) {
+      const int xcd = v & 7, j = v >> 3;
+      tile = j % ntile;
+      if (rot) tile = (tile + v / G + (2 * (v % G) >= G ? 1 : 0)) % ntile;
+      bh = (j / ntile) * 8 + xcd;
+    } else {
+      tile = v % ntile;
+      bh = v / ntile;
+    }
+    tile = __builtin_amdgcn_readfirstlane(tile);   // (the division runs on the VALU: tell the compiler the results are uniform)
+    bh = __builtin_amdgcn_readfirstlane(bh);
+  };
+
+  // ---- DMA cursor (wave-uniform): the next K/V tile to request ---------------------------------------------------
+  // this lane's part of a tile: key row 8 * wave + (lane >> 3), 16-byte slot lane & 7
+  const int rl = 8 * wave + (lane >> 3), slot = lane & 7;
+  const int kcol2 = (slot ^ ((rl >> 1) & 7)) * 16, vcol2 = (slot ^ (4 * ((rl >> 1) & 1))) * 16;   // byte column inside the 128-byte row
+  int c_item = (int)blockIdx.x, c_j = 0;
+  const char *cK, *cV;   // wave-uniform bases of the cursor's item (SGPRs; the lane part is a 32-bit offset)
+  auto cursor_item = [&]() {
+    int t, bh;
+    item_at(c_item, t, bh);
+    cK = (const char*)(K + (int64_t)bh * S * HD);
+    cV = (const char*)(V + (int64_t)bh * S * HD);
+  };
+  cursor_item();
+  auto issue_next = [&](int stage) {
+    const uint32_t row = (uint32_t)min(c_j * KT + rl, S - 1) * (HD * 2);
+    attn_glds16s(row + kcol2, cK, lds0 + stage * (2 * KT * 128) + wave * 1024);
+    attn_glds16s(row + vcol2, cV, lds0 + stage * (2 * KT * 128) + KT * 128 + wave * 1024);
+    if (c_j + 1 < nkv) {
+      c_j++;
+    } else if (c_item + G < items) {
+      c_item += G;
+      c_j = 0;
+      cursor_item();
+    }   // else: past the end of the stream the last tile is requested again (into a free stage; never read)
+  };
+#pragma unroll
+  for (int st = 0; st < ANS - 1; st++) issue_next(st);
+
+  bf16x8 qf[4];
+  auto load_q = [&](int v) {   // plain loads: the compiler tracks them (its waits over-count the untracked DMA traffic: safe)
+    int t, bh;
+    item_at(v, t, bh);
+    const int qc = min(t * 32 * NW + wave * 32 + (lane & 31), S - 1);
+    const bf16_t* src = Q + ((int64_t)bh * S + qc) * HD + (lane >> 5) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(src + ks * 16);
+  };
+  load_q((int)blockIdx.x);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
+
+  const float c = scale * LOG2E;
+  // per-lane LDS offsets of the fragment reads (see attn_fwd_dma_kernel); the k-step / feature-half only flips address bits 5-6,
+  // so one offset per operand is kept and the others are formed with an XOR
+  uint32_t kofs0, vofs0;
+  {
+    const int l31 = lane & 31, hi5 = lane >> 5, swz = (l31 >> 1) & 7, f = swz >> 1, e = hi5 ^ (swz & 1);
+    kofs0 = l31 * 128 + (f << 5) + (e << 4);
+    const int rr = (lane & 15) >> 2, x = (lane >> 4) & 1, y = lane & 3, bb = (rr >> 1) & 1;
+    vofs0 = KT * 128 + (4 * hi5 + rr) * 128 + (bb << 6) + (x << 5) + ((y >> 1) << 4) + ((y & 1) << 3);
+  }
+  const int n_txt = S - n_img, D = H * HD;
+  int stage = 0, v = (int)blockIdx.x, j = 0, qtile, bh;
+  item_at(v, qtile, bh);
+  f32x16 o[2];
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[db][r] = 0.f;
+  float m = -INFINITY, l = 0.f;
+#pragma unroll 1
+  for (;;) {   // one K/V tile per iteration, items back to back
+    // Tile j has landed once at most the two younger tiles are outstanding.  (At an item's first tile the queue also holds the
+    // previous item's output stores -- gfx9 counts stores in vmcnt -- all younger than the tiles: the same count over-waits.)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ANS - 2)) : "memory");
+    __builtin_amdgcn_s_barrier();                              // ... for every wave; and everyone has left the previous tile
+    issue_next(stage == 0 ? ANS - 1 : stage - 1);              // refill the stage of the previous tile
+    const bool active = qtile * 32 * NW + wave * 32 < S;       // wave-uniform
+    const bool last = j == nkv - 1, more = v + G < items;
+    const uint32_t tb = (uint32_t)(stage * (2 * KT * 128));
+    const char* kp[4] = {smem + (tb + kofs0), smem + (tb + (kofs0 ^ 32)), smem + (tb + (kofs0 ^ 64)), smem + (tb + (kofs0 ^ 96))};
+    const char* vp[2] = {smem + (tb + vofs0), smem + (tb + (vofs0 ^ 64))};
+    f32x16 s[2];
+    if (active) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++) {
+        if (j * KT + kb * 32 >= S) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) s[kb][r] = -INFINITY;
+          continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*LDS_PTR(const bf16x8, kp[ks] + kb * 32 * 128), qf[ks], s[kb], 0, 0, 0);
+        if ((j + 1) * KT > S) {
+#pragma unroll
+          for (int r = 0; r < 16; r++)
+            if (j * KT + kb * 32 + acc_row(r, lane) >= S) s[kb][r] = -INFINITY;
+        }
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
+      mx = fmaxf(mx, partner32(mx, lane)) * c;   // the two lanes of a query (l, l + 32)
+      // the accumulators are rescaled only when some query's running maximum grows (exact: alpha == 1 otherwise)
+      if (!__all(mx <= m)) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = fast_exp2(m - mn);
+        l *= alpha;
+        m = mn;
+#pragma unroll
+        for (int db = 0; db < 2; db++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[db][r] *= alpha;
+      }
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -m)); s[kb][r] = p; rs += p; }
+      l += rs + partner32(rs, lane);
+    }
+    // the Q fragments are dead: the next item's travel under the P V MFMAs (one load site for every wave, into the same registers;
+    // after the last item the current rows are simply read again)
+    if (last) load_q(more ? v + G : v);
+    if (active) {
+#pragma unroll
+      for (int kb = 0; kb < 2; kb++)
+        if (j * KT + kb * 32 < S)
+#pragma unroll
+          for (int h8 = 0; h8 < 2; h8++) {
+            const bf16x8 pf = pack_frag(s[kb], h8);
+#pragma unroll
+            for (int db = 0; db < 2; db++) {
+              const char* q0 = vp[db] + (kb * 32 + 16 * h8) * 128;
+              const s16x4 lo = lds_tr16(q0), hi = lds_tr16(q0 + 8 * 128);
+              const s16x8 vr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vr), pf, o[db], 0, 0, 0);
+            }
+          }
+    }
+    const int this_stage = stage;
+    stage = stage + 1 == ANS ? 0 : stage + 1;
+    if (!last) {
+      j++;
+      continue;
+    }
+    // ---- end of an item --------------------------------------------------------------------------------------------
+    // The compiler's wait for the Q loads is forced HERE (queue: the tile requested at the top of this iteration, then Q), ahead of
+    // the output stores, so that it never has to wait for a store or for a tile that was only just requested.
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    // Epilogue.  The accumulators hold O^T fragments (lane = query, 4 consecutive features per register group); stored directly,
+    // every instruction would touch 32 rows with 8 bytes each.  Each wave stages its block through a private 2 KB of the stage
+    // of the item's LAST tile (idle once every wave has left it: the barrier below; refilled only after the next barrier), one
+    // 32-feature half at a time -- 16-byte chunk c of row r at chunk c ^ ((r >> 2) & 3) -- and writes 16 rows x 64 B per instruction.
+    __builtin_amdgcn_s_barrier();
+    if (active) {
+      const float inv = 1.f / l;
+      const int h = bh % H;
+      const int64_t b = bh / H;
+      char* stg = smem + this_stage * (2 * KT * 128) + wave * 2048;
+      const int wr = lane & 31, wc = lane >> 5, rr = lane >> 2, rc = lane & 3;
+#pragma unroll
+      for (int db = 0; db < 2; db++) {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          const u32x2 pk = {pack_bf2(o[db][g * 4] * inv, o[db][g * 4 + 1] * inv), pack_bf2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv)};
+          *LDS_PTR(u32x2, stg + wr * 64 + ((g ^ ((wr >> 2) & 3)) << 4) + wc * 8) = pk;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+        u32x4 t[2];
+#pragma unroll
+        for (int it = 0; it < 2; it++) { const int r = it * 16 + rr; t[it] = *LDS_PTR(const u32x4, stg + r * 64 + ((rc ^ ((r >> 2) & 3)) << 4)); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... before the second half overwrites the block
+#pragma unroll
+        for (int it = 0; it < 2; it++) {
+          const int qq = qtile * 32 * NW + wave * 32 + it * 16 + rr;
+          if (qq < S) {
+            bf16_t* dst = qq < n_img ? Ox + ((b * n_img + qq) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (qq - n_img)) * (int64_t)D + h * HD);
+            *(u32x4*)(dst + db * 32 + rc * 8) = t[it];
+          }
+        }
+      }
+      const int q = qtile * 32 * NW + wave * 32 + (lane & 31);
+      if (q < S && lane < 32) lse[(int64_t)bh * S + q] = m * LN2 + logf(l);
+    }
+    if (!more) break;
+    v += G;
+    j = 0;
+    item_at(v, qtile, bh);
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) o[db][r] = 0.f;
+    m = -INFINITY;
+    l = 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (unused) DMA pieces must land before the LDS is released
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -896,7 +1157,11 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   else if (use_dma && !getenv("MMDIT_ATTN_NW") && dma_env && atoi(dma_env) == 2)   // MMDIT_ATTN_DMA=2: the 64-queries-per-wave variant (measured 80 vs 74 us at S = 410: not the default)
     hipLaunchKernelGGL(attn_fwd_w64_kernel<false>, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                        batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, nullptr);
-  else if (use_dma && !getenv("MMDIT_ATTN_NW"))
+  else if (use_dma && !getenv("MMDIT_ATTN_NW") && dma_env && atoi(dma_env) == 3) {   // MMDIT_ATTN_DMA=3: the persistent variant (measured 71.6 vs 69.7 us: not the default)
+    const int items = ((S + 255) / 256) * batch * heads;
+    hipLaunchKernelGGL(attn_fwd_pers_kernel<0>, dim3(items < 512 ? items : 512), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
+                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
+  } else if (use_dma && !getenv("MMDIT_ATTN_NW"))
     hipLaunchKernelGGL(attn_fwd_dma_kernel<0>, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                        batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
   else if (nw == 8) MMDIT_FWD(8, false);
@@ -923,7 +1188,7 @@ extern "C" int mmdit_probe_attn_fwd_dbg(const void* Q, const void* K, const void
 #define MMDIT_DBG(D) case D: hipLaunchKernelGGL(attn_fwd_dma_kernel<D>, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)Q, \
                                                  (const bf16_t*)K, (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse); break;
   switch (dbg) {
-    MMDIT_DBG(0) MMDIT_DBG(1) MMDIT_DBG(2) MMDIT_DBG(4) MMDIT_DBG(8) MMDIT_DBG(16) MMDIT_DBG(32) MMDIT_DBG(33) MMDIT_DBG(6) MMDIT_DBG(39) MMDIT_DBG(24) MMDIT_DBG(57) MMDIT_DBG(63)
+    MMDIT_DBG(0) MMDIT_DBG(1) MMDIT_DBG(2) MMDIT_DBG(4) MMDIT_DBG(8) MMDIT_DBG(16) MMDIT_DBG(32) MMDIT_DBG(33) MMDIT_DBG(6) MMDIT_DBG(39) MMDIT_DBG(24) MMDIT_DBG(57) MMDIT_DBG(63) MMDIT_DBG(64) MMDIT_DBG(191) MMDIT_DBG(128)
     default: return MMDIT_ERR_ARG;
   }
 #undef MMDIT_DBG

@@ -74,8 +74,10 @@ __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of the IEEE division sequence (a dozen VALU instructions per element: the SwiGLU GEMM epilogue evaluates
+// 64 of these per lane and tile); __expf is the hardware exponential already, so the quotient was never correctly rounded anyway
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // transpose read: lane gets 4 bf16 = column (lane&15) of the 4x16 block whose rows are addressed by the 16-lane group
 __device__ __forceinline__ s16x4 lds_tr16(const void* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p)); }

@@ -43,8 +43,9 @@ __device__ __forceinline__ uint32_t swiglu_voff(int c, int lane, int64_t ld, int
 // C[M, h]; alpha = product of the fp8 operand scales (1 for bf16 operands).  The activation is computed from the
 // ROUNDED pre-activations, i.e. bit-identical to mmdit_swiglu_fwd applied to aux.  Staging as in epilogue_bf16 (32 rows x
 // 128 B for g|u, then 32 rows x 64 B for the activation, wave-private).
-template <int MI>
-__device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage, float alpha) {
+template <int MI, bool SCALED>
+__device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage, float alpha_) {
+  const float alpha = SCALED ? alpha_ : 1.f;   // (bf16 operands: the multiplications fold away)
   bf16_t* Hout = (bf16_t*)p.C;
   bf16_t* GU = (bf16_t*)p.aux;
   const float* bias = p.bias;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       float alpha = 1.f;
       if constexpr (FP8) alpha = q.scale_a[0] * q.scale_b[0];
       if constexpr (SWIGLU) {
-        epilogue_swiglu<MI>(acc, q, it.tm * TBM, it.tn, wm, wn, lane, stage, alpha);
+        epilogue_swiglu<MI, FP8>(acc, q, it.tm * TBM, it.tn, wm, wn, lane, stage, alpha);
         return;
       }
       bool fast = false;

@@ -51,6 +51,11 @@ def main():
         if name in ("out", "w3"):
             aux = torch.empty((Mx, N), dtype=torch.bfloat16, device=dev)
             cases[f"{name} fwd gate+res+aux f32 (img)"] = (lambda: ops.gemm(Ax, W, out_dtype=torch.float32, gate=gate, rows_per_batch=256, residual=res_x, aux=aux), 2.0 * Mx * N * K)
+        if name == "w12":
+            auxx, auxc = torch.empty((Mx, N), dtype=torch.bfloat16, device=dev), torch.empty((Mc, N), dtype=torch.bfloat16, device=dev)
+            bias = rnd(N, dt=torch.float32)
+            cases["w12 fwd SwiGLU epilogue grouped"] = (lambda: ops.gemm_grouped([dict(A=Ax, B=W, bias=bias, act=ops.ACT_SWIGLU, aux=auxx), dict(A=Ac, B=W, bias=bias, act=ops.ACT_SWIGLU, aux=auxc)]), 2.0 * (Mx + Mc) * N * K)
+            cases["w12 fwd SwiGLU, no aux (sampler)"] = (lambda: ops.gemm_grouped([dict(A=Ax, B=W, bias=bias, act=ops.ACT_SWIGLU), dict(A=Ac, B=W, bias=bias, act=ops.ACT_SWIGLU)]), 2.0 * (Mx + Mc) * N * K)
         for cname, (fn, fl) in cases.items():
             t = bench(fn, args.reps)
             print(f"{cname:<34}{Mx:>7}{N:>7}{K:>7}{t * 1e6:>10.1f}{fl / t / 1e12:>10.1f}")

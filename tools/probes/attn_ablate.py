@@ -18,7 +18,7 @@ vp = ctypes.c_void_p
 fn.argtypes = [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp, ctypes.c_int, vp]
 names = {0: "full kernel", 1: "no exp", 32: "no rescale / row sums", 33: "no exp, no rescale / sums", 2: "no P V MFMAs", 4: "no K Q^T MFMAs", 6: "no MFMAs at all",
          39: "no MFMAs, no softmax arithmetic", 8: "no LDS fragment reads", 16: "no per-tile wait / barrier / DMA", 24: "no LDS reads, no barriers / DMA",
-         57: "MFMAs only (no reads, barriers, softmax)", 63: "empty loop"}
+         57: "MFMAs only (no reads, barriers, softmax)", 63: "empty loop", 191: "empty loop, no epilogue", 64: "launch floor (return at entry)", 128: "full loop, no epilogue"}
 for dbg, name in names.items():
     call = lambda: fn(Q.data_ptr(), K.data_ptr(), V.data_ptr(), B, H, S, N, 0.125, Ox.data_ptr(), Oc.data_ptr(), lse.data_ptr(), dbg, torch.cuda.current_stream().cuda_stream)
     for _ in range(3):
