@@ -348,13 +348,17 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   // 2: only where it offers the 320x256 tile; 1 (default): also for 256x256 launches
   static const char* lean_env = getenv("MMDIT_GEMM_LEAN");
   static const int lean_mode = lean_env ? atoi(lean_env) : 1;
-  bool lean_ok = dma && lean_mode > 0 && !fp8 && !conv && !swiglu && !stream_k && split_k == 1 && !a0->a_kmajor && a0->c_dtype == MMDIT_BF16 &&
-                 (a0->act == MMDIT_ACT_NONE || a0->act == MMDIT_ACT_SILU) && !a0->accumulate;
+  bool lean_ok = dma && lean_mode > 0 && !fp8 && !conv && !stream_k && split_k == 1 && !a0->a_kmajor && a0->c_dtype == MMDIT_BF16 &&
+                 (a0->act == MMDIT_ACT_NONE || a0->act == MMDIT_ACT_SILU || swiglu) && !a0->accumulate;
   for (int i = 0; i < count && lean_ok; i++) {
     const mmdit_gemm_args* a = &args[i];
-    lean_ok = !a->aux && !a->gate && !a->residual && a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) && (!a->b_kmajor || a->N >= 8);
+    lean_ok = (!a->aux || swiglu) && !a->gate && !a->residual && a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) && (!a->b_kmajor || a->N >= 8);
   }
-  if (dma) { cfg = swiglu ? CFG_256x256 : pick_dma_cfg(args, count, split_k, stream_k, lean_ok); dma_cfg_tile(cfg, bm, bn); }
+  if (dma) {
+    cfg = pick_dma_cfg(args, count, split_k, stream_k, lean_ok);
+    if (swiglu && cfg != CFG_320x256) cfg = CFG_256x256;   // the activation pairs gate / up columns inside a 256-column tile
+    dma_cfg_tile(cfg, bm, bn);
+  }
   const bool lean = lean_ok && (cfg == CFG_320x256 || (cfg == CFG_256x256 && lean_mode == 1));
   int tiles = 0, units = 0;
   // K-decomposed launches take the problems longest-K first: the tiles of the first round are then ordered long -> short and the

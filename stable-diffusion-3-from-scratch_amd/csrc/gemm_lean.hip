@@ -4,7 +4,8 @@
 // Same machinery as gemm_dma.hip (4-slot ring of 32-wide K halves filled by global_load_lds, DMA cursor three halves ahead and
 // running across tile boundaries, pieces issued between the MFMA rows, one counted vmcnt + one barrier per half, fragments
 // software-pipelined in registers, epilogue of a tile deferred behind the first half of the next one) without the general kernel's
-// work-item machinery (no split-K / stream-K / tails / implicit convolution / fp8 / fp32 epilogues): the whole schedule state is
+// work-item machinery (no split-K / stream-K / tails / implicit convolution / fp8 / fp32 epilogues; the SwiGLU epilogue of the
+// packed w12 GEMM is a template variant): the whole schedule state is
 // wave-uniform and lives in SGPRs, which frees the registers for a
 //   320 x 256 tile (8 waves 2x4, 5x2 accumulators = 160 VGPRs, 144 KB LDS):
 // the N = 768 GEMMs of MMDiT-B at per-GPU batch 64 (out-proj, MLP down, and the data gradients of QKV / out / MLP up; image +
@@ -36,8 +37,9 @@ __device__ __forceinline__ TileRef tile_at(const GroupParams& gp, int pos) {
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
-template <int WM, int WN, int MI, int NJ, bool B_KM>
+template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_lean_kernel(GroupParams gp) {
+  static_assert(!SWIGLU || (!B_KM && WN == 4 && NJ == 2), "SwiGLU epilogue: row-major packed weight, 256-column tile");
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
   constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB;          // bytes of one ring slot
   constexpr int NA = TBM / 16, NB = TBN / 16;                        // 1-KiB DMA pieces per half and operand
@@ -64,7 +66,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_lean_kernel(GroupParams gp)
 #pragma unroll
     for (int i = 0; i < PA_HI; i++) va[i] = piece_voff<false, TBM>(min(wave + NW * i, NA - 1), lane, q.lda, ct.tm * TBM, q.M);
 #pragma unroll
-    for (int i = 0; i < PB; i++) vb[i] = piece_voff<B_KM, TBN>(wave + NW * i, lane, q.ldb, ct.tn * TBN, q.N);
+    for (int i = 0; i < PB; i++) {
+      if constexpr (SWIGLU) vb[i] = swiglu_voff<2>(wave + NW * i, lane, q.ldb, ct.tn, q.N >> 1);   // gate / up rows interleaved per wave (gemm_tile.h)
+      else vb[i] = piece_voff<B_KM, TBN>(wave + NW * i, lane, q.ldb, ct.tn * TBN, q.N);
+    }
     stepb = B_KM ? (int64_t)BKH * q.ldb * 2 : BKH * 2;
     sa = (const char*)q.A;
     sb = (const char*)q.B;
@@ -111,7 +116,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_lean_kernel(GroupParams gp)
   auto bump = [](int s) { return s + 1 == RING ? 0 : s + 1; };
   auto run_epilogue = [&](const TileRef& t) {
     char* stage = smem + dslot * H + wave * EP32_WAVE_BYTES;   // dslot: free until the next issue
-    epilogue_bf16<MI, NJ>(acc, gp.p[t.pi], gp, t.tm * TBM, t.tn * TBN, wm, wn, lane, stage);
+    if constexpr (SWIGLU) epilogue_swiglu<MI, false>(acc, gp.p[t.pi], t.tm * TBM, t.tn, wm, wn, lane, stage, 1.f);
+    else epilogue_bf16<MI, NJ>(acc, gp.p[t.pi], gp, t.tm * TBM, t.tn * TBN, wm, wn, lane, stage);
   };
 
   if (ct.valid) {
@@ -198,10 +204,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_lean_kernel(GroupParams gp)
   if (pending) run_epilogue(prev);
 }
 
-template <int WM, int WN, int MI, int NJ, bool B_KM>
+template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false>
 int launch_lean(const GroupParams& gp, hipStream_t s) {
   constexpr int smem = RING * (WM * MI * 32 + WN * NJ * 32) * 64;
-  auto k = gemm_lean_kernel<WM, WN, MI, NJ, B_KM>;
+  auto k = gemm_lean_kernel<WM, WN, MI, NJ, B_KM, SWIGLU>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -216,6 +222,12 @@ int launch_lean(const GroupParams& gp, hipStream_t s) {
 }  // namespace
 
 int gemm::launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t s) {
+  if (gp.act == MMDIT_ACT_SWIGLU) {   // packed w12 GEMM with the activation in the epilogue (gemm.hip has checked the rest)
+    if (b_km) return MMDIT_ERR_ARG;
+    if (cfg == CFG_320x256) return launch_lean<2, 4, 5, 2, false, true>(gp, s);
+    if (cfg == CFG_256x256) return launch_lean<2, 4, 4, 2, false, true>(gp, s);
+    return MMDIT_ERR_ARG;
+  }
   if (cfg == CFG_320x256) return b_km ? launch_lean<2, 4, 5, 2, true>(gp, s) : launch_lean<2, 4, 5, 2, false>(gp, s);
   if (cfg == CFG_256x256) return b_km ? launch_lean<2, 4, 4, 2, true>(gp, s) : launch_lean<2, 4, 4, 2, false>(gp, s);
   return MMDIT_ERR_ARG;

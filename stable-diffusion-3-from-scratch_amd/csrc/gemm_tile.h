@@ -201,5 +201,153 @@ __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Probl
   }
 }
 
+// ---- SwiGLU-fused w12 GEMM (MMDIT_ACT_SWIGLU): B = packed [2h, K] weight (gate rows 0..h-1, up rows h..2h-1) -----------------
+// A 256-column tile covers hidden indices [128 tn, 128 tn + 128): tile-local B row r = 64 wn + 32 j + c is the gate (j = 0)
+// or up (j = 1) row of hidden index 128 tn + 32 wn + c, so every lane holds g and u of the same (row, hidden index) in
+// acc[i][0] / acc[i][1] and the activation is formed in registers.
+template <int ESZ>
+__device__ __forceinline__ uint32_t swiglu_voff(int c, int lane, int64_t ld, int tn, int h) {
+  const int r = 16 * c + (lane >> 2), slot = lane & 3, piece = slot ^ ((lane >> 4) & 3);
+  const int row = ((r >> 5) & 1) * h + tn * 128 + (r >> 6) * 32 + (r & 31);
+  return (uint32_t)((int64_t)row * ld * ESZ + piece * 16);
+}
+
+// Writes the bf16 pre-activations (+ bias) to aux[M, 2h] (if given: training keeps them for backward) and h = silu(g) * u to
+// C[M, h]; alpha = product of the fp8 operand scales (1 for bf16 operands).  The activation is computed from the
+// ROUNDED pre-activations, i.e. bit-identical to mmdit_swiglu_fwd applied to aux.  Staging as in epilogue_bf16 (32 rows x
+// 128 B for g|u, then 32 rows x 64 B for the activation, wave-private).
+template <int MI, bool SCALED>
+__device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage, float alpha_) {
+  const float alpha = SCALED ? alpha_ : 1.f;   // (bf16 operands: the multiplications fold away)
+  bf16_t* Hout = (bf16_t*)p.C;
+  bf16_t* GU = (bf16_t*)p.aux;
+  const float* bias = p.bias;
+  const int h = p.N >> 1;
+  const int wr = lane & 31, wc = lane >> 5;
+  const int hc = tn * 128 + wn * 32;                 // first hidden index of this wave
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+    u32x2 pa[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float vg[4] = {acc[i][0][g * 4] * alpha, acc[i][0][g * 4 + 1] * alpha, acc[i][0][g * 4 + 2] * alpha, acc[i][0][g * 4 + 3] * alpha};
+      float vu[4] = {acc[i][1][g * 4] * alpha, acc[i][1][g * 4 + 1] * alpha, acc[i][1][g * 4 + 2] * alpha, acc[i][1][g * 4 + 3] * alpha};
+      if (bias) {
+        const int c = hc + 8 * g + 4 * wc;
+        float b4[4];
+        ld4(bias + c, b4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) vg[e] += b4[e];
+        ld4(bias + h + c, b4);
+#pragma unroll
+        for (int e = 0; e < 4; e++) vu[e] += b4[e];
+      }
+      const u32x2 pg = {pack_bf2(vg[0], vg[1]), pack_bf2(vg[2], vg[3])}, pu = {pack_bf2(vu[0], vu[1]), pack_bf2(vu[2], vu[3])};
+      if (GU) {
+        *LDS_PTR(u32x2, stage + wr * 128 + ((g ^ (wr & 7)) << 4) + wc * 8) = pg;
+        *LDS_PTR(u32x2, stage + wr * 128 + (((4 + g) ^ (wr & 7)) << 4) + wc * 8) = pu;
+      }
+      float a[4];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const float g0 = __builtin_bit_cast(float, pg[e] << 16), g1 = __builtin_bit_cast(float, pg[e] & 0xffff0000u);
+        const float u0 = __builtin_bit_cast(float, pu[e] << 16), u1 = __builtin_bit_cast(float, pu[e] & 0xffff0000u);
+        a[2 * e] = silu_f(g0) * u0;
+        a[2 * e + 1] = silu_f(g1) * u1;
+      }
+      pa[g] = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+    if (GU) {
+      const int rr = lane >> 3, rc = lane & 7;
+      const int col = (rc & 4 ? h : 0) + hc + (rc & 3) * 8;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = m0 + wm * (MI * 32) + i * 32 + r;
+        if (row < p.M) *(u32x4*)(GU + (int64_t)row * p.ld_aux + col) = t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int g = 0; g < 4; g++) *LDS_PTR(u32x2, stage + wr * 64 + ((g ^ (wr & 3)) << 4) + wc * 8) = pa[g];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int rr = lane >> 2, rc = lane & 3;
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const int r = it * 16 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 64 + ((rc ^ (r & 3)) << 4));
+        const int row = m0 + wm * (MI * 32) + i * 32 + r;
+        if (row < p.M) *(u32x4*)(Hout + (int64_t)row * p.ldc + hc + rc * 8) = t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+}
+
+// one unit of work of a workgroup: K halves [h0, h1) of output tile (tm, tn) of problem p
+struct Item {
+  int pi;   // problem index (kept as an index so that every access stays a scalar kernarg load)
+  int tm, tn, h0, h1, sk;
+  bool atomic;   // partial tile: added atomically into the pre-zeroed fp32 C
+  int pos;
+  bool valid;
+};
+
+__device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end) {
+  Item it;
+  it.pos = pos;
+  it.valid = pos < end;
+  it.pi = 0;
+  it.tm = it.tn = it.h0 = it.h1 = it.sk = 0;
+  it.atomic = false;
+  if (!it.valid) return it;
+  if (gp.stream_k) {
+    // stream-K: the (tile, K-tile) units of all problems are split evenly over the resident workgroups; a workgroup
+    // walks its contiguous unit range [pos, end) segment by segment and adds each partial tile atomically into the
+    // pre-zeroed fp32 C.  Used for the weight gradients: few output tiles, very long reductions.
+    int pi = 0;
+#pragma unroll 1
+    for (int i = 1; i < gp.count; i++) pi = (pos >= gp.p[i].unit_start) ? i : pi;
+    const Problem& p = gp.p[pi];
+    const int local = pos - p.unit_start, t = local / p.nk, k0 = local - t * p.nk, k1 = min(p.nk, k0 + (end - pos));
+    it.pi = pi;
+    it.tm = t / p.tiles_n;
+    it.tn = t - it.tm * p.tiles_n;
+    it.h0 = 2 * k0;
+    it.h1 = 2 * k1;
+    it.sk = k0 == 0 ? 0 : 1;
+    it.atomic = true;
+  } else {
+    int sk, t;
+    if (gp.tail_first >= 0 && pos >= gp.full_tiles) {
+      // balanced tail: round rnd of the tail gives one unit to each workgroup whose first-round tile was a short one (the
+      // kernel bounds `end` per workgroup so that only positions with a unit are visited)
+      const int rnd = (pos - gp.full_tiles) / gp.tail_G, l = xcd_chunk((int)blockIdx.x, gp.full_tiles);
+      const int Tt = gp.total_tiles - gp.full_tiles, u = rnd * (gp.tail_G - gp.tail_first) + l - gp.tail_first;
+      sk = u / Tt;
+      t = gp.full_tiles + u - sk * Tt;
+    } else {
+      t = work_tile(gp, pos, sk);
+    }
+    const Problem& p = locate_in_problem(gp, t, it.tm, it.tn);
+    const int S = is_split_work(gp, pos) ? gp.split_k : 1;
+    const int nk_all = p.nk, per = (nk_all + S - 1) / S;
+    const int kt0 = sk * per, kt1 = max(kt0, min(nk_all, kt0 + per));
+    it.pi = (int)(&p - &gp.p[0]);
+    it.h0 = 2 * kt0;
+    it.h1 = 2 * kt1;
+    it.sk = sk;
+    it.atomic = S > 1;
+  }
+  return it;
+}
+
+__device__ __forceinline__ int next_pos(const GroupParams& gp, const Item& it) {
+  return gp.stream_k ? it.pos + (it.h1 - it.h0) / 2 : it.pos + (int)gridDim.x;
+}
+
 }  // namespace
 }  // namespace gemm

@@ -20,9 +20,9 @@ def norm(name):
     m = re.search(r"gemm_dma_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])ELb([01])E(\w)(\w)E", name)
     if m:
         return "gemm_dma_kernel<%s,%s,%s,%s,%s,%s,%s,%s>" % m.groups()
-    m = re.search(r"gemm_lean_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])E", name)
+    m = re.search(r"gemm_lean_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])ELb([01])E", name)
     if m:
-        return "gemm_lean_kernel<%s,%s,%s,%s,%s>" % m.groups()
+        return "gemm_lean_kernel<%s,%s,%s,%s,%s>" % m.groups()[:5] + ("+swiglu" if m.group(6) == "1" else "")
     m = re.search(r"gemm_kernelI(\w)(\w)Lb([01])ELb([01])ELb([01])E(\w)(\w)E", name)
     if m:
         return "gemm_kernel<%s,%s,%s,%s,%s,%s,%s>" % m.groups()
