@@ -32,17 +32,21 @@ namespace {
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false, bool SWIGLU = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) {
   // FP8: e4m3 operands (row-major only).  A ring slot still holds 64 B per row = 64 fp8 values, so the whole DMA / ring /
-  // barrier machinery is byte-identical; a half is four 16-wide k-steps of v_mfma_f32_32x32x16_fp8_fp8 instead of two bf16
-  // ones (same MFMA rate, half the operand bytes per FLOP -- this kernel is operand-traffic-bound).
+  // barrier machinery is byte-identical; a half is ONE 64-wide k-step of the MX matrix instruction
+  // v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate; 32 K bytes per lane and operand) with unit block scales (E8M0
+  // 127): the per-tensor scales of the operands are applied in the epilogue.  Half the operand bytes per FLOP and half the
+  // MFMA time of the bf16 kernel.
   static_assert(!FP8 || (!A_KM && !B_KM), "fp8 operands are row-major");
   static_assert(!SWIGLU || (!A_KM && !B_KM && WN == 4 && NJ == 2 && sizeof(TC) == 2 && sizeof(TAUX) == 2), "SwiGLU epilogue: bf16, row-major, 256-column tile");
-  constexpr int ESZ = FP8 ? 1 : 2, KSTEPS = FP8 ? 4 : 2;
-  using frag_t = typename std::conditional<FP8, long, bf16x8>::type;
+  constexpr int ESZ = FP8 ? 1 : 2, KSTEPS = FP8 ? 1 : 2;   // MFMA k-steps per half
+  using frag_t = typename std::conditional<FP8, i32x8, bf16x8>::type;
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
   constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB;      // bytes of one ring slot
   constexpr int PA = TBM / 16 / NW, PB = TBN / 16 / NW, PP = PA + PB;   // 1-KiB DMA pieces per wave and half
-  constexpr int DSTRIDE = ((FP8 ? 4 : 2) * MI) / PP > 0 ? ((FP8 ? 4 : 2) * MI) / PP : 1;   // MFMA rows between two pieces
-  static_assert(PA >= 1 && PB >= 1 && PP <= 2 * MI && PP <= 4, "piece schedule");
+  constexpr int ROWS = KSTEPS * MI;                                      // MFMA rows (one A fragment x NJ) per half
+  constexpr int DSTRIDE = ROWS / PP > 0 ? ROWS / PP : 1;                 // MFMA rows between two pieces ...
+  constexpr int PPR = (PP + ROWS - 1) / ROWS;                            // ... or pieces per row when a half has fewer rows than pieces
+  static_assert(PA >= 1 && PB >= 1 && PP <= 4, "piece schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -179,11 +183,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   // of the NEXT half (which half_sync made visible one half early), so no half starts with an exposed LDS burst.
   // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m
   frag_t a[MI], b[2][NJ];
-  auto ldA = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, ks, lane); else return load_frag_h<A_KM, TBM>(t, r0, ks, lane); };
-  auto ldB = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, ks, lane); else return load_frag_h<B_KM, TBN>(t, r0, ks, lane); };
+  auto ldA = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, lane); else return load_frag_h<A_KM, TBM>(t, r0, ks, lane); };
+  auto ldB = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, lane); else return load_frag_h<B_KM, TBN>(t, r0, ks, lane); };
   // one K half: multiply slot done&3 while the PP pieces of the cursor's half go into slot issued&3 (= (done-1)&3,
   // which every wave left before the barrier of half_sync).  No data-dependent branch inside.
-  auto half_body = [&]() {
+  // `par` (compile-time): which of the two B fragment sets the half starts with -- 0 for bf16 (two k-steps per half: the
+  // double buffer is back where it started), alternating 0 / 1 for fp8 (one k-step per half).
+  auto half_body = [&](auto par) {
+    constexpr int P0 = decltype(par)::value;
     const int nslot = bump(cslot);
     const char* ta = smem + cslot * H;
     const char* tb = ta + HA;
@@ -191,7 +198,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     const char* nb = na + HA;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) {
-      const int c = ks & 1, nx = c ^ 1;
+      const int c = (ks + P0) & 1, nx = c ^ 1;
       const bool last = ks + 1 == KSTEPS;
       // B fragments are double-buffered, each A fragment is reloaded right after the last MFMA that reads it; the
       // order is pinned so every ds_read has MFMAs of cover and gets a counted lgkmcnt wait.
@@ -202,14 +209,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
-          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(b[c][j], a[i], acc[i][j], 0, 0, 0);
+          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[c][j], a[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
           else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
         }
         a[i] = ldA(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1);
         const int q = ks * MI + i;   // compile-time after unrolling
-        if (q % DSTRIDE == 0 && q / DSTRIDE < PP) {
+        if constexpr (ROWS >= PP) {
+          if (q % DSTRIDE == 0 && q / DSTRIDE < PP) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(q / DSTRIDE, dslot);
+          }
+        } else {
           __builtin_amdgcn_sched_barrier(0);
-          issue_piece(q / DSTRIDE, dslot);
+#pragma unroll
+          for (int e = 0; e < PPR; e++)
+            if (q * PPR + e < PP) issue_piece(q * PPR + e, dslot);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -217,6 +231,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     dslot = bump(dslot);
     cslot = nslot;
     cursor_advance();
+  };
+  int fpar = 0;   // fp8: B fragment set of the next half (wave-uniform)
+  auto run_half = [&]() {
+    if constexpr (KSTEPS & 1) {
+      if (fpar) half_body(std::integral_constant<int, 1>());
+      else half_body(std::integral_constant<int, 0>());
+      fpar ^= 1;
+    } else {
+      half_body(std::integral_constant<int, 0>());
+    }
   };
   auto half_body_nocompute = [&]() {   // ablation (MMDIT_GEMM_DEBUG & 2): DMA stream only
 #pragma unroll
@@ -257,11 +281,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
 #pragma unroll
           for (int i = 0; i < MI; i++) a[i] = ldA(ta, wm * (MI * 32) + i * 32, 0);
         }
-        half_body();
+        run_half();
 #pragma unroll 1
         for (int u = 1; u < n; u++) {
           half_sync();
-          half_body();
+          run_half();
         }
       } else {
 #pragma unroll 1

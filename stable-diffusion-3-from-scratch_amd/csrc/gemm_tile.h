@@ -66,9 +66,12 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int r0, int ks, 
 
 // fp8 (e4m3) row-major half-tile [R][64] (64 B rows, same byte geometry as the bf16 half-tile): the fragment of k-step ks
 // (16 values) is the 16-B piece ks of the row, each lane half takes 8 of them -> one ds_read_b64
-__device__ __forceinline__ long load_frag8(const char* tile, int r0, int ks, int lane) {
-  const int r = r0 + (lane & 31);
-  return *LDS_PTR(const long, tile + r * 64 + ((ks ^ ((r >> 2) & 3)) << 4) + (lane >> 5) * 8);
+// fp8 operand fragment of the 64-wide MX MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): the 32 consecutive K bytes
+// [32 (lane >> 5), +32) of row lane & 31 = two swizzled 16-byte chunks of the 64-byte row
+__device__ __forceinline__ i32x8 load_frag8(const char* tile, int r0, int lane) {
+  const int r = r0 + (lane & 31), s = (r >> 2) & 3, c0 = 2 * (lane >> 5);
+  const u32x4 lo = *LDS_PTR(const u32x4, tile + r * 64 + ((c0 ^ s) << 4)), hi = *LDS_PTR(const u32x4, tile + r * 64 + (((c0 + 1) ^ s) << 4));
+  return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 }
 
 // Epilogue (see gemm_common.h for the arithmetic).  acc[i][j] holds a C^T fragment (lane = output row); each
