@@ -43,10 +43,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
   constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB;      // bytes of one ring slot
   constexpr int PA = TBM / 16 / NW, PB = TBN / 16 / NW, PP = PA + PB;   // 1-KiB DMA pieces per wave and half
-  constexpr int ROWS = KSTEPS * MI;                                      // MFMA rows (one A fragment x NJ) per half
-  constexpr int DSTRIDE = ROWS / PP > 0 ? ROWS / PP : 1;                 // MFMA rows between two pieces ...
-  constexpr int PPR = (PP + ROWS - 1) / ROWS;                            // ... or pieces per row when a half has fewer rows than pieces
-  static_assert(PA >= 1 && PB >= 1 && PP <= 4, "piece schedule");
+  constexpr int DSTRIDE = (2 * MI) / PP > 0 ? (2 * MI) / PP : 1;   // bf16: MFMA rows between two pieces
+  static_assert(PA >= 1 && PB >= 1 && PP <= 2 * MI && PP <= 4, "piece schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -187,60 +185,70 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   auto ldB = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, lane); else return load_frag_h<B_KM, TBN>(t, r0, ks, lane); };
   // one K half: multiply slot done&3 while the PP pieces of the cursor's half go into slot issued&3 (= (done-1)&3,
   // which every wave left before the barrier of half_sync).  No data-dependent branch inside.
-  // `par` (compile-time): which of the two B fragment sets the half starts with -- 0 for bf16 (two k-steps per half: the
-  // double buffer is back where it started), alternating 0 / 1 for fp8 (one k-step per half).
-  auto half_body = [&](auto par) {
-    constexpr int P0 = decltype(par)::value;
+  auto half_sync = [&]() {
+    // exactly RING-1 halves are in flight here: the current half and the next one have landed once only the pieces of
+    // the RING-3 youngest halves may still be outstanding (loads retire in order; stores only make the wait conservative)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * PP) : "memory");
+    __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left half done-1, whose slot the DMA below refills
+  };
+  // one K half: multiply slot cslot while the PP pieces of the cursor's half go into slot dslot (which every wave left before
+  // the barrier of half_sync).  No data-dependent branch inside.
+  auto half_body = [&]() {
     const int nslot = bump(cslot);
     const char* ta = smem + cslot * H;
     const char* tb = ta + HA;
     const char* na = smem + nslot * H;   // (after the last half of the stream: read, never used)
     const char* nb = na + HA;
+    if constexpr (FP8) {
+      // One 64-wide k-step per half.  B-fragment-major order with single-buffered fragments (32 K bytes = 8 VGPRs each: a second B
+      // set would not fit next to the 128 accumulators): b[0][j] is reloaded -- from the next slot -- behind the last MFMA of its
+      // column block, a[i] behind the last column block's MFMA of its row block, so every ds_read has at least MI MFMAs of cover.
+      constexpr int S = (MI * NJ) / PP > 0 ? (MI * NJ) / PP : 1;
+      static_assert(!FP8 || MI * NJ >= PP, "piece schedule (fp8)");
 #pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) {
-      const int c = (ks + P0) & 1, nx = c ^ 1;
-      const bool last = ks + 1 == KSTEPS;
-      // B fragments are double-buffered, each A fragment is reloaded right after the last MFMA that reads it; the
-      // order is pinned so every ds_read has MFMAs of cover and gets a counted lgkmcnt wait.
+      for (int j = 0; j < NJ; j++) {
 #pragma unroll
-      for (int j = 0; j < NJ; j++) b[nx][j] = ldB(last ? nb : tb, wn * (NJ * 32) + j * 32, last ? 0 : ks + 1);
-#pragma unroll
-      for (int i = 0; i < MI; i++) {
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[c][j], a[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MI; i++) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[0][j], a[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          if (j == NJ - 1) a[i] = ldA(na, wm * (MI * 32) + i * 32, 0);
+          if (i == MI - 1) b[0][j] = ldB(nb, wn * (NJ * 32) + j * 32, 0);
+          const int q = j * MI + i;   // compile-time after unrolling
+          if (q % S == 0 && q / S < PP) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_piece(q / S, dslot);
+          }
         }
-        a[i] = ldA(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1);
-        const int q = ks * MI + i;   // compile-time after unrolling
-        if constexpr (ROWS >= PP) {
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        const int c = ks & 1, nx = c ^ 1;
+        const bool last = ks + 1 == KSTEPS;
+        // B fragments are double-buffered, each A fragment is reloaded right after the last MFMA that reads it; the
+        // order is pinned so every ds_read has MFMAs of cover and gets a counted lgkmcnt wait.
+#pragma unroll
+        for (int j = 0; j < NJ; j++) b[nx][j] = ldB(last ? nb : tb, wn * (NJ * 32) + j * 32, last ? 0 : ks + 1);
+#pragma unroll
+        for (int i = 0; i < MI; i++) {
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+            if constexpr (!FP8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
+          a[i] = ldA(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1);
+          const int q = ks * MI + i;   // compile-time after unrolling
           if (q % DSTRIDE == 0 && q / DSTRIDE < PP) {
             __builtin_amdgcn_sched_barrier(0);
             issue_piece(q / DSTRIDE, dslot);
           }
-        } else {
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < PPR; e++)
-            if (q * PPR + e < PP) issue_piece(q * PPR + e, dslot);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     dslot = bump(dslot);
     cslot = nslot;
     cursor_advance();
-  };
-  int fpar = 0;   // fp8: B fragment set of the next half (wave-uniform)
-  auto run_half = [&]() {
-    if constexpr (KSTEPS & 1) {
-      if (fpar) half_body(std::integral_constant<int, 1>());
-      else half_body(std::integral_constant<int, 0>());
-      fpar ^= 1;
-    } else {
-      half_body(std::integral_constant<int, 0>());
-    }
   };
   auto half_body_nocompute = [&]() {   // ablation (MMDIT_GEMM_DEBUG & 2): DMA stream only
 #pragma unroll
@@ -248,12 +256,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     dslot = bump(dslot);
     cslot = bump(cslot);
     cursor_advance();
-  };
-  auto half_sync = [&]() {
-    // exactly RING-1 halves are in flight here: the current half and the next one have landed once only the pieces of
-    // the RING-3 youngest halves may still be outstanding (loads retire in order; stores only make the wait conservative)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * PP) : "memory");
-    __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left half done-1, whose slot the DMA below refills
   };
 
   Item item = item_at(gp, pos, end), prev = item;
@@ -281,11 +283,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
 #pragma unroll
           for (int i = 0; i < MI; i++) a[i] = ldA(ta, wm * (MI * 32) + i * 32, 0);
         }
-        run_half();
+        half_body();
 #pragma unroll 1
         for (int u = 1; u < n; u++) {
           half_sync();
-          run_half();
+          half_body();
         }
       } else {
 #pragma unroll 1
