@@ -88,10 +88,17 @@ typedef struct {
    * (0,1,0,1) (diffusers Downsample2D), M = batch * (conv_H/2) * (conv_W/2).  Output rows are the output pixels in NHWC
    * order.  Needs bf16 operands and conv_C % 32 == 0; lda is ignored. */
   int conv_mode, conv_H, conv_W, conv_C;
-  /* fp8 operands (a_dtype == b_dtype == MMDIT_FP8, row-major, K % 128 == 0): C = scale_a[0] * scale_b[0] * (A_q B_q^T), then the
-   * usual epilogue.  scale_*: device pointers to the per-tensor dequantisation scales written by mmdit_fp8_quantize. */
-  const float* scale_a;
-  const float* scale_b;
+  /* fp8 operands (a_dtype == b_dtype == MMDIT_FP8, row-major, K % 128 == 0), the matrix instruction is the 64-wide
+   * v_mfma_scale_f32_32x32x64_f8f6f4.
+   *   scale_mode 0 (per-tensor): C = scale_a[0] * scale_b[0] * (A_q B_q^T), then the usual epilogue; scale_*: device pointers to the
+   *     fp32 dequantisation scales written by mmdit_fp8_quantize / mmdit_fp8_quantize_delayed (unit block scales in the MFMA).
+   *   scale_mode 1 (MX, OCP microscaling): every 32 consecutive K values of a row share one E8M0 scale 2^(e-127); scale_* point to
+   *     the byte tensors written by mmdit_mxfp8_quantize, layout [K/64][rows][2] (rows = M for A, N for B; M % 8 == N % 8 == 0; the
+   *     buffer must extend 512 bytes past its last byte -- tile loads of the last rows read, and ignore, what follows).  The block
+   *     scales are applied by the matrix instruction itself. */
+  const void* scale_a;
+  const void* scale_b;
+  int scale_mode;
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 /* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,
@@ -115,6 +122,12 @@ int mmdit_fp8_quantize(const void* x, int x_dtype, int64_t n, const float* amax,
  * state: 4 floats {amax ring [3], dequantisation scale (output)}; phase = call counter of the call site (the caller initialises
  * state[phase % 3] with a two-pass mmdit_fp8_amax before the first call). */
 int mmdit_fp8_quantize_delayed(const void* x, int x_dtype, int64_t n, float* state, int phase, float margin, void* q_fp8, mmdit_stream_t stream);
+/* MX (OCP microscaling) e4m3 quantisation of a row-major operand x[rows][K] (leading dimension ldx, K % 64 == 0, rows % 8 == 0):
+ * one pass, no state.  Every 32 consecutive K values share the smallest E8M0 scale 2^e with amax / 2^e <= 448 (e = floor(log2 amax) - 8,
+ * or one more when the mantissa of amax exceeds 1.75; an all-zero block gets 2^-127); q[rows][K] = saturate_e4m3(x / scale), scales[K/64][rows][2] as mmdit_gemm_args.scale_mode 1 reads them
+ * (allocate (K/32) * rows + 512 bytes).  Replaces the per-tensor amax / delayed-scaling passes in front of an fp8 GEMM
+ * (reference: none -- the reference runs bf16 autocast; BASELINE.json config 5 asks for an fp8 inference path). */
+int mmdit_mxfp8_quantize(const void* x, int x_dtype, int rows, int K, int64_t ldx, void* q_fp8, void* scales_e8m0, mmdit_stream_t stream);
 
 /* dtype conversion of n elements (bf16 shadow copies of the fp32 master weights; the
  * reference gets these from torch.autocast, model_trainer.py:416). n%8==0 not required. */

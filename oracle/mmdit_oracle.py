@@ -44,6 +44,10 @@ Rounding modes (OracleConfig):
               weight ([Wq; Wk; Wv], w12, ...) shares ONE scale, C = s_a s_b (A_q B_q^T).
               This is test infrastructure for BASELINE config 5; the reference itself
               has no fp8 path.
+            = "mxfp8": the same four GEMM sites with MX (OCP microscaling) operands: every 32
+              consecutive K values share the smallest power-of-two scale with amax / scale <= 448, values
+              e4m3_rne(clamp(x / scale)) -- the HIP "mxfp8" inference mode (mmdit_mxfp8_quantize,
+              mmdit_gemm_args.scale_mode 1).
 """
 from __future__ import annotations
 
@@ -90,7 +94,7 @@ def _rb(x: torch.Tensor) -> torch.Tensor:
 
 def _lin(cfg: OracleConfig, x, w, b=None):
     """nn.Linear; in gemm=bf16 / fp8 mode both operands are rounded to bf16 first."""
-    if cfg.gemm in ("bf16", "fp8"):
+    if cfg.gemm in ("bf16", "fp8", "mxfp8"):
         x = _rb(x)
         w = _rb(w)
     return F.linear(x, w, b)
@@ -104,13 +108,34 @@ def _q8(x: torch.Tensor):
     return q, a / 448.0
 
 
+def _qmx(x: torch.Tensor):
+    """MX (OCP microscaling) e4m3 quantisation along the last dimension as csrc/rowops.hip mxfp8_quant_kernel does it: blocks of 32
+    values share the smallest power-of-two scale with amax / scale <= 448 (2^(floor(log2 amax) - 8) or twice that; 2^-127 for an all-zero block); returns the DEQUANTISED values
+    (e4m3 code x scale, exact in fp32), which is what the block-scaled matrix instruction multiplies."""
+    shp = x.shape
+    xb = x.detach().to(torch.float32).reshape(-1, shp[-1] // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    _, ex = torch.frexp(amax)                                     # amax = m 2^ex, m in [0.5, 1): floor(log2(amax)) = ex - 1
+    e = torch.where(amax > 0, ex - 1 - 8, torch.full_like(ex, -127))
+    e = torch.where(amax > 448.0 * torch.ldexp(torch.ones_like(amax), e), e + 1, e).clamp(-127, 127)     # amax / scale <= 448: nothing saturates
+    scale = torch.ldexp(torch.ones_like(amax), e)
+    q = (xb / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).to(torch.float32)
+    return (q * scale).reshape(shp)
+
+
 def _lin8(cfg: OracleConfig, x, ws, b=None):
     """One of the fp8 GEMM sites of a block: `ws` are the weights the HIP path packs row-wise into ONE operand (so they share
     one e4m3 scale); returns the list of outputs.  Outside fp8 mode (or K % 128 != 0, which the HIP path keeps in bf16) these
     are plain _lin calls."""
-    if cfg.gemm != "fp8" or x.shape[-1] % 128:
+    if cfg.gemm not in ("fp8", "mxfp8") or x.shape[-1] % 128:
         assert b is None or len(ws) == 1
         return [_lin(cfg, x, w, b) for w in ws]      # (bias inside F.linear: the reference's op, bit for bit)
+    if cfg.gemm == "mxfp8":     # block scales: no shared per-tensor scale, the packing of the weights does not matter
+        xq = _qmx(_rb(x))
+        outs = [F.linear(xq, _qmx(_rb(w))) for w in ws]
+        if b is not None:
+            outs[0] = outs[0] + b
+        return outs
     xq, sa = _q8(_rb(x))
     wq, sb = _q8(_rb(torch.cat(list(ws), dim=0)))
     out = F.linear(xq, wq) * (sa * sb)
@@ -121,7 +146,7 @@ def _lin8(cfg: OracleConfig, x, ws, b=None):
 
 def _act(cfg: OracleConfig, x):
     """Activation tensor that the HIP fast path stores as bf16."""
-    return _rb(x) if cfg.gemm in ("bf16", "fp8") else x
+    return _rb(x) if cfg.gemm in ("bf16", "fp8", "mxfp8") else x
 
 
 # ----------------------------------------------------------------------------
@@ -201,7 +226,7 @@ def attention_core(q, k, v, scale: float, mode: str):
 def patch_embed(x_t, w_patch, cfg: OracleConfig):
     """PatchEmbed.forward with pos_embed=None: Conv2d(k=p, stride=p, no bias),
     flatten(2).transpose(1,2)  (blocks/ImagePositionalEncoding.py:114-116, 181-183)."""
-    if cfg.gemm == "bf16":
+    if cfg.gemm in ("bf16", "fp8", "mxfp8"):
         x_t, w_patch = _rb(x_t), _rb(w_patch)
     y = F.conv2d(x_t, w_patch, None, stride=cfg.patch_size)
     return y.flatten(2).transpose(1, 2)

@@ -35,7 +35,7 @@ class GemmArgs(ctypes.Structure):
         ("split_k", _i),
         ("stream_k", _i),
         ("conv_mode", _i), ("conv_H", _i), ("conv_W", _i), ("conv_C", _i),
-        ("scale_a", _vp), ("scale_b", _vp),
+        ("scale_a", _vp), ("scale_b", _vp), ("scale_mode", _i),
     ]
 
 
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "mmdit_fp8_amax": ([_vp, _i, _i64, _vp, _vp], _i),
     "mmdit_fp8_quantize": ([_vp, _i, _i64, _vp, _vp, _vp, _vp], _i),
     "mmdit_fp8_quantize_delayed": ([_vp, _i, _i64, _vp, _i, ctypes.c_float, _vp, _vp], _i),
+    "mmdit_mxfp8_quantize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp], _i),
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_fwd_res": ([_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),

@@ -257,6 +257,16 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
   static const char* force_epi = getenv("MMDIT_GEMM_CFG_EPI");   // experiments: tile configuration of the gated-residual (fp32 C) launches only
   if (force_epi && args[0].gate) return atoi(force_epi);
   if (stream_k) return CFG_256x256;   // no quantisation with stream-K: take the fewest bytes per FLOP
+  if (args[0].a_dtype == MMDIT_FP8) {
+    // e4m3 operands halve the L2 -> LDS bytes per FLOP, which is what the 256x256 tile buys with bf16 operands; measured
+    // (tools/probes/fp8_bench.py, M = 26 240): 128x128 tiles win up to K = 4096 (w12 216 vs 247 us, qkv 96 vs 101 us), 256x256 only
+    // on long reductions (8192^3: 566 vs 668 us).  The MX variant of the 256x256 kernel spills accumulators inside its K loop
+    // (128 accumulators + 48 fragment + scale registers do not fit 256 VGPRs: 3x slower) and is not selected.
+    int kmax = 0;
+    for (int i = 0; i < count; i++) kmax = args[i].K > kmax ? args[i].K : kmax;
+    if (args[0].scale_mode == 1 || kmax <= 4096) return CFG_128x128;
+    return CFG_256x256;
+  }
   // Wave quantisation decides (measured, tools/gemm_bench.py): a "round" of 128x128 tiles (2 workgroups per CU)
   // costs 1.0, a round of 256x256 tiles (1 per CU, 4x the FLOPs each) 1.58.
   long t128 = 0, t256 = 0;
@@ -306,7 +316,8 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
                     a->b_kmajor == a0->b_kmajor && a->precision == a0->precision && a->act == a0->act && a->accumulate == a0->accumulate);
     if (a->aux) { MMDIT_CHECK_ARG(aux_dt < 0 || aux_dt == a->aux_dtype); aux_dt = a->aux_dtype; }
     MMDIT_CHECK_ARG((a->split_k > 1 ? a->split_k : 1) == split_k);
-    if (fp8) MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && a->K % bk == 0 && a->scale_a && a->scale_b && !a->conv_mode);
+    if (fp8) MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && a->K % bk == 0 && a->scale_a && a->scale_b && !a->conv_mode && a->scale_mode == a0->scale_mode &&
+                             (a->scale_mode == 0 || (a->scale_mode == 1 && a->M % 8 == 0 && a->N % 8 == 0 && aligned16(a->scale_a) && aligned16(a->scale_b))));
     if (a->K % bk != 0) dma = false;
     if (a->a_kmajor && a->M < 8) dma = false;
     if (a->b_kmajor && a->N < 8) dma = false;
@@ -384,13 +395,14 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     p.tiles_m = (a->M + bm - 1) / bm;
     p.tile_start = tiles;
     p.nk = a->K / bk;
-    p.scale_a = a->scale_a; p.scale_b = a->scale_b;
+    p.scale_a = (const float*)a->scale_a; p.scale_b = (const float*)a->scale_b;
     p.unit_start = units;
     tiles += p.tiles_n * p.tiles_m;
     units += p.tiles_n * p.tiles_m * p.nk;
     if (stream_k) MMDIT_CHECK_ARG(!a->aux && !a->gate && a->stream_k);
   }
   gp.stream_k = stream_k; gp.total_units = units;
+  gp.mx = fp8 && a0->scale_mode == 1;
   // K-decomposition for the weight gradients (few output tiles, very long reductions; a0->stream_k = "C is pre-zeroed fp32,
   // decompose along K as you like").  Default "tail": R full rounds of one-tile-per-workgroup over the whole K -- the 32
   // workgroups of an XCD then walk K together and share operand panels through its L2 (stream-K's contiguous unit ranges

@@ -19,7 +19,7 @@ struct Problem {
   // implicit-GEMM 3x3 convolution (conv_mode != 0): A is a zero-bordered NHWC bf16 tensor (batch, cHp, cWp, cC); output row
   // m = (b, yo, xo) reads pixel (s*yo + kh + o, s*xo + kw + o) for K index (kh*3 + kw)*cC + c  (mode 1: s=1, o=0; mode 2: s=2, o=1)
   int conv_mode, cHo, cWo, cHp, cWp, cC;
-  const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (device scalars); C = sa*sb*(A_q B_q^T)
+  const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (device scalars), C = sa*sb*(A_q B_q^T); MX mode: E8M0 bytes [K/64][rows][2]
 };
 struct GroupParams {
   Problem p[MAXG];
@@ -30,6 +30,7 @@ struct GroupParams {
   // the workgroups whose first-round tile is a SHORT one (its position in the tile order >= tail_first), tail_rounds units each.
   int tail_first, tail_rounds, tail_G;
   int stream_k, total_units, persistent;   // stream-K: every workgroup gets an equal share of the (tile, K-tile) units
+  int mx;                                  // fp8 operands: scale_a / scale_b are E8M0 block-scale tensors (MX), not per-tensor fp32 scalars
 };
 
 // block id -> (problem, m-tile, n-tile, split-K slice).

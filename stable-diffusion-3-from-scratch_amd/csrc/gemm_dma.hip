@@ -29,19 +29,22 @@ using namespace gemm;
 namespace {
 
 
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false, bool SWIGLU = false>
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, int FP8 = 0, bool SWIGLU = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) {
   // FP8: e4m3 operands (row-major only).  A ring slot still holds 64 B per row = 64 fp8 values, so the whole DMA / ring /
   // barrier machinery is byte-identical; a half is ONE 64-wide k-step of the MX matrix instruction
   // v_mfma_scale_f32_32x32x64_f8f6f4 (twice the bf16 MFMA rate; 32 K bytes per lane and operand) with unit block scales (E8M0
   // 127): the per-tensor scales of the operands are applied in the epilogue.  Half the operand bytes per FLOP and half the
   // MFMA time of the bf16 kernel.
+  // FP8 = 1: per-tensor scales (applied in the epilogue, unit block scales); FP8 = 2 (MX): E8M0 block scales fed to the instruction.
+  constexpr bool MX = FP8 == 2;
   static_assert(!FP8 || (!A_KM && !B_KM), "fp8 operands are row-major");
   static_assert(!SWIGLU || (!A_KM && !B_KM && WN == 4 && NJ == 2 && sizeof(TC) == 2 && sizeof(TAUX) == 2), "SwiGLU epilogue: bf16, row-major, 256-column tile");
   constexpr int ESZ = FP8 ? 1 : 2, KSTEPS = FP8 ? 1 : 2;   // MFMA k-steps per half
-  using frag_t = typename std::conditional<FP8, i32x8, bf16x8>::type;
+  using frag_t = typename std::conditional<(FP8 != 0), i32x8, bf16x8>::type;
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
-  constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB;      // bytes of one ring slot
+  constexpr int SCB = MX ? 1024 : 0;                           // fp8: E8M0 block scales of the half (MX mode), [A rows x 2 | B rows x 2] bytes
+  constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB + SCB;   // bytes of one ring slot
   constexpr int PA = TBM / 16 / NW, PB = TBN / 16 / NW, PP = PA + PB;   // 1-KiB DMA pieces per wave and half
   constexpr int DSTRIDE = (2 * MI) / PP > 0 ? (2 * MI) / PP : 1;   // bf16: MFMA rows between two pieces
   static_assert(PA >= 1 && PB >= 1 && PP <= 2 * MI && PP <= 4, "piece schedule");
@@ -76,6 +79,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   const char* sa = nullptr;
   const char* sb = nullptr;
   int64_t stepa = 0, stepb = 0;
+  // MX mode (fp8 operands with E8M0 block scales, gp.mx): one extra 1-KiB DMA piece per half, issued by wave 0 -- lanes 0..31 fetch
+  // the A tile's scale bytes of the half (scale layout [K/64][rows][2]: 2 bytes per row and half, rows contiguous), lanes 32..63
+  // the B tile's; per-lane 64-bit source pointer, advanced by rows * 2 bytes per half
+  constexpr bool mx = MX;
+  const bool mx0 = MX && wave == 0;
+  const char* psc = nullptr;
+  int64_t pstep = 0;
   int cseg = 0, cseg_len = 0;      // implicit-GEMM convolution: halves left in / per kernel row (3 taps x cC/32 halves are contiguous)
   int64_t crow_jump = 0;           // extra bytes when the K index moves to the next kernel row
   auto cursor_setup = [&]() {
@@ -96,6 +106,22 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     stepb = B_KM ? (int64_t)BKH * q.ldb * 2 : BKH * 2;
     sa = (const char*)q.A + ch * stepa;
     sb = (const char*)q.B + ch * stepb;
+    if constexpr (MX) {
+      {
+        const int l = lane & 31;
+        if (lane < 32) {
+          pstep = (int64_t)q.M * 2;
+          psc = (const char*)q.scale_a + (int64_t)cit.tm * TBM * 2 + (l * 16 < TBM * 2 ? l * 16 : TBM * 2 - 16);
+        } else {
+          pstep = (int64_t)q.N * 2;
+          int off = cit.tn * TBN * 2 + (l * 16 < TBN * 2 ? l * 16 : TBN * 2 - 16);
+          if constexpr (SWIGLU)   // gate rows [128 tn, +128) then up rows [h + 128 tn, +128) of the packed weight: two 256-byte runs
+            off = ((l < 16 ? 0 : (q.N >> 1)) + cit.tn * 128) * 2 + (l & 15) * 16;
+          psc = (const char*)q.scale_b + off;
+        }
+        psc += ch * pstep;
+      }
+    }
     cseg = 0;
     if (!A_KM && q.conv_mode) {
       cseg_len = 3 * (q.cC / BKH);
@@ -113,6 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       ch++;
       sa += stepa;
       sb += stepb;
+      if constexpr (MX) psc += pstep;
       if (cseg && --cseg == 0) {   // convolution: next kernel row
         sa += crow_jump;
         cseg = cseg_len;
@@ -134,6 +161,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     if (q < PA) glds16(va[q], sa, dst + (wave * PA + q) * 1024);
     else glds16(vb[q - PA], sb, dst + HA + (wave * PB + (q - PA)) * 1024);
   };
+  auto issue_scales = [&](int slot) {         // MX mode, wave 0: the scale bytes of the cursor's half
+    if constexpr (MX)
+      if (mx0) glds16p(psc, lds0 + slot * H + HA + HB);
+  };
 
   f32x16 acc[MI][NJ];
   auto zero_acc = [&]() {
@@ -151,9 +182,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     if (!(gp.debug & 8)) {
       const Problem& q = gp.p[it.pi];
       float alpha = 1.f;
-      if constexpr (FP8) alpha = q.scale_a[0] * q.scale_b[0];
+      if constexpr (FP8 == 1) alpha = q.scale_a[0] * q.scale_b[0];   // (MX: the block scales went into the MFMAs)
       if constexpr (SWIGLU) {
-        epilogue_swiglu<MI, FP8>(acc, q, it.tm * TBM, it.tn, wm, wn, lane, stage, alpha);
+        epilogue_swiglu<MI, FP8 == 1>(acc, q, it.tm * TBM, it.tn, wm, wn, lane, stage, alpha);
         return;
       }
       bool fast = false;
@@ -172,6 +203,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     for (int s = 0; s < RING - 1; s++) {
 #pragma unroll
       for (int q = 0; q < PP; q++) issue_piece(q, dslot);
+      issue_scales(dslot);
       dslot = bump(dslot);
       cursor_advance();
     }
@@ -181,6 +213,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   // of the NEXT half (which half_sync made visible one half early), so no half starts with an exposed LDS burst.
   // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m
   frag_t a[MI], b[2][NJ];
+  int sca[MI], scb[NJ];   // fp8: E8M0 block scale of this lane's 32 K bytes per fragment (127 = 1.0 outside MX mode)
+  auto ldSA = [&](const char* slot, int i) -> int {
+    if constexpr (!MX) return 127;
+    return *LDS_PTR(const unsigned char, slot + HA + HB + (wm * (MI * 32) + i * 32 + (lane & 31)) * 2 + (lane >> 5));
+  };
+  auto ldSB = [&](const char* slot, int j) -> int {
+    const int row = SWIGLU ? j * 128 + wn * 32 + (lane & 31) : wn * (NJ * 32) + j * 32 + (lane & 31);
+    if constexpr (!MX) return 127;
+    return *LDS_PTR(const unsigned char, slot + HA + HB + 512 + row * 2 + (lane >> 5));
+  };
   auto ldA = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, lane); else return load_frag_h<A_KM, TBM>(t, r0, ks, lane); };
   auto ldB = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, lane); else return load_frag_h<B_KM, TBN>(t, r0, ks, lane); };
   // one K half: multiply slot done&3 while the PP pieces of the cursor's half go into slot issued&3 (= (done-1)&3,
@@ -188,7 +230,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   auto half_sync = [&]() {
     // exactly RING-1 halves are in flight here: the current half and the next one have landed once only the pieces of
     // the RING-3 youngest halves may still be outstanding (loads retire in order; stores only make the wait conservative)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * PP) : "memory");
+    if (MX && mx0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * (PP + 1)) : "memory");   // (wave 0 also carries the scale piece)
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * PP) : "memory");
     __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left half done-1, whose slot the DMA below refills
   };
   // one K half: multiply slot cslot while the PP pieces of the cursor's half go into slot dslot (which every wave left before
@@ -210,9 +253,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
 #pragma unroll
         for (int i = 0; i < MI; i++) {
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[0][j], a[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-          if (j == NJ - 1) a[i] = ldA(na, wm * (MI * 32) + i * 32, 0);
-          if (i == MI - 1) b[0][j] = ldB(nb, wn * (NJ * 32) + j * 32, 0);
+          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[0][j], a[i], acc[i][j], 0, 0, 0, scb[j], 0, sca[i]);
+          if (j == NJ - 1) { a[i] = ldA(na, wm * (MI * 32) + i * 32, 0); sca[i] = ldSA(na, i); }
+          if (i == MI - 1) { b[0][j] = ldB(nb, wn * (NJ * 32) + j * 32, 0); scb[j] = ldSB(na, j); }
           const int q = j * MI + i;   // compile-time after unrolling
           if (q % S == 0 && q / S < PP) {
             __builtin_amdgcn_sched_barrier(0);
@@ -221,6 +264,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      issue_scales(dslot);
     } else {
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
@@ -253,6 +297,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   auto half_body_nocompute = [&]() {   // ablation (MMDIT_GEMM_DEBUG & 2): DMA stream only
 #pragma unroll
     for (int q = 0; q < PP; q++) issue_piece(q, dslot);
+    issue_scales(dslot);
     dslot = bump(dslot);
     cslot = bump(cslot);
     cursor_advance();
@@ -279,9 +324,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
           first = false;
           const char* ta = smem;
 #pragma unroll
-          for (int j = 0; j < NJ; j++) b[0][j] = ldB(ta + HA, wn * (NJ * 32) + j * 32, 0);
+          for (int j = 0; j < NJ; j++) { b[0][j] = ldB(ta + HA, wn * (NJ * 32) + j * 32, 0); if constexpr (FP8) scb[j] = ldSB(ta, j); }
 #pragma unroll
-          for (int i = 0; i < MI; i++) a[i] = ldA(ta, wm * (MI * 32) + i * 32, 0);
+          for (int i = 0; i < MI; i++) { a[i] = ldA(ta, wm * (MI * 32) + i * 32, 0); if constexpr (FP8) sca[i] = ldSA(ta, i); }
         }
         half_body();
 #pragma unroll 1
@@ -306,9 +351,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   if (pending) run_epilogue(prev);
 }
 
-template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, bool FP8 = false, bool SWIGLU = false>
+template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, int FP8 = 0, bool SWIGLU = false>
 int launch_cfg(const GroupParams& gp, hipStream_t s) {
-  constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64;
+  constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64 + (FP8 == 2 ? 1024 : 0);
   constexpr int smem = RING * slot + (WM * WN * EP32_WAVE_BYTES <= slot ? 0 : WM * WN * EP32_WAVE_BYTES);
   auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX, FP8, SWIGLU>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
@@ -346,12 +391,18 @@ int by_layout(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t 
 int gemm::launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s) {
   if (gp.act == MMDIT_ACT_SWIGLU) {   // packed w12 GEMM with the activation in the epilogue (gemm.hip has checked the rest)
     if (a_km || b_km || c_dtype != MMDIT_BF16 || aux_dtype != MMDIT_BF16 || cfg != CFG_256x256) return MMDIT_ERR_DTYPE;
-    return fp8 ? launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, true, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, false, true>(gp, s);
+    if (fp8 && gp.mx) return launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 2, true>(gp, s);
+    return fp8 ? launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 1, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 0, true>(gp, s);
   }
   if (fp8) {   // e4m3 operands: row-major x row-major, bf16 or fp32 output (aux, if any, in the output dtype)
     if (a_km || b_km || aux_dtype != c_dtype || cfg == CFG_256x128) return MMDIT_ERR_DTYPE;
-    if (c_dtype == MMDIT_BF16) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, bf16_t, bf16_t, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, true>(gp, s);
-    if (c_dtype == MMDIT_F32) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, float, float, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, float, float, true>(gp, s);
+    if (gp.mx) {
+      if (c_dtype == MMDIT_BF16) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, bf16_t, bf16_t, 2>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 2>(gp, s);
+      if (c_dtype == MMDIT_F32) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, float, float, 2>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, float, float, 2>(gp, s);
+      return MMDIT_ERR_DTYPE;
+    }
+    if (c_dtype == MMDIT_BF16) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, bf16_t, bf16_t, 1>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 1>(gp, s);
+    if (c_dtype == MMDIT_F32) return cfg == CFG_128x128 ? launch_cfg<2, 2, 2, 2, false, false, float, float, 1>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, float, float, 1>(gp, s);
     return MMDIT_ERR_DTYPE;
   }
   if (c_dtype == MMDIT_F32 && aux_dtype == MMDIT_F32) return by_layout<float, float>(cfg, a_km, b_km, gp, s);

@@ -49,6 +49,12 @@ __device__ __forceinline__ void glds16(uint32_t voff, const char* sbase_, uint32
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
+// the same with a per-lane 64-bit source pointer (sources that do not share a wave-uniform base)
+__device__ __forceinline__ void glds16p(const void* gptr, uint32_t lds_dst_) {
+  const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gptr), "s"(lds_dst) : "memory", "m0");
+}
+
 template <bool KM, int R>
 __device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int r0, int ks, int lane) {
   if (!KM) {
@@ -66,11 +72,14 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int r0, int ks, 
 
 // fp8 (e4m3) row-major half-tile [R][64] (64 B rows, same byte geometry as the bf16 half-tile): the fragment of k-step ks
 // (16 values) is the 16-B piece ks of the row, each lane half takes 8 of them -> one ds_read_b64
-// fp8 operand fragment of the 64-wide MX MFMA (v_mfma_scale_f32_32x32x64_f8f6f4): the 32 consecutive K bytes
-// [32 (lane >> 5), +32) of row lane & 31 = two swizzled 16-byte chunks of the 64-byte row
+// fp8 operand fragment of the 64-wide MX MFMA (v_mfma_scale_f32_32x32x64_f8f6f4).  K layout of the instruction (established with
+// block scales that vary along K, tools/probes/mx_dbg.py): registers 0-3 of lane l hold k = 16 (l >> 5) + [0, 16), registers 4-7
+// k = 32 + 16 (l >> 5) + [0, 16) of row l & 31 -- the 16-byte chunks (l >> 5) and 2 + (l >> 5) of the 64-byte row.  The E8M0 scale
+// of (row r, 32-block b) is taken from lane r + 32 b of the scale register, so a lane's two register halves are scaled by two
+// different lanes' bytes.  (With unit scales any K permutation shared by both operands gives the same product.)
 __device__ __forceinline__ i32x8 load_frag8(const char* tile, int r0, int lane) {
-  const int r = r0 + (lane & 31), s = (r >> 2) & 3, c0 = 2 * (lane >> 5);
-  const u32x4 lo = *LDS_PTR(const u32x4, tile + r * 64 + ((c0 ^ s) << 4)), hi = *LDS_PTR(const u32x4, tile + r * 64 + (((c0 + 1) ^ s) << 4));
+  const int r = r0 + (lane & 31), s = (r >> 2) & 3, c0 = lane >> 5;
+  const u32x4 lo = *LDS_PTR(const u32x4, tile + r * 64 + ((c0 ^ s) << 4)), hi = *LDS_PTR(const u32x4, tile + r * 64 + (((c0 + 2) ^ s) << 4));
   return i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
 }
 

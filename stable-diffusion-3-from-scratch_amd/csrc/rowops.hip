@@ -1032,6 +1032,56 @@ __global__ __launch_bounds__(256) void fp8_quant_delayed_kernel(const TI* __rest
 }
 }  // namespace
 
+namespace {
+// MX quantisation: one thread per 32-element block (64 B of bf16 / 128 B of fp32 in, 32 B + 1 scale byte out); consecutive
+// threads take consecutive blocks of a row, so the loads and the e4m3 stores of a wave are contiguous.
+template <typename TI>
+__global__ __launch_bounds__(256) void mxfp8_quant_kernel(const TI* __restrict__ x, int rows, int K, int64_t ldx, uint4* __restrict__ q, unsigned char* __restrict__ sc) {
+  const int bpr = K >> 5;                                             // blocks per row
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)rows * bpr) return;
+  const int row = (int)(t / bpr), blk = (int)(t - (int64_t)row * bpr);
+  const TI* src = x + (int64_t)row * ldx + blk * 32;
+  float v[32];
+#pragma unroll
+  for (int c = 0; c < 4; c++) ld8(src + c * 8, *(float(*)[8])(v + c * 8));
+  float amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 32; e++) amax = fmaxf(amax, fabsf(v[e]));
+  // E8M0 exponent: the smallest power of two with amax / 2^ex <= 448 -- floor(log2(amax)) - emax(e4m3 = 8) from the float's own
+  // exponent field, plus one when the mantissa exceeds 448 / 256 (denormal / zero amax -> the smallest scale)
+  int ex = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+  if (amax > 448.f * __uint_as_float((unsigned)(ex + 127 > 0 ? ex + 127 : 0) << 23)) ex++;   // mantissa above 1.75: take the next scale, nothing saturates
+  ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
+  const float inv = __uint_as_float((unsigned)(127 - ex) << 23 ? (unsigned)(127 - ex) << 23 : 0x00400000u);   // 2^-ex (ex = 127: 2^-127 is a denormal)
+  unsigned w[8];
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    float a0 = fminf(fmaxf(v[4 * c] * inv, -448.f), 448.f), a1 = fminf(fmaxf(v[4 * c + 1] * inv, -448.f), 448.f);
+    float a2 = fminf(fmaxf(v[4 * c + 2] * inv, -448.f), 448.f), a3 = fminf(fmaxf(v[4 * c + 3] * inv, -448.f), 448.f);
+    int pk = 0;
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, pk, false);
+    pk = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
+    w[c] = (unsigned)pk;
+  }
+  uint4* dst = q + ((int64_t)row * K + blk * 32) / 16;
+  dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+  dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+  sc[((int64_t)(blk >> 1) * rows + row) * 2 + (blk & 1)] = (unsigned char)(ex + 127);
+}
+}  // namespace
+
+extern "C" int mmdit_mxfp8_quantize(const void* x, int x_dtype, int rows, int K, int64_t ldx, void* q_fp8, void* scales, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && q_fp8 && scales && rows > 0 && rows % 8 == 0 && K > 0 && K % 64 == 0 && ldx >= K && ldx % 8 == 0);
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t nblk = (int64_t)rows * (K / 32);
+  const dim3 grid((unsigned)((nblk + 255) / 256));
+  if (x_dtype == MMDIT_F32) hipLaunchKernelGGL((mxfp8_quant_kernel<float>), grid, dim3(256), 0, s, (const float*)x, rows, K, ldx, (uint4*)q_fp8, (unsigned char*)scales);
+  else if (x_dtype == MMDIT_BF16) hipLaunchKernelGGL((mxfp8_quant_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)x, rows, K, ldx, (uint4*)q_fp8, (unsigned char*)scales);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
 extern "C" int mmdit_fp8_quantize_delayed(const void* x, int x_dtype, int64_t n, float* state, int phase, float margin, void* q_fp8, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(x && state && q_fp8 && n > 0 && n % 8 == 0 && phase >= 0 && margin >= 1.f);
   hipStream_t s = (hipStream_t)stream;

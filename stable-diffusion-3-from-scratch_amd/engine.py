@@ -16,6 +16,8 @@ Precision modes:
   fast   : bf16 activations / bf16 MFMA operands, fp32 accumulation, fp32 residual stream, flash attention.
   parity : fp32 activations, 3-term split-bf16 (fp32-exact) MFMA GEMMs, attention core that reproduces the
            rounding points of the reference's CPU branch (Attention.py:277-284).  For the 1e-3 golden check.
+  mxfp8  : as fp8 with MX block scales (one E8M0 scale per 32 K values, applied by the matrix instruction; stateless one-pass
+           quantisation of the activations).
   fp8    : fast, plus e4m3 operands (per-tensor scales, delayed activation scaling) for the QKV / out / MLP GEMMs of every
            block.  Forward only (the sampler, BASELINE config 5).
 """
@@ -31,9 +33,10 @@ BF16 = torch.bfloat16
 
 
 class Mode:
-    def __init__(self, fast: bool = True, fp8: bool = False):
+    def __init__(self, fast: bool = True, fp8: bool = False, mx: bool = False):
         self.fast = fast
         self.fp8 = fp8          # inference only: the four big GEMMs of a block take e4m3 operands (per-tensor scales)
+        self.mx = mx            # ... with MX block scales (E8M0 per 32 K values) instead of per-tensor scales
         self.T = BF16 if fast else F32
         self.prec = PREC_BF16 if fast else PREC_SPLIT
         self.attn_mode = 0 if fast else 1
@@ -47,6 +50,7 @@ class Mode:
 FAST = Mode(True)
 PARITY = Mode(False)
 FP8 = Mode(True, fp8=True)
+MXFP8 = Mode(True, fp8=True, mx=True)
 
 MOD_NAMES_FULL = ["shift1x", "scale1x", "gate1x", "shift2x", "scale2x", "gate2x", "shift1c", "scale1c", "gate1c", "shift2c", "scale2c", "gate2c"]
 
@@ -67,6 +71,16 @@ def _to_fp8(m, p):
     if A.dtype != BF16 or B.dtype != BF16 or A.shape[1] % 128 or p.get("a_kmajor") or p.get("b_kmajor"):
         return p
     ent, gen = m._q.get(id(B)), getattr(B, "_mmdit_gen", 0)     # (the bf16 copy is refreshed in place: packing.Pack.generation)
+    if m.mx:    # MX: block scales, stateless one-pass quantisation of the activation (rows must be a multiple of 8: scale layout)
+        if A.shape[0] % 8 or B.shape[0] % 8 or not A.is_contiguous():
+            return p
+        if ent is None or ent[4] != gen:
+            qb, sb = ops.quant_mxfp8(B)
+            ent = m._q[id(B)] = (B, qb, sb, None, gen)
+        qa, sa = ops.quant_mxfp8(A)
+        q = {k: v for k, v in p.items() if k != "aux"}
+        q.update(A=qa, B=ent[1], scale_a=sa, scale_b=ent[2], scale_mode=1)
+        return q
     if ent is None or ent[4] != gen:
         qb, sb = ops.quant_fp8(B)
         ent = m._q[id(B)] = (B, qb, sb, ent[3] if ent is not None else ops.Fp8Site(), gen)
@@ -79,7 +93,9 @@ def _to_fp8(m, p):
 def _group(m, problems, fp8=False):
     """One grouped launch; problems = list of dicts (A, B, + gemm kwargs).  fp8: eligible for e4m3 operands in FP8 mode."""
     if fp8 and m.fp8:
-        problems = [_to_fp8(m, p) for p in problems]
+        q = [_to_fp8(m, p) for p in problems]
+        if all(x is not p for x, p in zip(q, problems)):     # one kernel variant per launch: all problems in e4m3, or none
+            problems = q
     for p in problems:
         p["precision"] = m.prec
     return ops.gemm_grouped(problems)
@@ -290,7 +306,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     sv.X1, sv.ln2x, sv.mu2x, sv.rs2x = ops.ln_modulate_fwd_res(sv.X, sv.acc_ox, ms.gate1x, ms.scale2x, ms.shift2x, N, m.T)
     # SwiGLU in the up-projection's epilogue (bf16 mode, hidden % 128 == 0, K % 64 == 0): the GEMM writes the pre-activations and
     # the activation; otherwise (GELU, parity / fp8 mode, odd sizes) the activation is a row kernel over the GEMM output
-    fuse = _FUSE_SWIGLU and m.fast and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % (128 if m.fp8 else 64) == 0
+    fuse = _FUSE_SWIGLU and m.fast and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % (128 if m.fp8 else 64) == 0 and not m.mx   # (MX: 128x128 tiles, see gemm.hip pick_dma_cfg -- the fused epilogue needs the 256-column tile)
 
     def up(xn, mw, rows):
         if fuse:

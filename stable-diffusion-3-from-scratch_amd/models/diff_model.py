@@ -135,16 +135,16 @@ class diff_model(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def _mode(self):
-        return {"fast": engine.FAST, "parity": engine.PARITY, "fp8": engine.FP8}[self.precision]
+        return {"fast": engine.FAST, "parity": engine.PARITY, "fp8": engine.FP8, "mxfp8": engine.MXFP8}[self.precision]
 
     def set_precision(self, precision: str):
         """"fast" (bf16, training and inference), "parity" (fp32-exact GEMMs, the 1e-3 golden check) or "fp8": inference
         only -- e4m3 operands with per-tensor scales for the QKV / out / MLP GEMMs of every block (BASELINE config 5)."""
-        assert precision in ("fast", "parity", "fp8")
+        assert precision in ("fast", "parity", "fp8", "mxfp8")
         engine.FP8._q.clear()
         for mod in self.modules():
             if hasattr(mod, "precision"):
-                mod.precision = "fast" if precision == "fp8" else precision     # stand-alone sub-modules have no fp8 path
+                mod.precision = "fast" if precision in ("fp8", "mxfp8") else precision     # stand-alone sub-modules have no fp8 path
         self.precision = precision
         return self
 
@@ -188,8 +188,8 @@ class diff_model(nn.Module):
                            "assign an object with .text_to_embedding(text) and .VAE to self.text_encoders")
 
     def forward(self, x_t, t, c, c_pooled, nullCls_pooled=None, nullCls_gemma=None, nullCls_bert=None):
-        if self.precision == "fp8" and torch.is_grad_enabled():
-            raise RuntimeError('precision "fp8" is inference-only (no backward schedule): call under torch.no_grad()')
+        if self.precision in ("fp8", "mxfp8") and torch.is_grad_enabled():
+            raise RuntimeError(f'precision "{self.precision}" is inference-only (no backward schedule): call under torch.no_grad()')
         x_t = x_t.to(self.device)
         t = t.to(self.device) if torch.is_tensor(t) else t
         c = c.to(self.device)

@@ -89,7 +89,7 @@ def torch_dtype(code: int):
 
 # ---------------------------------------------------------------------------------------------
 def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None, scale_a=None, scale_b=None):
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None, scale_a=None, scale_b=None, scale_mode=0):
     """conv = (mode, H, W, C): A is a zero-bordered NHWC bf16 tensor (batch, H+2, W+2, C) -- implicit-GEMM 3x3 convolution."""
     if conv is not None:
         mode, cH, cW, cC = conv
@@ -119,7 +119,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), (K_ if conv is not None else A.stride(0))
     if conv is not None:
         a.conv_mode, a.conv_H, a.conv_W, a.conv_C = conv
-    a.scale_a, a.scale_b = _p(scale_a), _p(scale_b)
+    a.scale_a, a.scale_b, a.scale_mode = _p(scale_a), _p(scale_b), int(scale_mode)
     a.B, a.b_dtype, a.b_kmajor, a.ldb = _p(B), _dt(B), int(b_kmajor), B.stride(0)
     a.C, a.c_dtype, a.ldc = _p(out), _dt(out), out.stride(0)
     a.M, a.N, a.K = M, N, K_
@@ -189,6 +189,16 @@ def quant_fp8(x):
     check(L.mmdit_fp8_amax(_p(_c(x)), _dt(x), n, _p(buf), _s()), "mmdit_fp8_amax")
     check(L.mmdit_fp8_quantize(_p(x), _dt(x), n, _p(buf), _p(q), _p(buf[1:]), _s()), "mmdit_fp8_quantize")
     return q, buf[1:]
+
+
+def quant_mxfp8(x):
+    """MX (OCP microscaling) e4m3 quantisation of a row-major 2-D operand: returns (q: float8_e4m3fn like x, scales: uint8 E8M0 block
+    scales in the GEMM's layout [K/64][rows][2], 512 spare bytes behind them) -- mmdit_mxfp8_quantize; pass scale_mode=1 to gemm()."""
+    rows, K = x.shape
+    q = torch.empty((rows, K), dtype=torch.float8_e4m3fn, device=x.device)
+    sc = torch.empty((K // 32) * rows + 512, dtype=torch.uint8, device=x.device)
+    check(_lib.lib().mmdit_mxfp8_quantize(_p(x), _dt(x), rows, K, x.stride(0), _p(q), _p(sc), _s()), "mmdit_mxfp8_quantize")
+    return q, sc
 
 
 class Fp8Site:

@@ -167,6 +167,32 @@ def test_fp8_mode_vs_e4m3_oracle(cname, h, w):
     assert torch.isfinite(v_fp8).all() and r8 < (2.5e-2 if cname == "xs" else 6e-2) and r8 < 0.8 * r816
 
 
+@pytest.mark.parametrize("cname,h,w", [("xs", 64, 64), ("b", 32, 32)])
+def test_mxfp8_mode_vs_mx_oracle(cname, h, w):
+    """precision "mxfp8" (MX block scales: one E8M0 scale per 32 K values, applied by the matrix instruction; stateless one-pass
+    quantisation) against the CPU oracle run with the same block quantisation (oracle gemm="mxfp8"), the bf16 forward and the
+    per-tensor fp8 mode.  Measured with these seeded weights: MX and per-tensor e4m3 sit equally far from the bf16 forward (xs 2.6e-2
+    both, B depth 6.7e-2 vs 7.1e-2) -- the activations have no outlier channels for the block scales to rescue -- so the check is
+    "not worse" (within 10 %), plus agreement with the MX oracle at the same bars as the per-tensor mode."""
+    x, c, cp = make_inputs(21, 4, h, w, text_scale=30.0)        # batch 4: 4 x 154 text rows are a multiple of 8 (scale layout)
+    t = torch.tensor([0.2, 0.9, 0.5, 0.7])
+    net, sd = build(cname, "fast")
+    with torch.no_grad():
+        v_fast = net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())
+        net.set_precision("fp8")
+        v_fp8 = net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())
+        net.set_precision("mxfp8")
+        v_mx = net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())
+        with pytest.raises(RuntimeError):
+            with torch.enable_grad():
+                net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())        # inference only
+        vomx = O.forward(sd, O.OracleConfig(**CFGS[cname], attn_core="flash_bf16", gemm="mxfp8"), x.clone(), t, c.clone(), cp.clone())
+    net.set_precision("fast")
+    rmx, rmx16, r816 = rel(v_mx, vomx), rel(v_mx, v_fast), rel(v_fp8, v_fast)
+    print(f"[mxfp8] {cname}: HIP mxfp8 vs MX oracle {rmx:.3e}; HIP mxfp8 vs HIP bf16 {rmx16:.3e}; HIP per-tensor fp8 vs HIP bf16 {r816:.3e}")
+    assert torch.isfinite(v_mx).all() and rmx < (2.5e-2 if cname == "xs" else 6e-2) and rmx16 < 1.1 * r816 and rmx < rmx16
+
+
 def test_l_train_step_with_vae_encode_in_the_loop():
     """Config 4's step at a size that runs in seconds: U(-1,1) 512^2 images -> FLUX-VAE encode on the same GPU (ImageLatentSource,
     reference helpers/VAE_T5_CLIP.py:176-182) -> MMDiT-L flow-matching step.  Checks the wiring (latent geometry and affine, the

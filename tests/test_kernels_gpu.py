@@ -486,6 +486,62 @@ def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
     assert rel(y.float(), A.float() @ W.float().t() + bias) < 6e-2
 
 
+def _mx_reference(x):
+    """torch restatement of mmdit_mxfp8_quantize: (e4m3 codes as uint8 (rows, K), E8M0 bytes in the GEMM layout [K/64][rows][2], dequantised fp32)."""
+    rows, K = x.shape
+    xb = x.float().reshape(rows, K // 32, 32)
+    amax = xb.abs().amax(-1, keepdim=True)
+    _, ex = torch.frexp(amax)
+    e = torch.where(amax > 0, ex - 1 - 8, torch.full_like(ex, -127))
+    e = torch.where(amax > 448.0 * torch.ldexp(torch.ones_like(amax), e), e + 1, e).clamp(-127, 127)     # amax / scale <= 448: nothing saturates
+    scale = torch.ldexp(torch.ones_like(amax), e)
+    q = (xb / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
+    sc = (e + 127).to(torch.uint8).reshape(rows, K // 64, 2).permute(1, 0, 2).contiguous().reshape(-1)
+    return q.reshape(rows, K).view(torch.uint8), sc, (q.float() * scale).reshape(rows, K)
+
+
+@pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (616, 2304, 768, torch.float32),
+                                             (16384, 2304, 768, torch.bfloat16)])
+def test_gemm_mxfp8_operands(ops, M, N, K, out_dtype):
+    """MX (block-scaled e4m3) operand GEMM: the quantiser is bit-identical to its torch restatement (codes and E8M0 scales, in the
+    GEMM's scale layout), and the GEMM -- block scales applied by v_mfma_scale_f32_32x32x64_f8f6f4 -- equals the fp32 product of
+    the dequantised operands.  Blocks get magnitudes spread over 2^-20 .. 2^20 (plus an all-zero block) to exercise the scales."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    A = torch.randn((M, K), generator=g, device="cuda")
+    A = (A.reshape(M, K // 32, 32) * torch.exp2(torch.randint(-20, 21, (M, K // 32, 1), generator=g, device="cuda").float())).reshape(M, K)
+    A[3, 32:64] = 0.0
+    A = A.to(torch.bfloat16)
+    W = (torch.randn((N, K), generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g, device="cuda")
+    qa, sa = ops.quant_mxfp8(A)
+    qw, sw = ops.quant_mxfp8(W)
+    for (q, sc, x) in ((qa, sa, A), (qw, sw, W)):
+        q_ref, sc_ref, deq = _mx_reference(x)
+        assert torch.equal(q.view(torch.uint8), q_ref) and torch.equal(sc[:sc_ref.numel()], sc_ref)
+        assert rel(deq, x.float()) < 4e-2
+    y = ops.gemm(qa, qw, bias=bias, out_dtype=out_dtype, scale_a=sa, scale_b=sw, scale_mode=1)
+    ref = _mx_reference(A)[2].double() @ _mx_reference(W)[2].double().t() + bias.double()
+    r = rel(y.double(), ref)
+    print(f"[mxfp8 gemm] {M}x{N}x{K} -> {out_dtype}: rel err vs the fp64 product of the dequantised operands = {r:.3e}")
+    assert r < (5e-3 if out_dtype == torch.bfloat16 else 5e-5)      # (fp32 accumulation over blocks whose magnitudes span 2^40)
+    assert rel(y.float(), A.float() @ W.float().t() + bias) < 6e-2
+
+
+def test_gemm_mxfp8_swiglu_epilogue(ops):
+    """The packed w12 GEMM with the SwiGLU epilogue on MX operands (the gate / up rows of a tile are two separate runs of scale rows)."""
+    g = torch.Generator(device="cuda").manual_seed(2)
+    M, h, K = 1024, 512, 256
+    A = torch.randn((M, K), generator=g, device="cuda").to(torch.bfloat16)
+    W = (torch.randn((2 * h, K), generator=g, device="cuda") * torch.exp2(torch.randint(-6, 3, (2 * h, 1), generator=g, device="cuda").float()) * 0.1).to(torch.bfloat16)
+    bias = torch.randn(2 * h, generator=g, device="cuda")
+    qa, sa = ops.quant_mxfp8(A)
+    qw, sw = ops.quant_mxfp8(W)
+    y = ops.gemm(qa, qw, bias=bias, act=ops.ACT_SWIGLU, scale_a=sa, scale_b=sw, scale_mode=1)
+    gu = (_mx_reference(A)[2] @ _mx_reference(W)[2].t() + bias).to(torch.bfloat16).float()
+    ref = torch.nn.functional.silu(gu[:, :h]) * gu[:, h:]
+    assert rel(y.float(), ref) < 6e-3
+
+
 def test_fp8_delayed_scaling_site(ops):
     """One-pass quantiser with delayed scaling: call k uses margin x amax(call k-1); values above that range saturate at +-448."""
     g = torch.Generator(device="cuda").manual_seed(1)

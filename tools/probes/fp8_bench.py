@@ -1,4 +1,4 @@
-"""fp8 (e4m3) vs bf16 operand GEMM on the MMDiT forward shapes (NT, bf16 out)."""
+"""fp8 (e4m3: per-tensor scales / MX block scales) vs bf16 operand GEMM on the MMDiT forward shapes (NT, bf16 out), and the quantisers."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import sd3_amd
@@ -19,5 +19,11 @@ for name, M, N, K in (("qkv", 26240, 2304, 768), ("out", 26240, 768, 768), ("w12
     tb = bench(lambda: ops.gemm(A, W, out_dtype=torch.bfloat16))
     tf = bench(lambda: ops.gemm(qa, qw, out_dtype=torch.bfloat16, scale_a=sa, scale_b=sw))
     tq = bench(lambda: ops.quant_fp8(A))
+    ma, msa = ops.quant_mxfp8(A); mw, msw = ops.quant_mxfp8(W)
+    tm = bench(lambda: ops.gemm(ma, mw, out_dtype=torch.bfloat16, scale_a=msa, scale_b=msw, scale_mode=1))
+    tmq = bench(lambda: ops.quant_mxfp8(A))
+    site = ops.Fp8Site(); site.quantise(A)
+    tdq = bench(lambda: site.quantise(A))
     fl = 2.0 * M * N * K
-    print(f"{name:<6} {M}x{N}x{K}: bf16 {tb*1e6:8.1f} us {fl/tb/1e12:7.1f} TF | fp8 {tf*1e6:8.1f} us {fl/tf/1e12:7.1f} TF ({tb/tf:.2f}x) | quantise A {tq*1e6:6.1f} us")
+    print(f"{name:<6} {M}x{N}x{K}: bf16 {tb*1e6:8.1f} us {fl/tb/1e12:7.1f} TF | fp8 {tf*1e6:8.1f} us {fl/tf/1e12:7.1f} TF ({tb/tf:.2f}x) | mxfp8 {tm*1e6:8.1f} us {fl/tm/1e12:7.1f} TF ({tb/tm:.2f}x)"
+          f" | quantise A: two-pass {tq*1e6:5.1f}, delayed {tdq*1e6:5.1f}, MX {tmq*1e6:5.1f} us")

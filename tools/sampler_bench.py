@@ -1,5 +1,5 @@
 """BASELINE.json config 5 on one GPU: 28-step rectified-flow sampler (Euler, CFG: a batch of 2B forwards per step) at MMDiT-L / 512^2
-(or --B: MMDiT-B / 256^2) through diff_model.sample_imgs, bf16 and fp8 operands; identity stand-ins for the text encoders / VAE
+(or --B: MMDiT-B / 256^2) through diff_model.sample_imgs, bf16, per-tensor fp8 and MX fp8 operands; identity stand-ins for the text encoders / VAE
 decode (out of this build's scope).  Prints images/s = B / wall.  python tools/sampler_bench.py [--B] [--batch 32] [--steps 28]"""
 import argparse
 import os
@@ -48,7 +48,7 @@ class _Enc:
 
 
 net.text_encoders = _Enc()
-for prec in ("fast", "fp8"):
+for prec in ("fast", "fp8", "mxfp8"):
     net.set_precision(prec)
     net.sample_imgs(args.batch, 2, ["x"], cfg_scale=3.0, width=res, height=res, generator=torch.Generator().manual_seed(0))
     torch.cuda.synchronize()
@@ -56,5 +56,5 @@ for prec in ("fast", "fp8"):
     out = net.sample_imgs(args.batch, args.steps, ["x"], cfg_scale=3.0, width=res, height=res, generator=torch.Generator().manual_seed(0))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"{'MMDiT-B 256^2' if args.B else 'MMDiT-L 512^2'} sampler, {args.steps} Euler steps, CFG, batch {args.batch} [{'bf16' if prec == 'fast' else 'fp8'}]: "
+    print(f"{'MMDiT-B 256^2' if args.B else 'MMDiT-L 512^2'} sampler, {args.steps} Euler steps, CFG, batch {args.batch} [{'bf16' if prec == 'fast' else prec}]: "
           f"{dt * 1e3:.1f} ms, {args.batch / dt:.2f} images/s, finite={bool(torch.isfinite(out).all())}")
