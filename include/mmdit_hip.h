@@ -128,6 +128,21 @@ int mmdit_fp8_quantize_delayed(const void* x, int x_dtype, int64_t n, float* sta
  * (allocate (K/32) * rows + 512 bytes).  Replaces the per-tensor amax / delayed-scaling passes in front of an fp8 GEMM
  * (reference: none -- the reference runs bf16 autocast; BASELINE.json config 5 asks for an fp8 inference path). */
 int mmdit_mxfp8_quantize(const void* x, int x_dtype, int rows, int K, int64_t ldx, void* q_fp8, void* scales_e8m0, mmdit_stream_t stream);
+/* MX-producing variants of the three kernels whose outputs feed the fp8 GEMMs of a block (inference, "mxfp8" precision): the
+ * activation leaves its producer as e4m3 codes + E8M0 block scales (layout of mmdit_gemm_args.scale_mode 1, buffers of
+ * (K/32) * rows + 512 bytes), bit-identical to the bf16 output followed by mmdit_mxfp8_quantize -- no quantise pass in front of the
+ * QKV / out-projection / MLP GEMMs.  rows % 8 == 0 everywhere.
+ *   mmdit_ln_modulate_fwd_mx: adaLN (Norm.py:16-22), optionally with the pending gated residual update of mmdit_ln_modulate_fwd_res
+ *     (acc != NULL: bf16 acc, writes x_out); d % 64 == 0.
+ *   mmdit_swiglu_fwd_mx: SwiGLU activation of the bf16 pre-activations [g | u] (MLP.py:25-40); hidden % 64 == 0.
+ *   mmdit_attn_fwd_mx: flash attention forward (mode 0 of mmdit_attn_fwd) writing Ox / Oc as e4m3 (B, tokens, heads * 64) with scales
+ *     [heads][B * tokens][2]; no lse (inference). */
+int mmdit_ln_modulate_fwd_mx(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, float* x_out,
+                             const float* scale, const float* shift, int64_t ld_mod, int rows, int d, int rows_per_batch,
+                             void* q_fp8, void* scales_e8m0, float* mean, float* rstd, mmdit_stream_t stream);
+int mmdit_swiglu_fwd_mx(const void* gu, int dtype, int rows, int hidden, void* q_fp8, void* scales_e8m0, mmdit_stream_t stream);
+int mmdit_attn_fwd_mx(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
+                      void* Ox_fp8, void* Oc_fp8, void* scales_x, void* scales_c, mmdit_stream_t stream);
 
 /* dtype conversion of n elements (bf16 shadow copies of the fp32 master weights; the
  * reference gets these from torch.autocast, model_trainer.py:416). n%8==0 not required. */

@@ -50,6 +50,9 @@ _SIGNATURES = {
     "mmdit_fp8_quantize": ([_vp, _i, _i64, _vp, _vp, _vp, _vp], _i),
     "mmdit_fp8_quantize_delayed": ([_vp, _i, _i64, _vp, _i, ctypes.c_float, _vp, _vp], _i),
     "mmdit_mxfp8_quantize": ([_vp, _i, _i, _i, _i64, _vp, _vp, _vp], _i),
+    "mmdit_ln_modulate_fwd_mx": ([_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "mmdit_swiglu_fwd_mx": ([_vp, _i, _i, _i, _vp, _vp, _vp], _i),
+    "mmdit_attn_fwd_mx": ([_vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_float, _vp, _vp, _vp, _vp, _vp], _i),
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_fwd_res": ([_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),

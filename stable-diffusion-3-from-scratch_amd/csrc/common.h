@@ -80,6 +80,25 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
+// ---- MX (OCP microscaling) e4m3 helpers ------------------------------------------------------------------------------------
+// E8M0 exponent of a 32-block with absolute maximum amax: the smallest power of two with amax / 2^ex <= 448 (floor(log2 amax) - 8
+// from the float's exponent field, plus one when the mantissa exceeds 448 / 256; zero / denormal amax -> 2^-127), and 2^-ex.
+__device__ __forceinline__ int mx_exponent(float amax, float& inv) {
+  int ex = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
+  if (amax > 448.f * __uint_as_float((unsigned)(ex + 127 > 0 ? ex + 127 : 0) << 23)) ex++;
+  ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
+  const unsigned f = (unsigned)(127 - ex) << 23;
+  inv = __uint_as_float(f ? f : 0x00400000u);   // (ex = 127: 2^-127 is a denormal)
+  return ex;
+}
+__device__ __forceinline__ unsigned mx_pack4(const float* v, float inv) {
+  const float a0 = fminf(fmaxf(v[0] * inv, -448.f), 448.f), a1 = fminf(fmaxf(v[1] * inv, -448.f), 448.f);
+  const float a2 = fminf(fmaxf(v[2] * inv, -448.f), 448.f), a3 = fminf(fmaxf(v[3] * inv, -448.f), 448.f);
+  int pk = 0;
+  pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, pk, false);
+  pk = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
+  return (unsigned)pk;
+}
 // transpose read: lane gets 4 bf16 = column (lane&15) of the 4x16 block whose rows are addressed by the 16-lane group
 __device__ __forceinline__ s16x4 lds_tr16(const void* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p)); }
 

@@ -17,11 +17,19 @@ constexpr float RMS_EPS = FLT_EPSILON;    // nn.RMSNorm(eps=None) on fp32 input
 // (X_out = acc * gate + X_in, Transformer_Block_Dual.py:64-76) is formed here, where the row is in registers anyway, instead of
 // in the fp32 epilogue of the projection GEMM (which then only writes acc in the activation dtype); the updated residual
 // stream row is written to xo (it is the next residual input and the x of the backward pass).
-template <int NIT, typename TO, typename TA, bool RES>
+// round to bf16 and back: a fused producer quantises exactly what the unfused path would have stored as bf16 and quantised afterwards
+__device__ __forceinline__ float bf16_round(float x) { return __builtin_bit_cast(float, pack_bf2(x, 0.f) << 16); }
+// scale byte of (row, 32-block blk) in the GEMM's layout [K/64][rows][2]
+__device__ __forceinline__ int64_t mx_scale_index(int row, int blk, int rows) { return ((int64_t)(blk >> 1) * rows + row) * 2 + (blk & 1); }
+
+// MX (TO = unsigned char, d % 32 == 0): the normalised row leaves as e4m3 codes + E8M0 block scales (a 32-block is the 4 values of 8
+// adjacent lanes of one iteration), bit-identical to the bf16 output followed by mmdit_mxfp8_quantize.
+template <int NIT, typename TO, typename TA, bool RES, bool MX = false>
 __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                          int64_t ld_mod, int rows, int d, int rpb, TO* __restrict__ out,
                                                          float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, float* __restrict__ xo) {
+                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, float* __restrict__ xo,
+                                                         unsigned char* __restrict__ mx_scales = nullptr) {
   const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = d >> 2;
@@ -69,7 +77,20 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
       ld4(sc + ch * 4, a); ld4(sh + ch * 4, h);
 #pragma unroll
       for (int e = 0; e < 4; e++) o[e] = (v[it][e] - mean) * rstd * (1.f + a[e]) + h[e];
-      st4(orow + ch * 4, o);
+      if constexpr (MX) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) o[e] = bf16_round(o[e]);
+        float amax = fmaxf(fmaxf(fabsf(o[0]), fabsf(o[1])), fmaxf(fabsf(o[2]), fabsf(o[3])));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 4, 64));
+        float inv;
+        const int ex = mx_exponent(amax, inv);
+        *(unsigned*)((unsigned char*)out + (int64_t)row * d + ch * 4) = mx_pack4(o, inv);
+        if ((lane & 7) == 0) mx_scales[mx_scale_index(row, ch >> 3, rows)] = (unsigned char)(ex + 127);
+      } else {
+        st4(orow + ch * 4, o);
+      }
     }
   }
 }
@@ -468,8 +489,9 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
-template <typename T, bool GELU>
-__global__ __launch_bounds__(256) void mlp_act_fwd_kernel(const T* __restrict__ gu, T* __restrict__ h, int rows, int hidden) {
+// MX: h leaves as e4m3 codes + E8M0 block scales (a 32-block is the 8 values of 4 adjacent column lanes), hidden % 32 == 0
+template <typename T, bool GELU, bool MX = false>
+__global__ __launch_bounds__(256) void mlp_act_fwd_kernel(const T* __restrict__ gu, T* __restrict__ h, int rows, int hidden, unsigned char* __restrict__ mx_scales = nullptr) {
   // 256 columns x CO_RCH rows per workgroup (32 column groups of 8 x 8 row lanes), two rows in flight per thread
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 256 + tx * 8;
@@ -493,7 +515,19 @@ __global__ __launch_bounds__(256) void mlp_act_fwd_kernel(const T* __restrict__ 
       float o[8];
 #pragma unroll
       for (int e = 0; e < 8; e++) o[e] = GELU ? gelu_f(g[k][e]) : silu_f(g[k][e]) * u[k][e];
-      st8(h + (int64_t)r * hidden + c, o);
+      if constexpr (MX) {
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { o[e] = bf16_round(o[e]); amax = fmaxf(amax, fabsf(o[e])); }
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        float inv;
+        const int ex = mx_exponent(amax, inv);
+        *(uint2*)((unsigned char*)h + (int64_t)r * hidden + c) = make_uint2(mx_pack4(o, inv), mx_pack4(o + 4, inv));
+        if ((tx & 3) == 0) mx_scales[mx_scale_index(r, c >> 5, rows)] = (unsigned char)(ex + 127);
+      } else {
+        st8(h + (int64_t)r * hidden + c, o);
+      }
     }
   }
 }
@@ -786,6 +820,21 @@ extern "C" int mmdit_ln_modulate_fwd_res(const float* x, const void* acc, int ac
   return mmdit_launch_status();
 }
 
+extern "C" int mmdit_ln_modulate_fwd_mx(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, float* x_out,
+                                        const float* scale, const float* shift, int64_t ld_mod, int rows, int d, int rpb,
+                                        void* q_fp8, void* scales_e8m0, float* mean, float* rstd, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(x && scale && shift && q_fp8 && scales_e8m0 && mean && rstd && rows > 0 && rows % 8 == 0 && d > 0 && d % 64 == 0 && d <= 4096 && rpb > 0 && ld_mod % 4 == 0);
+  MMDIT_CHECK_ARG(!acc || (gate && x_out && acc_dtype == MMDIT_BF16 && ld_gate % 4 == 0));
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d);
+  dim3 grid((rows + 3) / 4);
+  unsigned char* q = (unsigned char*)q_fp8;
+  unsigned char* sc = (unsigned char*)scales_e8m0;
+  if (acc) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, unsigned char, bf16_t, true, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, q, mean, rstd, (const bf16_t*)acc, gate, ld_gate, x_out, sc)); }
+  else { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, unsigned char, bf16_t, false, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, q, mean, rstd, nullptr, nullptr, 0, nullptr, sc)); }
+  return mmdit_launch_status();
+}
+
 extern "C" int mmdit_gate_residual_fwd(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, int rows, int d, int rpb,
                                        float* out, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(x && acc && gate && out && rows > 0 && d > 0 && d % 4 == 0 && rpb > 0 && ld_gate % 4 == 0);
@@ -928,6 +977,14 @@ static int mlp_act_bwd(const void* dh, const void* gu, void* dgu, int dtype, int
   else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }
+extern "C" int mmdit_swiglu_fwd_mx(const void* gu, int dtype, int rows, int hidden, void* q_fp8, void* scales_e8m0, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(gu && q_fp8 && scales_e8m0 && rows > 0 && rows % 8 == 0 && hidden > 0 && hidden % 64 == 0);
+  dim3 grid((hidden + 255) / 256, (rows + CO_RCH - 1) / CO_RCH);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == MMDIT_BF16) hipLaunchKernelGGL((mlp_act_fwd_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)q_fp8, rows, hidden, (unsigned char*)scales_e8m0);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
 extern "C" int mmdit_swiglu_fwd(const void* gu, void* h, int dtype, int rows, int hidden, mmdit_stream_t st) { return mlp_act_fwd<false>(gu, h, dtype, rows, hidden, st); }
 extern "C" int mmdit_swiglu_bwd(const void* dh, const void* gu, void* dgu, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t st) { return mlp_act_bwd<false>(dh, gu, dgu, dtype, rows, hidden, dbias, st); }
 extern "C" int mmdit_gelu_fwd(const void* u, void* h, int dtype, int rows, int hidden, mmdit_stream_t st) { return mlp_act_fwd<true>(u, h, dtype, rows, hidden, st); }
@@ -1048,26 +1105,15 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const TI* __restrict__
   float amax = 0.f;
 #pragma unroll
   for (int e = 0; e < 32; e++) amax = fmaxf(amax, fabsf(v[e]));
-  // E8M0 exponent: the smallest power of two with amax / 2^ex <= 448 -- floor(log2(amax)) - emax(e4m3 = 8) from the float's own
-  // exponent field, plus one when the mantissa exceeds 448 / 256 (denormal / zero amax -> the smallest scale)
-  int ex = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127 - 8;
-  if (amax > 448.f * __uint_as_float((unsigned)(ex + 127 > 0 ? ex + 127 : 0) << 23)) ex++;   // mantissa above 1.75: take the next scale, nothing saturates
-  ex = ex < -127 ? -127 : (ex > 127 ? 127 : ex);
-  const float inv = __uint_as_float((unsigned)(127 - ex) << 23 ? (unsigned)(127 - ex) << 23 : 0x00400000u);   // 2^-ex (ex = 127: 2^-127 is a denormal)
+  float inv;
+  const int ex = mx_exponent(amax, inv);
   unsigned w[8];
 #pragma unroll
-  for (int c = 0; c < 8; c++) {
-    float a0 = fminf(fmaxf(v[4 * c] * inv, -448.f), 448.f), a1 = fminf(fmaxf(v[4 * c + 1] * inv, -448.f), 448.f);
-    float a2 = fminf(fmaxf(v[4 * c + 2] * inv, -448.f), 448.f), a3 = fminf(fmaxf(v[4 * c + 3] * inv, -448.f), 448.f);
-    int pk = 0;
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, pk, false);
-    pk = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
-    w[c] = (unsigned)pk;
-  }
+  for (int c = 0; c < 8; c++) w[c] = mx_pack4(v + 4 * c, inv);
   uint4* dst = q + ((int64_t)row * K + blk * 32) / 16;
   dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
   dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
-  sc[((int64_t)(blk >> 1) * rows + row) * 2 + (blk & 1)] = (unsigned char)(ex + 127);
+  sc[mx_scale_index(row, blk, rows)] = (unsigned char)(ex + 127);
 }
 }  // namespace
 

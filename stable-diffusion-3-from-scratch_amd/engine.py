@@ -68,16 +68,17 @@ def _to_fp8(m, p):
     """fp8 inference mode: quantise the activation on the fly (per-tensor amax -> e4m3), take the cached e4m3 copy of the
     weight, drop the backward-only aux output.  Problems whose K is not a multiple of the 128-wide fp8 K-tile stay bf16."""
     A, B = p["A"], p["B"]
-    if A.dtype != BF16 or B.dtype != BF16 or A.shape[1] % 128 or p.get("a_kmajor") or p.get("b_kmajor"):
+    pre = isinstance(A, ops.MxAct)       # the producer already emitted MX e4m3 (block_fwd checked the site's eligibility)
+    if not pre and (A.dtype != BF16 or B.dtype != BF16 or A.shape[1] % 128 or p.get("a_kmajor") or p.get("b_kmajor")):
         return p
     ent, gen = m._q.get(id(B)), getattr(B, "_mmdit_gen", 0)     # (the bf16 copy is refreshed in place: packing.Pack.generation)
     if m.mx:    # MX: block scales, stateless one-pass quantisation of the activation (rows must be a multiple of 8: scale layout)
-        if A.shape[0] % 8 or B.shape[0] % 8 or not A.is_contiguous():
+        if not pre and (A.shape[0] % 8 or B.shape[0] % 8 or not A.is_contiguous()):
             return p
         if ent is None or ent[4] != gen:
             qb, sb = ops.quant_mxfp8(B)
             ent = m._q[id(B)] = (B, qb, sb, None, gen)
-        qa, sa = ops.quant_mxfp8(A)
+        qa, sa = (A.q, A.sc) if pre else ops.quant_mxfp8(A)
         q = {k: v for k, v in p.items() if k != "aux"}
         q.update(A=qa, B=ent[1], scale_a=sa, scale_b=ent[2], scale_mode=1)
         return q
@@ -261,9 +262,13 @@ class Pending:
         return self.x if self.acc is None else ops.gate_residual_fwd(self.x, self.acc, self.gate, self.rpb)
 
 
-def _norm(m, P, scale, shift, rpb):
-    """adaLN of a (possibly pending) residual stream: returns (materialised stream fp32, normed, mean, rstd)."""
-    if isinstance(P, Pending) and P.acc is not None:
+def _norm(m, P, scale, shift, rpb, mx=False):
+    """adaLN of a (possibly pending) residual stream: returns (materialised stream fp32, normed, mean, rstd).  mx: the normed rows
+    leave as MX e4m3 (ops.MxAct) for the fp8 GEMM that consumes them."""
+    pend = isinstance(P, Pending) and P.acc is not None
+    if mx:
+        return ops.ln_modulate_fwd_mx(P.x if isinstance(P, Pending) else P, scale, shift, rpb, acc=P.acc if pend else None, gate=P.gate if pend else None)
+    if pend:
         return ops.ln_modulate_fwd_res(P.x, P.acc, P.gate, scale, shift, rpb, m.T)
     x = P.x if isinstance(P, Pending) else P
     return (x,) + ops.ln_modulate_fwd(x, scale, shift, rpb, m.T)
@@ -285,25 +290,33 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
         sv.yp = _gemm(m, y, w.Wy, bias=w.by, act=ACT_SILU, aux=sv.pre, out_dtype=m.T)
         sv.mod = _gemm(m, sv.yp, w.Wmod, out_dtype=F32)
     ms = _mod_views(sv.mod, d, w.last)
+    # "mxfp8" inference: the activations that feed the four fp8 GEMM sites leave their producers (adaLN, attention, SwiGLU) as MX e4m3
+    # -- no quantise passes -- when every site of the block is eligible (K % 128, rows % 8: the scale layout; SwiGLU MLPs)
+    mxf = (m.mx and not keep and dev.type == "cuda" and d % 128 == 0 and (B * N) % 8 == 0 and (B * Mt) % 8 == 0 and not w.mlp_x.gelu
+           and w.mlp_x.hidden % 128 == 0 and (w.last or (not w.mlp_c.gelu and w.mlp_c.hidden % 128 == 0)) and _MX_FUSE)
 
-    sv.X, sv.ln1x, sv.mu1x, sv.rs1x = _norm(m, X, ms.scale1x, ms.shift1x, N)
-    sv.C, sv.ln1c, sv.mu1c, sv.rs1c = _norm(m, C, ms.scale1c, ms.shift1c, Mt)
+    sv.X, sv.ln1x, sv.mu1x, sv.rs1x = _norm(m, X, ms.scale1x, ms.shift1x, N, mx=mxf)
+    sv.C, sv.ln1c, sv.mu1c, sv.rs1c = _norm(m, C, ms.scale1c, ms.shift1c, Mt, mx=mxf)
     sv.qkv_x, sv.qkv_c = _group(m, [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T)], fp8=True)
     sv.Q = torch.empty((B, H, S, 64), dtype=BF16, device=dev)
     sv.K, sv.V = torch.empty_like(sv.Q), torch.empty_like(sv.Q)
     ops.qk_norm_rope_fwd(sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, sv.Q, sv.K, sv.V)
     ops.qk_norm_rope_fwd(sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, sv.Q, sv.K, sv.V)
-    sv.Ox, sv.Oc, sv.lse = ops.attn_fwd(sv.Q, sv.K, sv.V, N, 64 ** -0.5, m.attn_mode)
+    if mxf:
+        sv.Oxa, sv.Oca = ops.attn_fwd_mx(sv.Q, sv.K, sv.V, N, 64 ** -0.5)
+    else:
+        sv.Ox, sv.Oc, sv.lse = ops.attn_fwd(sv.Q, sv.K, sv.V, N, 64 ** -0.5, m.attn_mode)
+        sv.Oxa = m.act(sv.Ox.view(B * N, d))
+        if both:
+            sv.Oca = m.act(sv.Oc.view(B * Mt, d))
 
     # attention output projections: the GEMM writes acc in the activation dtype; X1 = X + gate1 * acc is formed by norm2's kernel
-    sv.Oxa = m.act(sv.Ox.view(B * N, d))
     probs = [dict(A=sv.Oxa, B=w.Wo_x, out_dtype=m.T)]
     if both:
-        sv.Oca = m.act(sv.Oc.view(B * Mt, d))
         probs.append(dict(A=sv.Oca, B=w.Wo_c, out_dtype=m.T))
     outs = _group(m, probs, fp8=True)
     sv.acc_ox = outs[0]
-    sv.X1, sv.ln2x, sv.mu2x, sv.rs2x = ops.ln_modulate_fwd_res(sv.X, sv.acc_ox, ms.gate1x, ms.scale2x, ms.shift2x, N, m.T)
+    sv.X1, sv.ln2x, sv.mu2x, sv.rs2x = _norm(m, Pending(sv.X, sv.acc_ox, ms.gate1x, N), ms.scale2x, ms.shift2x, N, mx=mxf)
     # SwiGLU in the up-projection's epilogue (bf16 mode, hidden % 128 == 0, K % 64 == 0): the GEMM writes the pre-activations and
     # the activation; otherwise (GELU, parity / fp8 mode, odd sizes) the activation is a row kernel over the GEMM output
     fuse = _FUSE_SWIGLU and m.fast and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % (128 if m.fp8 else 64) == 0 and not m.mx   # (MX: 128x128 tiles, see gemm.hip pick_dma_cfg -- the fused epilogue needs the 256-column tile)
@@ -317,7 +330,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     sv.C1 = sv.C
     if both:
         sv.acc_oc = outs[1]
-        sv.C1, sv.ln2c, sv.mu2c, sv.rs2c = ops.ln_modulate_fwd_res(sv.C, sv.acc_oc, ms.gate1c, ms.scale2c, ms.shift2c, Mt, m.T)
+        sv.C1, sv.ln2c, sv.mu2c, sv.rs2c = _norm(m, Pending(sv.C, sv.acc_oc, ms.gate1c, Mt), ms.scale2c, ms.shift2c, Mt, mx=mxf)
         probs.append(up(sv.ln2c, w.mlp_c, B * Mt))
     outs = _group(m, probs, fp8=True)
     pre = [p.get("aux") for p in probs]
@@ -325,14 +338,14 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
         sv.gu_x, sv.h_x = pre[0], outs[0]
     else:
         sv.gu_x = outs[0]
-        sv.h_x = ops.mlp_act_fwd(sv.gu_x, w.mlp_x.hidden, w.mlp_x.gelu)
+        sv.h_x = ops.swiglu_fwd_mx(sv.gu_x, w.mlp_x.hidden) if mxf else ops.mlp_act_fwd(sv.gu_x, w.mlp_x.hidden, w.mlp_x.gelu)
     probs = [dict(A=sv.h_x, B=w.mlp_x.Wdown, bias=w.mlp_x.bdown, out_dtype=m.T)]
     if both:
         if fuse:
             sv.gu_c, sv.h_c = pre[1], outs[1]
         else:
             sv.gu_c = outs[1]
-            sv.h_c = ops.mlp_act_fwd(sv.gu_c, w.mlp_c.hidden, w.mlp_c.gelu)
+            sv.h_c = ops.swiglu_fwd_mx(sv.gu_c, w.mlp_c.hidden) if mxf else ops.mlp_act_fwd(sv.gu_c, w.mlp_c.hidden, w.mlp_c.gelu)
         probs.append(dict(A=sv.h_c, B=w.mlp_c.Wdown, bias=w.mlp_c.bdown, out_dtype=m.T))
     outs = _group(m, probs, fp8=True)
     sv.acc_mx = outs[0]
@@ -347,6 +360,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     return X2, C2, sv
 
 
+_MX_FUSE = _os.environ.get("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
 _FUSE_GATE = _os.environ.get("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
 
 

@@ -191,6 +191,61 @@ def quant_fp8(x):
     return q, buf[1:]
 
 
+class MxAct:
+    """An activation that left its producer in MX e4m3: q (rows, K) float8_e4m3fn codes + sc, the E8M0 block scales in the GEMM's
+    layout (see quant_mxfp8).  engine._to_fp8 hands it to the GEMM as is."""
+    __slots__ = ("q", "sc")
+
+    def __init__(self, q, sc):
+        self.q, self.sc = q, sc
+
+    @property
+    def shape(self):
+        return self.q.shape
+
+    def dequant(self):
+        """fp32 values (tests)."""
+        rows, K = self.q.shape
+        e = self.sc[:(K // 32) * rows].view(K // 64, rows, 2).permute(1, 0, 2).reshape(rows, K // 32).to(torch.int32) - 127
+        return (self.q.float().view(rows, K // 32, 32) * torch.ldexp(torch.ones((), device=self.q.device), e).unsqueeze(-1)).view(rows, K)
+
+
+def _mx_buffers(rows, K, device):
+    return (torch.empty((rows, K), dtype=torch.float8_e4m3fn, device=device), torch.empty((K // 32) * rows + 512, dtype=torch.uint8, device=device))
+
+
+def ln_modulate_fwd_mx(x, scale, shift, rows_per_batch, acc=None, gate=None):
+    """adaLN with the output in MX e4m3 (mmdit_ln_modulate_fwd_mx); acc / gate: the pending gated residual update, as in
+    ln_modulate_fwd_res.  Returns (x1 fp32 (x itself without acc), MxAct, mean, rstd)."""
+    rows, d = x.shape
+    q, sc = _mx_buffers(rows, d, x.device)
+    mean = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+    x1 = torch.empty((rows, d), dtype=torch.float32, device=x.device) if acc is not None else x
+    check(_lib.lib().mmdit_ln_modulate_fwd_mx(_p(_c(x)), _p(acc), _dt(acc) if acc is not None else BF16, _p(gate), gate.stride(0) if gate is not None else 0,
+                                              _p(x1) if acc is not None else None, _p(scale), _p(shift), scale.stride(0), rows, d, rows_per_batch,
+                                              _p(q), _p(sc), _p(mean), _p(rstd), _s()), "mmdit_ln_modulate_fwd_mx")
+    return x1, MxAct(q, sc), mean, rstd
+
+
+def swiglu_fwd_mx(gu, hidden):
+    """SwiGLU activation of the bf16 pre-activations (rows, 2 hidden) with the output in MX e4m3 (mmdit_swiglu_fwd_mx)."""
+    rows = gu.shape[0]
+    q, sc = _mx_buffers(rows, hidden, gu.device)
+    check(_lib.lib().mmdit_swiglu_fwd_mx(_p(_c(gu)), _dt(gu), rows, hidden, _p(q), _p(sc), _s()), "mmdit_swiglu_fwd_mx")
+    return MxAct(q, sc)
+
+
+def attn_fwd_mx(Q, K, V, n_img, scale):
+    """Flash attention forward with the head-merged outputs in MX e4m3 (mmdit_attn_fwd_mx): returns (MxAct (B*N, H*64), MxAct (B*M, H*64) or None)."""
+    B, H, S, hd = Q.shape
+    n_txt = S - n_img
+    qx, sx = _mx_buffers(B * n_img, H * hd, Q.device)
+    qc, scc = _mx_buffers(B * n_txt, H * hd, Q.device) if n_txt else (None, None)
+    check(_lib.lib().mmdit_attn_fwd_mx(_p(Q), _p(K), _p(V), B, H, S, n_img, float(scale), _p(qx), _p(qc), _p(sx), _p(scc), _s()), "mmdit_attn_fwd_mx")
+    return MxAct(qx, sx), (MxAct(qc, scc) if n_txt else None)
+
+
 def quant_mxfp8(x):
     """MX (OCP microscaling) e4m3 quantisation of a row-major 2-D operand: returns (q: float8_e4m3fn like x, scales: uint8 E8M0 block
     scales in the GEMM's layout [K/64][rows][2], 512 spare bytes behind them) -- mmdit_mxfp8_quantize; pass scale_mode=1 to gemm()."""

@@ -187,6 +187,14 @@ def test_mxfp8_mode_vs_mx_oracle(cname, h, w):
             with torch.enable_grad():
                 net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())        # inference only
         vomx = O.forward(sd, O.OracleConfig(**CFGS[cname], attn_core="flash_bf16", gemm="mxfp8"), x.clone(), t, c.clone(), cp.clone())
+        # the producers emit MX directly (no quantise passes): bit-identical to the forward with the passes in front of the GEMMs
+        from sd3_amd import engine
+        fuse, engine._MX_FUSE = engine._MX_FUSE, False
+        try:
+            v_mx_unfused = net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())
+        finally:
+            engine._MX_FUSE = fuse
+        assert fuse and torch.equal(v_mx, v_mx_unfused)
     net.set_precision("fast")
     rmx, rmx16, r816 = rel(v_mx, vomx), rel(v_mx, v_fast), rel(v_fp8, v_fast)
     print(f"[mxfp8] {cname}: HIP mxfp8 vs MX oracle {rmx:.3e}; HIP mxfp8 vs HIP bf16 {rmx16:.3e}; HIP per-tensor fp8 vs HIP bf16 {r816:.3e}")

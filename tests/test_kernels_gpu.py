@@ -542,6 +542,42 @@ def test_gemm_mxfp8_swiglu_epilogue(ops):
     assert rel(y.float(), ref) < 6e-3
 
 
+def test_mx_producers_match_bf16_output_plus_quantise_pass(ops):
+    """The MX-producing variants of adaLN (plain and with the pending gated residual), SwiGLU and attention forward emit exactly
+    the codes and scale bytes that their bf16 outputs followed by mmdit_mxfp8_quantize give (the out-projection / QKV / MLP GEMMs
+    of the "mxfp8" mode then run without quantise passes)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, N, d, hid = 4, 64, 256, 512
+    rows = B * N
+    x = torch.randn((rows, d), generator=g, device="cuda") * 3
+    sc, sh = torch.randn((B, d), generator=g, device="cuda") * 0.3, torch.randn((B, d), generator=g, device="cuda") * 0.3
+    acc = torch.randn((rows, d), generator=g, device="cuda").to(torch.bfloat16)
+    gate = torch.randn((B, d), generator=g, device="cuda")
+
+    def same(mx, ref_bf16):
+        q, s = ops.quant_mxfp8(ref_bf16)
+        n = s.numel() - 512
+        assert torch.equal(mx.q.view(torch.uint8), q.view(torch.uint8)) and torch.equal(mx.sc[:n], s[:n])
+        assert rel(mx.dequant(), ref_bf16.float()) < 4e-2
+
+    out, mean, rstd = ops.ln_modulate_fwd(x, sc, sh, N, torch.bfloat16)
+    x1, mx, mean2, rstd2 = ops.ln_modulate_fwd_mx(x, sc, sh, N)
+    same(mx, out)
+    assert x1 is x and torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    xr, outr, _, _ = ops.ln_modulate_fwd_res(x, acc, gate, sc, sh, N, torch.bfloat16)
+    xr2, mxr, _, _ = ops.ln_modulate_fwd_mx(x, sc, sh, N, acc=acc, gate=gate)
+    same(mxr, outr)
+    assert torch.equal(xr, xr2)
+    gu = torch.randn((rows, 2 * hid), generator=g, device="cuda").to(torch.bfloat16)
+    same(ops.swiglu_fwd_mx(gu, hid), ops.mlp_act_fwd(gu, hid, False))
+    H, M = 4, 26                                                   # S = 90: ragged tiles; 4 x 26 text rows are a multiple of 8
+    Q, K, V = (torch.randn((B, H, N + M, 64), generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
+    Ox, Oc, _ = ops.attn_fwd(Q, K, V, N, 0.125, 0)
+    mxx, mxc = ops.attn_fwd_mx(Q, K, V, N, 0.125)
+    same(mxx, Ox.view(B * N, H * 64))
+    same(mxc, Oc.view(B * M, H * 64))
+
+
 def test_fp8_delayed_scaling_site(ops):
     """One-pass quantiser with delayed scaling: call k uses margin x amax(call k-1); values above that range saturate at +-448."""
     g = torch.Generator(device="cuda").manual_seed(1)
