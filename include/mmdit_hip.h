@@ -93,12 +93,19 @@ typedef struct {
    *   scale_mode 0 (per-tensor): C = scale_a[0] * scale_b[0] * (A_q B_q^T), then the usual epilogue; scale_*: device pointers to the
    *     fp32 dequantisation scales written by mmdit_fp8_quantize / mmdit_fp8_quantize_delayed (unit block scales in the MFMA).
    *   scale_mode 1 (MX, OCP microscaling): every 32 consecutive K values of a row share one E8M0 scale 2^(e-127); scale_* point to
-   *     the byte tensors written by mmdit_mxfp8_quantize, layout [K/64][rows][2] (rows = M for A, N for B; M % 8 == N % 8 == 0; the
-   *     buffer must extend 512 bytes past its last byte -- tile loads of the last rows read, and ignore, what follows).  The block
-   *     scales are applied by the matrix instruction itself. */
+   *     the byte tensors written by mmdit_mxfp8_quantize (rows = M for A, N for B).  Layout: for every 64-wide
+   *     K half the rows in groups of 128 (rows padded to a multiple of 128), inside a group the byte of (row, half-block h) at
+   *     (row & 31) * 8 + h * 4 + ((row >> 5) & 3): a 256-row tile's scales of one half are one contiguous 512-byte run (one LDS-DMA
+   *     piece), and the bytes of the four 32-row blocks a wave multiplies sit in one dword per lane (op_sel picks the block).  Size
+   *     (K / 64) * rows_pad * 2 + 512 bytes (tile loads of the last rows read, and ignore, what follows).  The block scales are
+   *     applied by the matrix instruction itself. */
   const void* scale_a;
   const void* scale_b;
   int scale_mode;
+  /* MMDIT_ACT_SWIGLU with MX operands only: c_dtype = MMDIT_FP8 and c_scales != NULL make the activation leave as MX e4m3 codes
+   * (C: (M, N/2) bytes, ldc in bytes) + E8M0 block scales (layout / size as scale_mode 1 for an (M, N/2) operand), so that the
+   * down-projection GEMM reads it without a quantise pass; aux must be NULL (inference). */
+  void* c_scales;
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 /* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,
@@ -122,21 +129,20 @@ int mmdit_fp8_quantize(const void* x, int x_dtype, int64_t n, const float* amax,
  * state: 4 floats {amax ring [3], dequantisation scale (output)}; phase = call counter of the call site (the caller initialises
  * state[phase % 3] with a two-pass mmdit_fp8_amax before the first call). */
 int mmdit_fp8_quantize_delayed(const void* x, int x_dtype, int64_t n, float* state, int phase, float margin, void* q_fp8, mmdit_stream_t stream);
-/* MX (OCP microscaling) e4m3 quantisation of a row-major operand x[rows][K] (leading dimension ldx, K % 64 == 0, rows % 8 == 0):
+/* MX (OCP microscaling) e4m3 quantisation of a row-major operand x[rows][K] (leading dimension ldx, K % 64 == 0):
  * one pass, no state.  Every 32 consecutive K values share the smallest E8M0 scale 2^e with amax / 2^e <= 448 (e = floor(log2 amax) - 8,
- * or one more when the mantissa of amax exceeds 1.75; an all-zero block gets 2^-127); q[rows][K] = saturate_e4m3(x / scale), scales[K/64][rows][2] as mmdit_gemm_args.scale_mode 1 reads them
- * (allocate (K/32) * rows + 512 bytes).  Replaces the per-tensor amax / delayed-scaling passes in front of an fp8 GEMM
+ * or one more when the mantissa of amax exceeds 1.75; an all-zero block gets 2^-127); q[rows][K] = saturate_e4m3(x / scale), scales in the layout mmdit_gemm_args.scale_mode 1 reads
+ * (allocate (K / 64) * rows_pad128 * 2 + 512 bytes).  Replaces the per-tensor amax / delayed-scaling passes in front of an fp8 GEMM
  * (reference: none -- the reference runs bf16 autocast; BASELINE.json config 5 asks for an fp8 inference path). */
 int mmdit_mxfp8_quantize(const void* x, int x_dtype, int rows, int K, int64_t ldx, void* q_fp8, void* scales_e8m0, mmdit_stream_t stream);
 /* MX-producing variants of the three kernels whose outputs feed the fp8 GEMMs of a block (inference, "mxfp8" precision): the
- * activation leaves its producer as e4m3 codes + E8M0 block scales (layout of mmdit_gemm_args.scale_mode 1, buffers of
- * (K/32) * rows + 512 bytes), bit-identical to the bf16 output followed by mmdit_mxfp8_quantize -- no quantise pass in front of the
- * QKV / out-projection / MLP GEMMs.  rows % 8 == 0 everywhere.
+ * activation leaves its producer as e4m3 codes + E8M0 block scales (layout and size as for mmdit_gemm_args.scale_mode 1), bit-identical to the bf16 output followed by mmdit_mxfp8_quantize -- no quantise pass in front of the
+ * QKV / out-projection / MLP GEMMs.
  *   mmdit_ln_modulate_fwd_mx: adaLN (Norm.py:16-22), optionally with the pending gated residual update of mmdit_ln_modulate_fwd_res
  *     (acc != NULL: bf16 acc, writes x_out); d % 64 == 0.
  *   mmdit_swiglu_fwd_mx: SwiGLU activation of the bf16 pre-activations [g | u] (MLP.py:25-40); hidden % 64 == 0.
  *   mmdit_attn_fwd_mx: flash attention forward (mode 0 of mmdit_attn_fwd) writing Ox / Oc as e4m3 (B, tokens, heads * 64) with scales
- *     [heads][B * tokens][2]; no lse (inference). */
+ *     in that layout (K = heads * 64); no lse (inference). */
 int mmdit_ln_modulate_fwd_mx(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, float* x_out,
                              const float* scale, const float* shift, int64_t ld_mod, int rows, int d, int rows_per_batch,
                              void* q_fp8, void* scales_e8m0, float* mean, float* rstd, mmdit_stream_t stream);

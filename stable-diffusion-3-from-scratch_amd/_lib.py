@@ -35,7 +35,7 @@ class GemmArgs(ctypes.Structure):
         ("split_k", _i),
         ("stream_k", _i),
         ("conv_mode", _i), ("conv_H", _i), ("conv_W", _i), ("conv_C", _i),
-        ("scale_a", _vp), ("scale_b", _vp), ("scale_mode", _i),
+        ("scale_a", _vp), ("scale_b", _vp), ("scale_mode", _i), ("c_scales", _vp),
     ]
 
 

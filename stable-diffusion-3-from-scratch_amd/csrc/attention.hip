@@ -311,7 +311,7 @@ __device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int rb, int h8, i
 // DBG (ablation builds, tools/probes/attn_ablate.py): 1 no exponentials (p = s), 2 no P V MFMAs, 4 no K Q^T MFMAs, 8 no LDS fragment reads
 // (constant operands), 16 no per-tile wait / barrier / DMA, 32 no rescale / row sums
 // MXO (fp8 inference): the output leaves as MX e4m3 -- codes in place of the bf16 rows (same (B, tokens, H * 64) geometry, one byte per
-// feature) plus E8M0 block scales in the GEMM's layout [H][rows][2] (a head's 64 features are two 32-blocks) -- so the out-projection
+// feature) plus E8M0 block scales in the GEMM's layout (mx_scale_index; a head's 64 features are two 32-blocks) -- so the out-projection
 // GEMM needs no quantise pass; bit-identical to the bf16 output followed by mmdit_mxfp8_quantize.
 template <int DBG = 0, bool MXO = false>
 __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
           const int64_t tok = img ? b * n_img + qq : b * n_txt + (qq - n_img);
           unsigned char* dst = (unsigned char*)(img ? Ox : Oc) + tok * D + h * HD + rc * 8;
           *(uint2*)dst = make_uint2(mx_pack4(v, inv), mx_pack4(v + 4, inv));
-          if ((rc & 3) == 0) (img ? scx : scc)[((int64_t)h * (BH / H) * (img ? n_img : n_txt) + tok) * 2 + (rc >> 2)] = (unsigned char)(ex + 127);
+          if ((rc & 3) == 0) (img ? scx : scc)[mx_scale_index((int)tok, h * 2 + (rc >> 2), (BH / H) * (img ? n_img : n_txt))] = (unsigned char)(ex + 127);
         }
       } else if (qq < S) {
         bf16_t* dst = qq < n_img ? Ox + ((b * n_img + qq) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (qq - n_img)) * (int64_t)D + h * HD);
@@ -1208,7 +1208,6 @@ extern "C" int mmdit_attn_fwd_mx(const void* Q, const void* K, const void* V, in
                                  void* Ox_fp8, void* Oc_fp8, void* scales_x, void* scales_c, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(Q && K && V && Ox_fp8 && scales_x && batch > 0 && heads > 0 && S > 0 && n_img > 0 && n_img <= S);
   MMDIT_CHECK_ARG((Oc_fp8 && scales_c) || n_img == S);
-  MMDIT_CHECK_ARG((batch * n_img) % 8 == 0 && (batch * (S - n_img)) % 8 == 0);
   hipLaunchKernelGGL((attn_fwd_dma_kernel<0, true>), dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox_fp8, (bf16_t*)Oc_fp8, nullptr, (unsigned char*)scales_x, (unsigned char*)scales_c);
   return mmdit_launch_status();

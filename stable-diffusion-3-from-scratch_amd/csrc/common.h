@@ -99,6 +99,14 @@ __device__ __forceinline__ unsigned mx_pack4(const float* v, float inv) {
   pk = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, pk, true);
   return (unsigned)pk;
 }
+// Scale byte of (row, 32-block blk of K) in the layout the GEMM reads (mmdit_gemm_args.scale_mode 1): for every 64-wide K half the
+// rows in groups of 128, inside a group the byte of (row, half-block h = blk & 1) at (row & 31) * 8 + h * 4 + ((row >> 5) & 3) --
+// so the E8M0 bytes of the four 32-row blocks a wave's fragments cover sit in ONE dword per lane (selected by op_sel in the MFMA).
+// rows are padded to a multiple of 128: buffer = (K / 64) * rows_pad * 2 + 512 bytes.
+__device__ __forceinline__ int64_t mx_scale_index(int row, int blk, int rows) {
+  const int64_t rows_pad = ((int64_t)rows + 127) & ~(int64_t)127;
+  return ((int64_t)(blk >> 1) * rows_pad + (row & ~127)) * 2 + (row & 31) * 8 + (blk & 1) * 4 + ((row >> 5) & 3);
+}
 // transpose read: lane gets 4 bf16 = column (lane&15) of the 4x16 block whose rows are addressed by the 16-lane group
 __device__ __forceinline__ s16x4 lds_tr16(const void* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p)); }
 

@@ -233,7 +233,7 @@ int check_problem(const mmdit_gemm_args* a) {
   MMDIT_CHECK_ARG(a->A && a->B && a->C);
   MMDIT_CHECK_ARG(a->M > 0 && a->N > 0 && a->K > 0 && a->N % 4 == 0);
   const int esa = a->a_dtype == MMDIT_F32 ? 4 : a->a_dtype == MMDIT_FP8 ? 1 : 2, esb = a->b_dtype == MMDIT_F32 ? 4 : a->b_dtype == MMDIT_FP8 ? 1 : 2, esc = a->c_dtype == MMDIT_F32 ? 4 : 2;
-  MMDIT_CHECK_ARG(a->c_dtype == MMDIT_F32 || a->c_dtype == MMDIT_BF16);
+  MMDIT_CHECK_ARG(a->c_dtype == MMDIT_F32 || a->c_dtype == MMDIT_BF16 || (a->c_dtype == MMDIT_FP8 && a->act == MMDIT_ACT_SWIGLU && a->c_scales));   // (FP8: MX output of the SwiGLU epilogue)
   MMDIT_CHECK_ARG(aligned16(a->A) && aligned16(a->B) && ((uintptr_t)a->C & (4 * esc - 1)) == 0);
   MMDIT_CHECK_ARG((a->lda * esa) % 16 == 0 && (a->ldb * esb) % 16 == 0 && a->ldc % 4 == 0);
   if (a->a_kmajor) { MMDIT_CHECK_ARG(a->M % 8 == 0 && a->lda >= a->M); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->lda >= a->K); }
@@ -257,16 +257,6 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
   static const char* force_epi = getenv("MMDIT_GEMM_CFG_EPI");   // experiments: tile configuration of the gated-residual (fp32 C) launches only
   if (force_epi && args[0].gate) return atoi(force_epi);
   if (stream_k) return CFG_256x256;   // no quantisation with stream-K: take the fewest bytes per FLOP
-  if (args[0].a_dtype == MMDIT_FP8) {
-    // e4m3 operands halve the L2 -> LDS bytes per FLOP, which is what the 256x256 tile buys with bf16 operands; measured
-    // (tools/probes/fp8_bench.py, M = 26 240): 128x128 tiles win up to K = 4096 (w12 216 vs 247 us, qkv 96 vs 101 us), 256x256 only
-    // on long reductions (8192^3: 566 vs 668 us).  The MX variant of the 256x256 kernel spills accumulators inside its K loop
-    // (128 accumulators + 48 fragment + scale registers do not fit 256 VGPRs: 3x slower) and is not selected.
-    int kmax = 0;
-    for (int i = 0; i < count; i++) kmax = args[i].K > kmax ? args[i].K : kmax;
-    if (args[0].scale_mode == 1 || kmax <= 4096) return CFG_128x128;
-    return CFG_256x256;
-  }
   // Wave quantisation decides (measured, tools/gemm_bench.py): a "round" of 128x128 tiles (2 workgroups per CU)
   // costs 1.0, a round of 256x256 tiles (1 per CU, 4x the FLOPs each) 1.58.
   long t128 = 0, t256 = 0;
@@ -274,7 +264,10 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
     t128 += (long)((args[i].M + 127) / 128) * ((args[i].N + 127) / 128);
     t256 += (long)((args[i].M + 255) / 256) * ((args[i].N + 255) / 256);
   }
-  const double c128 = (double)((t128 * split_k + 511) / 512), c256 = 1.58 * (double)((t256 * split_k + 255) / 256);
+  // (e4m3 operands: a 256x256 round costs 1.67 rounds of 128x128 tiles -- tools/probes/fp8_bench.py: qkv 80 vs 96 us, w12 190 vs 226 us
+  // in favour of 256x256, out-proj / w3 (N = 768) 37 vs 39 us, 98 vs 107 us in favour of 128x128)
+  const double r256 = args[0].a_dtype == MMDIT_FP8 ? 1.67 : 1.58;
+  const double c128 = (double)((t128 * split_k + 511) / 512), c256 = r256 * (double)((t256 * split_k + 255) / 256);
   if (lean_ok) {
     // 320x256 tiles (lean kernel): a round costs 1.25x a 256x256 round (tile area); MMDiT-B's N = 768 GEMMs at batch 64 fit ONE round
     long t320 = 0;
@@ -317,7 +310,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     if (a->aux) { MMDIT_CHECK_ARG(aux_dt < 0 || aux_dt == a->aux_dtype); aux_dt = a->aux_dtype; }
     MMDIT_CHECK_ARG((a->split_k > 1 ? a->split_k : 1) == split_k);
     if (fp8) MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && a->K % bk == 0 && a->scale_a && a->scale_b && !a->conv_mode && a->scale_mode == a0->scale_mode &&
-                             (a->scale_mode == 0 || (a->scale_mode == 1 && a->M % 8 == 0 && a->N % 8 == 0 && aligned16(a->scale_a) && aligned16(a->scale_b))));
+                             (a->scale_mode == 0 || (a->scale_mode == 1 && aligned16(a->scale_a) && aligned16(a->scale_b))));
     if (a->K % bk != 0) dma = false;
     if (a->a_kmajor && a->M < 8) dma = false;
     if (a->b_kmajor && a->N < 8) dma = false;
@@ -344,7 +337,9 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     if (!dma) return MMDIT_ERR_SHAPE;
     for (int i = 0; i < count; i++) {
       const mmdit_gemm_args* a = &args[i];
-      MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && a->c_dtype == MMDIT_BF16 && (!a->aux || a->aux_dtype == MMDIT_BF16) && !a->gate && !a->residual &&
+      // (c_dtype FP8: the activation leaves as MX e4m3 codes + c_scales -- MX operands, no pre-activation output)
+      MMDIT_CHECK_ARG(a->c_dtype == MMDIT_BF16 || (a->c_dtype == MMDIT_FP8 && a->c_scales && !a->aux && fp8 && a->scale_mode == 1 && a->c_dtype == a0->c_dtype));
+      MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && (!a->aux || a->aux_dtype == MMDIT_BF16) && !a->gate && !a->residual &&
                       !a->accumulate && split_k == 1 && !a->stream_k && !a->conv_mode);
       if (a->N % 256 != 0) return MMDIT_ERR_SHAPE;
       MMDIT_CHECK_ARG(a->ldc >= a->N / 2 && a->ldc % 8 == 0 && aligned16(a->C));
@@ -395,7 +390,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     p.tiles_m = (a->M + bm - 1) / bm;
     p.tile_start = tiles;
     p.nk = a->K / bk;
-    p.scale_a = (const float*)a->scale_a; p.scale_b = (const float*)a->scale_b;
+    p.scale_a = (const float*)a->scale_a; p.scale_b = (const float*)a->scale_b; p.c_scales = (unsigned char*)a->c_scales;
     p.unit_start = units;
     tiles += p.tiles_n * p.tiles_m;
     units += p.tiles_n * p.tiles_m * p.nk;
@@ -453,7 +448,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   }
   static const bool no_persist = getenv("MMDIT_GEMM_NO_PERSIST") != nullptr;
   gp.persistent = !no_persist;
-  if (aux_dt < 0) aux_dt = a0->c_dtype;
+  if (aux_dt < 0) aux_dt = a0->c_dtype == MMDIT_FP8 ? MMDIT_BF16 : a0->c_dtype;
   gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = tail_split; gp.full_tiles = full_tiles;
   static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation bits (tools/gemm_ablate.py): 2 = operand stream only (no LDS reads / MFMA), 8 = no epilogue, 64 = no bf16 fast epilogue
   gp.debug = debug_env ? atoi(debug_env) : 0;

@@ -19,7 +19,8 @@ struct Problem {
   // implicit-GEMM 3x3 convolution (conv_mode != 0): A is a zero-bordered NHWC bf16 tensor (batch, cHp, cWp, cC); output row
   // m = (b, yo, xo) reads pixel (s*yo + kh + o, s*xo + kw + o) for K index (kh*3 + kw)*cC + c  (mode 1: s=1, o=0; mode 2: s=2, o=1)
   int conv_mode, cHo, cWo, cHp, cWp, cC;
-  const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (device scalars), C = sa*sb*(A_q B_q^T); MX mode: E8M0 bytes [K/64][rows][2]
+  const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (device scalars), C = sa*sb*(A_q B_q^T); MX mode: E8M0 bytes (mx_scale_index)
+  unsigned char* c_scales;                      // SwiGLU epilogue with an MX e4m3 output: E8M0 scales of C (C then holds e4m3 codes)
 };
 struct GroupParams {
   Problem p[MAXG];

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   constexpr int ESZ = FP8 ? 1 : 2, KSTEPS = FP8 ? 1 : 2;   // MFMA k-steps per half
   using frag_t = typename std::conditional<(FP8 != 0), i32x8, bf16x8>::type;
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
-  constexpr int SCB = MX ? 1024 : 0;                           // fp8: E8M0 block scales of the half (MX mode), [A rows x 2 | B rows x 2] bytes
+  constexpr int SCB = MX ? 2048 : 0;                           // MX: E8M0 block scales of the half, A rows at +0, B rows at +1024 (layout: mx_scale_index)
   constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB + SCB;   // bytes of one ring slot
   constexpr int PA = TBM / 16 / NW, PB = TBN / 16 / NW, PP = PA + PB;   // 1-KiB DMA pieces per wave and half
   constexpr int DSTRIDE = (2 * MI) / PP > 0 ? (2 * MI) / PP : 1;   // bf16: MFMA rows between two pieces
@@ -79,13 +79,15 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   const char* sa = nullptr;
   const char* sb = nullptr;
   int64_t stepa = 0, stepb = 0;
-  // MX mode (fp8 operands with E8M0 block scales, gp.mx): one extra 1-KiB DMA piece per half, issued by wave 0 -- lanes 0..31 fetch
-  // the A tile's scale bytes of the half (scale layout [K/64][rows][2]: 2 bytes per row and half, rows contiguous), lanes 32..63
-  // the B tile's; per-lane 64-bit source pointer, advanced by rows * 2 bytes per half
+  // MX mode (fp8 operands with E8M0 block scales): two extra DMA pieces per half, issued by wave 0 -- the A tile's and the B tile's
+  // scale bytes of the half (TBM * 2 resp. TBN * 2 contiguous bytes of the [K/64][rows_pad][..] tensors; the lanes beyond that
+  // re-read the last 16 bytes).  Wave-uniform bases in SGPRs, advanced by rows_pad * 2 bytes per half.
   constexpr bool mx = MX;
   const bool mx0 = MX && wave == 0;
-  const char* psc = nullptr;
-  int64_t pstep = 0;
+  const char* ssa = nullptr;
+  const char* ssb = nullptr;
+  int64_t sstepa = 0, sstepb = 0;
+  uint32_t vsb = 0;   // per-lane byte offset of the B scale piece (SwiGLU: two 256-byte runs, gate and up rows)
   int cseg = 0, cseg_len = 0;      // implicit-GEMM convolution: halves left in / per kernel row (3 taps x cC/32 halves are contiguous)
   int64_t crow_jump = 0;           // extra bytes when the K index moves to the next kernel row
   auto cursor_setup = [&]() {
@@ -107,20 +109,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     sa = (const char*)q.A + ch * stepa;
     sb = (const char*)q.B + ch * stepb;
     if constexpr (MX) {
-      {
-        const int l = lane & 31;
-        if (lane < 32) {
-          pstep = (int64_t)q.M * 2;
-          psc = (const char*)q.scale_a + (int64_t)cit.tm * TBM * 2 + (l * 16 < TBM * 2 ? l * 16 : TBM * 2 - 16);
-        } else {
-          pstep = (int64_t)q.N * 2;
-          int off = cit.tn * TBN * 2 + (l * 16 < TBN * 2 ? l * 16 : TBN * 2 - 16);
-          if constexpr (SWIGLU)   // gate rows [128 tn, +128) then up rows [h + 128 tn, +128) of the packed weight: two 256-byte runs
-            off = ((l < 16 ? 0 : (q.N >> 1)) + cit.tn * 128) * 2 + (l & 15) * 16;
-          psc = (const char*)q.scale_b + off;
-        }
-        psc += ch * pstep;
-      }
+      sstepa = (((int64_t)q.M + 127) & ~(int64_t)127) * 2;
+      sstepb = (((int64_t)q.N + 127) & ~(int64_t)127) * 2;
+      ssa = (const char*)q.scale_a + ch * sstepa + (int64_t)cit.tm * TBM * 2;
+      ssb = (const char*)q.scale_b + ch * sstepb + (SWIGLU ? 0 : (int64_t)cit.tn * TBN * 2);
+      if constexpr (SWIGLU) vsb = (uint32_t)(((lane & 16 ? (q.N >> 1) : 0) + cit.tn * 128) * 2 + (lane & 15) * 16);   // gate rows [128 tn, +128), up rows [h + 128 tn, +128)
+      else vsb = (uint32_t)(lane * 16 < TBN * 2 ? lane * 16 : TBN * 2 - 16);
     }
     cseg = 0;
     if (!A_KM && q.conv_mode) {
@@ -139,7 +133,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       ch++;
       sa += stepa;
       sb += stepb;
-      if constexpr (MX) psc += pstep;
+      if constexpr (MX) { ssa += sstepa; ssb += sstepb; }
       if (cseg && --cseg == 0) {   // convolution: next kernel row
         sa += crow_jump;
         cseg = cseg_len;
@@ -163,7 +157,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   };
   auto issue_scales = [&](int slot) {         // MX mode, wave 0: the scale bytes of the cursor's half
     if constexpr (MX)
-      if (mx0) glds16p(psc, lds0 + slot * H + HA + HB);
+      if (mx0) {
+        const uint32_t dst = lds0 + slot * H + HA + HB;
+        glds16((uint32_t)(lane * 16 < TBM * 2 ? lane * 16 : TBM * 2 - 16), ssa, dst);
+        glds16(vsb, ssb, dst + 1024);
+      }
   };
 
   f32x16 acc[MI][NJ];
@@ -213,16 +211,23 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   // of the NEXT half (which half_sync made visible one half early), so no half starts with an exposed LDS burst.
   // transposed product: acc[i][j] = (B_j A_i^T) -> rows = n, lanes = m
   frag_t a[MI], b[2][NJ];
-  int sca[MI], scb[NJ];   // fp8: E8M0 block scale of this lane's 32 K bytes per fragment (127 = 1.0 outside MX mode)
-  auto ldSA = [&](const char* slot, int i) -> int {
-    if constexpr (!MX) return 127;
-    return *LDS_PTR(const unsigned char, slot + HA + HB + (wm * (MI * 32) + i * 32 + (lane & 31)) * 2 + (lane >> 5));
+  // MX: the E8M0 bytes of this lane's 32 K bytes, for all of the wave's A row blocks in ONE register (the layout puts the four
+  // 32-row blocks of a 128-row group next to each other; op_sel picks the block in the MFMA), likewise for B.  Per-tensor mode: 1.0
+  // (E8M0 127) in every byte.
+  constexpr int SCBN = SWIGLU ? 2 : 1;
+  int sca = 0x7f7f7f7f, scb[SCBN] = {0x7f7f7f7f};   // (unit scales in every byte: op_sel picks a byte)
+  auto ldSA = [&](const char* slot) -> int {
+    if constexpr (!MX) return 0x7f7f7f7f;
+    const char* p = slot + HA + HB + ((wm * MI) >> 2) * 256 + (lane & 31) * 8 + (lane >> 5) * 4 + ((wm * MI) & 3);
+    if constexpr (MI == 4) return *LDS_PTR(const int, p);
+    else return *LDS_PTR(const unsigned short, p);
   };
   auto ldSB = [&](const char* slot, int j) -> int {
-    const int row = SWIGLU ? j * 128 + wn * 32 + (lane & 31) : wn * (NJ * 32) + j * 32 + (lane & 31);
-    if constexpr (!MX) return 127;
-    return *LDS_PTR(const unsigned char, slot + HA + HB + 512 + row * 2 + (lane >> 5));
+    if constexpr (!MX) return 0x7f7f7f7f;
+    if constexpr (SWIGLU) return *LDS_PTR(const unsigned char, slot + HA + HB + 1024 + j * 256 + (lane & 31) * 8 + (lane >> 5) * 4 + wn);
+    else return *LDS_PTR(const unsigned short, slot + HA + HB + 1024 + ((wn * NJ) >> 2) * 256 + (lane & 31) * 8 + (lane >> 5) * 4 + ((wn * NJ) & 3));
   };
+  static_assert(!MX || ((MI == 4 || MI == 2) && NJ == 2), "scale packing");
   auto ldA = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, lane); else return load_frag_h<A_KM, TBM>(t, r0, ks, lane); };
   auto ldB = [&](const char* t, int r0, int ks) -> frag_t { if constexpr (FP8) return load_frag8(t, r0, lane); else return load_frag_h<B_KM, TBN>(t, r0, ks, lane); };
   // one K half: multiply slot done&3 while the PP pieces of the cursor's half go into slot issued&3 (= (done-1)&3,
@@ -230,7 +235,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   auto half_sync = [&]() {
     // exactly RING-1 halves are in flight here: the current half and the next one have landed once only the pieces of
     // the RING-3 youngest halves may still be outstanding (loads retire in order; stores only make the wait conservative)
-    if (MX && mx0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * (PP + 1)) : "memory");   // (wave 0 also carries the scale piece)
+    if (MX && mx0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * (PP + 2)) : "memory");   // (wave 0 also carries the two scale pieces)
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * PP) : "memory");
     __builtin_amdgcn_s_barrier();   // everyone's pieces landed; everyone left half done-1, whose slot the DMA below refills
   };
@@ -243,25 +248,34 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
     const char* na = smem + nslot * H;   // (after the last half of the stream: read, never used)
     const char* nb = na + HA;
     if constexpr (FP8) {
-      // One 64-wide k-step per half.  B-fragment-major order with single-buffered fragments (32 K bytes = 8 VGPRs each: a second B
-      // set would not fit next to the 128 accumulators): b[0][j] is reloaded -- from the next slot -- behind the last MFMA of its
-      // column block, a[i] behind the last column block's MFMA of its row block, so every ds_read has at least MI MFMAs of cover.
-      constexpr int S = (MI * NJ) / PP > 0 ? (MI * NJ) / PP : 1;
+      // fp8 (one 64-wide k-step per half): fragments are NOT carried from half to half.  With 32-byte fragments the carried (in
+      // place reloaded) registers come out of the compiler as two sets plus copies (loop phis of 8-register tuples built from two
+      // ds_read_b128 are not coalesced): 128 accumulators + 2 x 48 spill accumulators inside the K loop once the MX scale
+      // registers are added (3x slower), and even without them the copies cost (per-tensor w12 247 us).  Instead every half loads
+      // its own fragments: both B fragments and the first A fragment up front (their latency is covered by the other wave of the
+      // SIMD), the next A fragment under the MFMAs of the current one -- 32 fragment registers live, no phis (w12 190 us).
       static_assert(!FP8 || MI * NJ >= PP, "piece schedule (fp8)");
+      constexpr int S = (MI * NJ) / PP > 0 ? (MI * NJ) / PP : 1;
+      frag_t bq[NJ], acur = ldA(ta, wm * (MI * 32), 0), anxt;
 #pragma unroll
-      for (int j = 0; j < NJ; j++) {
+      for (int j = 0; j < NJ; j++) bq[j] = ldB(tb, wn * (NJ * 32) + j * 32, 0);
+      sca = ldSA(ta);
 #pragma unroll
-        for (int i = 0; i < MI; i++) {
+      for (int j = 0; j < SCBN; j++) scb[j] = ldSB(ta, j);
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        if (i + 1 < MI) anxt = ldA(ta, wm * (MI * 32) + (i + 1) * 32, 0);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
           __builtin_amdgcn_sched_barrier(0);
-          if constexpr (FP8) acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b[0][j], a[i], acc[i][j], 0, 0, 0, scb[j], 0, sca[i]);
-          if (j == NJ - 1) { a[i] = ldA(na, wm * (MI * 32) + i * 32, 0); sca[i] = ldSA(na, i); }
-          if (i == MI - 1) { b[0][j] = ldB(nb, wn * (NJ * 32) + j * 32, 0); scb[j] = ldSB(na, j); }
-          const int q = j * MI + i;   // compile-time after unrolling
+          acc[i][j] = mx_mfma(bq[j], acur, acc[i][j], SWIGLU ? 0 : j, scb[SWIGLU ? j : 0], i, sca);
+          const int q = i * NJ + j;   // compile-time after unrolling
           if (q % S == 0 && q / S < PP) {
             __builtin_amdgcn_sched_barrier(0);
             issue_piece(q / S, dslot);
           }
         }
+        acur = anxt;
       }
       __builtin_amdgcn_sched_barrier(0);
       issue_scales(dslot);
@@ -323,10 +337,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
         if (first) {
           first = false;
           const char* ta = smem;
+          if constexpr (!FP8) {
 #pragma unroll
-          for (int j = 0; j < NJ; j++) { b[0][j] = ldB(ta + HA, wn * (NJ * 32) + j * 32, 0); if constexpr (FP8) scb[j] = ldSB(ta, j); }
+            for (int j = 0; j < NJ; j++) b[0][j] = ldB(ta + HA, wn * (NJ * 32) + j * 32, 0);
 #pragma unroll
-          for (int i = 0; i < MI; i++) { a[i] = ldA(ta, wm * (MI * 32) + i * 32, 0); if constexpr (FP8) sca[i] = ldSA(ta, i); }
+            for (int i = 0; i < MI; i++) a[i] = ldA(ta, wm * (MI * 32) + i * 32, 0);
+          }
         }
         half_body();
 #pragma unroll 1
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
 
 template <int WM, int WN, int MI, int NJ, bool A_KM, bool B_KM, typename TC, typename TAUX, int FP8 = 0, bool SWIGLU = false>
 int launch_cfg(const GroupParams& gp, hipStream_t s) {
-  constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64 + (FP8 == 2 ? 1024 : 0);
+  constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64 + (FP8 == 2 ? 2048 : 0);
   constexpr int smem = RING * slot + (WM * WN * EP32_WAVE_BYTES <= slot ? 0 : WM * WN * EP32_WAVE_BYTES);
   auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX, FP8, SWIGLU>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
@@ -390,7 +406,7 @@ int by_layout(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t 
 
 int gemm::launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s) {
   if (gp.act == MMDIT_ACT_SWIGLU) {   // packed w12 GEMM with the activation in the epilogue (gemm.hip has checked the rest)
-    if (a_km || b_km || c_dtype != MMDIT_BF16 || aux_dtype != MMDIT_BF16 || cfg != CFG_256x256) return MMDIT_ERR_DTYPE;
+    if (a_km || b_km || (c_dtype != MMDIT_BF16 && !(c_dtype == MMDIT_FP8 && fp8 && gp.mx)) || aux_dtype != MMDIT_BF16 || cfg != CFG_256x256) return MMDIT_ERR_DTYPE;
     if (fp8 && gp.mx) return launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 2, true>(gp, s);
     return fp8 ? launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 1, true>(gp, s) : launch_cfg<2, 4, 4, 2, false, false, bf16_t, bf16_t, 0, true>(gp, s);
   }

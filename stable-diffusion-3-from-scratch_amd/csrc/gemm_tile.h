@@ -72,6 +72,24 @@ __device__ __forceinline__ bf16x8 load_frag_h(const char* tile, int r0, int ks, 
 
 // fp8 (e4m3) row-major half-tile [R][64] (64 B rows, same byte geometry as the bf16 half-tile): the fragment of k-step ks
 // (16 values) is the 16-B piece ks of the row, each lane half takes 8 of them -> one ds_read_b64
+// v_mfma_scale_f32_32x32x64_f8f6f4 with the op_sel fields (which byte of each scale register) chosen by loop indices: the
+// builtin wants literals, so the indices go through a switch that folds once the surrounding loops are unrolled.
+template <int OA, int OB>
+__device__ __forceinline__ f32x16 mx_mfma_lit(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, OA, sa, OB, sb);
+}
+__device__ __forceinline__ f32x16 mx_mfma(i32x8 a, i32x8 b, f32x16 c, int oa, int sa, int ob, int sb) {
+  switch (oa * 4 + ob) {
+#define MMDIT_MX_CASE(A, B) case A * 4 + B: return mx_mfma_lit<A, B>(a, b, c, sa, sb);
+    MMDIT_MX_CASE(0, 0) MMDIT_MX_CASE(0, 1) MMDIT_MX_CASE(0, 2) MMDIT_MX_CASE(0, 3)
+    MMDIT_MX_CASE(1, 0) MMDIT_MX_CASE(1, 1) MMDIT_MX_CASE(1, 2) MMDIT_MX_CASE(1, 3)
+    MMDIT_MX_CASE(2, 0) MMDIT_MX_CASE(2, 1) MMDIT_MX_CASE(2, 2) MMDIT_MX_CASE(2, 3)
+    MMDIT_MX_CASE(3, 0) MMDIT_MX_CASE(3, 1) MMDIT_MX_CASE(3, 2)
+#undef MMDIT_MX_CASE
+    default: return mx_mfma_lit<3, 3>(a, b, c, sa, sb);
+  }
+}
+
 // fp8 operand fragment of the 64-wide MX MFMA (v_mfma_scale_f32_32x32x64_f8f6f4).  K layout of the instruction (established with
 // block scales that vary along K, tools/probes/mx_dbg.py): registers 0-3 of lane l hold k = 16 (l >> 5) + [0, 16), registers 4-7
 // k = 32 + 16 (l >> 5) + [0, 16) of row l & 31 -- the 16-byte chunks (l >> 5) and 2 + (l >> 5) of the 64-byte row.  The E8M0 scale
@@ -282,6 +300,31 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (p.c_scales) {
+      // MX output: the wave's 32 hidden indices of a row (16 values in each of the lanes wr, wr + 32) are one block: common scale,
+      // e4m3 codes staged as 32 rows x 32 B, stored 16 B per lane (two lanes per row)
+      float hv[16];
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int e = 0; e < 2; e++) { hv[4 * g + 2 * e] = __builtin_bit_cast(float, pa[g][e] << 16); hv[4 * g + 2 * e + 1] = __builtin_bit_cast(float, pa[g][e] & 0xffff0000u); }
+      float amax = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; e++) amax = fmaxf(amax, fabsf(hv[e]));
+      amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+      float inv;
+      const int ex = mx_exponent(amax, inv);
+#pragma unroll
+      for (int g = 0; g < 4; g++) *LDS_PTR(unsigned, stage + wr * 32 + g * 8 + wc * 4) = mx_pack4(hv + 4 * g, inv);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int r = lane >> 1, row = m0 + wm * (MI * 32) + i * 32 + r;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 32 + (lane & 1) * 16);
+      if (row < p.M) *(u32x4*)((unsigned char*)p.C + (int64_t)row * p.ldc + hc + (lane & 1) * 16) = t;
+      const int myrow = m0 + wm * (MI * 32) + i * 32 + wr;
+      if (wc == 0 && myrow < p.M) p.c_scales[mx_scale_index(myrow, hc >> 5, p.M)] = (unsigned char)(ex + 127);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      continue;
+    }
 #pragma unroll
     for (int g = 0; g < 4; g++) *LDS_PTR(u32x2, stage + wr * 64 + ((g ^ (wr & 3)) << 4) + wc * 8) = pa[g];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

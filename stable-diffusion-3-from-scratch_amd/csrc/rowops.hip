@@ -19,8 +19,6 @@ constexpr float RMS_EPS = FLT_EPSILON;    // nn.RMSNorm(eps=None) on fp32 input
 // stream row is written to xo (it is the next residual input and the x of the backward pass).
 // round to bf16 and back: a fused producer quantises exactly what the unfused path would have stored as bf16 and quantised afterwards
 __device__ __forceinline__ float bf16_round(float x) { return __builtin_bit_cast(float, pack_bf2(x, 0.f) << 16); }
-// scale byte of (row, 32-block blk) in the GEMM's layout [K/64][rows][2]
-__device__ __forceinline__ int64_t mx_scale_index(int row, int blk, int rows) { return ((int64_t)(blk >> 1) * rows + row) * 2 + (blk & 1); }
 
 // MX (TO = unsigned char, d % 32 == 0): the normalised row leaves as e4m3 codes + E8M0 block scales (a 32-block is the 4 values of 8
 // adjacent lanes of one iteration), bit-identical to the bf16 output followed by mmdit_mxfp8_quantize.
@@ -823,7 +821,7 @@ extern "C" int mmdit_ln_modulate_fwd_res(const float* x, const void* acc, int ac
 extern "C" int mmdit_ln_modulate_fwd_mx(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate, float* x_out,
                                         const float* scale, const float* shift, int64_t ld_mod, int rows, int d, int rpb,
                                         void* q_fp8, void* scales_e8m0, float* mean, float* rstd, mmdit_stream_t stream) {
-  MMDIT_CHECK_ARG(x && scale && shift && q_fp8 && scales_e8m0 && mean && rstd && rows > 0 && rows % 8 == 0 && d > 0 && d % 64 == 0 && d <= 4096 && rpb > 0 && ld_mod % 4 == 0);
+  MMDIT_CHECK_ARG(x && scale && shift && q_fp8 && scales_e8m0 && mean && rstd && rows > 0 && d > 0 && d % 64 == 0 && d <= 4096 && rpb > 0 && ld_mod % 4 == 0);
   MMDIT_CHECK_ARG(!acc || (gate && x_out && acc_dtype == MMDIT_BF16 && ld_gate % 4 == 0));
   hipStream_t s = (hipStream_t)stream;
   const int nit = nit_for(d);
@@ -978,7 +976,7 @@ static int mlp_act_bwd(const void* dh, const void* gu, void* dgu, int dtype, int
   return mmdit_launch_status();
 }
 extern "C" int mmdit_swiglu_fwd_mx(const void* gu, int dtype, int rows, int hidden, void* q_fp8, void* scales_e8m0, mmdit_stream_t stream) {
-  MMDIT_CHECK_ARG(gu && q_fp8 && scales_e8m0 && rows > 0 && rows % 8 == 0 && hidden > 0 && hidden % 64 == 0);
+  MMDIT_CHECK_ARG(gu && q_fp8 && scales_e8m0 && rows > 0 && hidden > 0 && hidden % 64 == 0);
   dim3 grid((hidden + 255) / 256, (rows + CO_RCH - 1) / CO_RCH);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == MMDIT_BF16) hipLaunchKernelGGL((mlp_act_fwd_kernel<bf16_t, false, true>), grid, dim3(256), 0, s, (const bf16_t*)gu, (bf16_t*)q_fp8, rows, hidden, (unsigned char*)scales_e8m0);
@@ -1118,7 +1116,7 @@ __global__ __launch_bounds__(256) void mxfp8_quant_kernel(const TI* __restrict__
 }  // namespace
 
 extern "C" int mmdit_mxfp8_quantize(const void* x, int x_dtype, int rows, int K, int64_t ldx, void* q_fp8, void* scales, mmdit_stream_t stream) {
-  MMDIT_CHECK_ARG(x && q_fp8 && scales && rows > 0 && rows % 8 == 0 && K > 0 && K % 64 == 0 && ldx >= K && ldx % 8 == 0);
+  MMDIT_CHECK_ARG(x && q_fp8 && scales && rows > 0 && K > 0 && K % 64 == 0 && ldx >= K && ldx % 8 == 0);
   hipStream_t s = (hipStream_t)stream;
   const int64_t nblk = (int64_t)rows * (K / 32);
   const dim3 grid((unsigned)((nblk + 255) / 256));

@@ -72,8 +72,8 @@ def _to_fp8(m, p):
     if not pre and (A.dtype != BF16 or B.dtype != BF16 or A.shape[1] % 128 or p.get("a_kmajor") or p.get("b_kmajor")):
         return p
     ent, gen = m._q.get(id(B)), getattr(B, "_mmdit_gen", 0)     # (the bf16 copy is refreshed in place: packing.Pack.generation)
-    if m.mx:    # MX: block scales, stateless one-pass quantisation of the activation (rows must be a multiple of 8: scale layout)
-        if not pre and (A.shape[0] % 8 or B.shape[0] % 8 or not A.is_contiguous()):
+    if m.mx:    # MX: block scales, stateless one-pass quantisation of the activation
+        if not pre and not A.is_contiguous():
             return p
         if ent is None or ent[4] != gen:
             qb, sb = ops.quant_mxfp8(B)
@@ -291,8 +291,8 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
         sv.mod = _gemm(m, sv.yp, w.Wmod, out_dtype=F32)
     ms = _mod_views(sv.mod, d, w.last)
     # "mxfp8" inference: the activations that feed the four fp8 GEMM sites leave their producers (adaLN, attention, SwiGLU) as MX e4m3
-    # -- no quantise passes -- when every site of the block is eligible (K % 128, rows % 8: the scale layout; SwiGLU MLPs)
-    mxf = (m.mx and not keep and dev.type == "cuda" and d % 128 == 0 and (B * N) % 8 == 0 and (B * Mt) % 8 == 0 and not w.mlp_x.gelu
+    # -- no quantise passes -- when every site of the block is eligible (K % 128; SwiGLU MLPs)
+    mxf = (m.mx and not keep and dev.type == "cuda" and d % 128 == 0 and not w.mlp_x.gelu
            and w.mlp_x.hidden % 128 == 0 and (w.last or (not w.mlp_c.gelu and w.mlp_c.hidden % 128 == 0)) and _MX_FUSE)
 
     sv.X, sv.ln1x, sv.mu1x, sv.rs1x = _norm(m, X, ms.scale1x, ms.shift1x, N, mx=mxf)
@@ -319,9 +319,12 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     sv.X1, sv.ln2x, sv.mu2x, sv.rs2x = _norm(m, Pending(sv.X, sv.acc_ox, ms.gate1x, N), ms.scale2x, ms.shift2x, N, mx=mxf)
     # SwiGLU in the up-projection's epilogue (bf16 mode, hidden % 128 == 0, K % 64 == 0): the GEMM writes the pre-activations and
     # the activation; otherwise (GELU, parity / fp8 mode, odd sizes) the activation is a row kernel over the GEMM output
-    fuse = _FUSE_SWIGLU and m.fast and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % (128 if m.fp8 else 64) == 0 and not m.mx   # (MX: 128x128 tiles, see gemm.hip pick_dma_cfg -- the fused epilogue needs the 256-column tile)
+    fuse = _FUSE_SWIGLU and m.fast and dev.type == "cuda" and not w.mlp_x.gelu and w.mlp_x.hidden % 128 == 0 and d % (128 if m.fp8 else 64) == 0
 
     def up(xn, mw, rows):
+        if fuse and mxf:     # MX in, MX out: the activation leaves the epilogue as e4m3 codes + block scales (no quantise pass before w3)
+            q, sc = ops._mx_buffers(rows, mw.hidden, dev)
+            return dict(A=xn, B=mw.Wup, bias=mw.bup, act=ops.ACT_SWIGLU, out=q, out_scales=sc)
         if fuse:
             return dict(A=xn, B=mw.Wup, bias=mw.bup, act=ops.ACT_SWIGLU, aux=torch.empty((rows, 2 * mw.hidden), dtype=m.T, device=dev) if keep else None)
         return dict(A=xn, B=mw.Wup, bias=mw.bup, out_dtype=m.T)
@@ -334,6 +337,8 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
         probs.append(up(sv.ln2c, w.mlp_c, B * Mt))
     outs = _group(m, probs, fp8=True)
     pre = [p.get("aux") for p in probs]
+    if fuse and mxf:
+        outs = [ops.MxAct(p["out"], p["out_scales"]) for p in probs]
     if fuse:
         sv.gu_x, sv.h_x = pre[0], outs[0]
     else:

@@ -89,7 +89,7 @@ def torch_dtype(code: int):
 
 # ---------------------------------------------------------------------------------------------
 def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None, scale_a=None, scale_b=None, scale_mode=0):
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None, scale_a=None, scale_b=None, scale_mode=0, out_scales=None):
     """conv = (mode, H, W, C): A is a zero-bordered NHWC bf16 tensor (batch, H+2, W+2, C) -- implicit-GEMM 3x3 convolution."""
     if conv is not None:
         mode, cH, cW, cC = conv
@@ -109,6 +109,8 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     if act == ACT_SWIGLU:   # packed SwiGLU up-projection: out (M, h) = silu(g) * u, aux (M, 2h) = the pre-activations [g | u]
         if (aux is not None and (aux.dtype != torch.bfloat16 or tuple(aux.shape) != (M, N))) or (out is not None and tuple(out.shape) != (M, N // 2)):
             raise RuntimeError("gemm(act=ACT_SWIGLU): aux (optional) is the bf16 (M, 2h) pre-activation buffer, out (M, h)")
+        if (out_scales is not None) != (out is not None and out.dtype == torch.float8_e4m3fn):
+            raise RuntimeError("gemm(act=ACT_SWIGLU): an MX output needs out (float8_e4m3fn) AND out_scales")
         if out is None:
             out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=A.device)
     if out is None:
@@ -119,7 +121,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), (K_ if conv is not None else A.stride(0))
     if conv is not None:
         a.conv_mode, a.conv_H, a.conv_W, a.conv_C = conv
-    a.scale_a, a.scale_b, a.scale_mode = _p(scale_a), _p(scale_b), int(scale_mode)
+    a.scale_a, a.scale_b, a.scale_mode, a.c_scales = _p(scale_a), _p(scale_b), int(scale_mode), _p(out_scales)
     a.B, a.b_dtype, a.b_kmajor, a.ldb = _p(B), _dt(B), int(b_kmajor), B.stride(0)
     a.C, a.c_dtype, a.ldc = _p(out), _dt(out), out.stride(0)
     a.M, a.N, a.K = M, N, K_
@@ -206,12 +208,25 @@ class MxAct:
     def dequant(self):
         """fp32 values (tests)."""
         rows, K = self.q.shape
-        e = self.sc[:(K // 32) * rows].view(K // 64, rows, 2).permute(1, 0, 2).reshape(rows, K // 32).to(torch.int32) - 127
+        e = mx_scales_to_rows(self.sc, rows, K).to(torch.int32) - 127
         return (self.q.float().view(rows, K // 32, 32) * torch.ldexp(torch.ones((), device=self.q.device), e).unsqueeze(-1)).view(rows, K)
 
 
+def mx_scale_bytes(rows, K):
+    """Size of the E8M0 scale buffer of a (rows, K) MX operand: rows padded to 128, 2 bytes per row and 64-wide K half, 512 spare."""
+    return (K // 64) * ((rows + 127) // 128 * 128) * 2 + 512
+
+
+def mx_scales_to_rows(sc, rows, K):
+    """The scale bytes as a (rows, K/32) uint8 tensor (inverse of the GEMM layout: per 64-wide K half the rows in groups of 128, inside
+    a group byte (row & 31) * 8 + h * 4 + ((row >> 5) & 3) for half-block h)."""
+    rp = (rows + 127) // 128 * 128
+    v = sc[:(K // 64) * rp * 2].view(K // 64, rp // 128, 32, 2, 4)          # [k64][group][r31][h][rb]
+    return v.permute(1, 4, 2, 0, 3).reshape(rp, K // 32)[:rows]              # row = group*128 + rb*32 + r31, blk = k64*2 + h
+
+
 def _mx_buffers(rows, K, device):
-    return (torch.empty((rows, K), dtype=torch.float8_e4m3fn, device=device), torch.empty((K // 32) * rows + 512, dtype=torch.uint8, device=device))
+    return (torch.empty((rows, K), dtype=torch.float8_e4m3fn, device=device), torch.empty(mx_scale_bytes(rows, K), dtype=torch.uint8, device=device))
 
 
 def ln_modulate_fwd_mx(x, scale, shift, rows_per_batch, acc=None, gate=None):
@@ -248,10 +263,10 @@ def attn_fwd_mx(Q, K, V, n_img, scale):
 
 def quant_mxfp8(x):
     """MX (OCP microscaling) e4m3 quantisation of a row-major 2-D operand: returns (q: float8_e4m3fn like x, scales: uint8 E8M0 block
-    scales in the GEMM's layout [K/64][rows][2], 512 spare bytes behind them) -- mmdit_mxfp8_quantize; pass scale_mode=1 to gemm()."""
+    scales in the GEMM's layout, see mx_scales_to_rows; 512 spare bytes behind them) -- mmdit_mxfp8_quantize; pass scale_mode=1 to gemm()."""
     rows, K = x.shape
     q = torch.empty((rows, K), dtype=torch.float8_e4m3fn, device=x.device)
-    sc = torch.empty((K // 32) * rows + 512, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(mx_scale_bytes(rows, K), dtype=torch.uint8, device=x.device)
     check(_lib.lib().mmdit_mxfp8_quantize(_p(x), _dt(x), rows, K, x.stride(0), _p(q), _p(sc), _s()), "mmdit_mxfp8_quantize")
     return q, sc
 

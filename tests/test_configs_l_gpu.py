@@ -124,13 +124,13 @@ def test_l_full_size_properties_batch16():
 
 def test_l_sampler_28_steps_bf16_and_fp8_vs_reference_loop(golden_dir):
     """Config 5: the 28-step Euler + CFG sampler at MMDiT-L / 512^2 against the reference's own sample_imgs loop (sampler_l.npz):
-    parity mode < 5e-3, bf16 < 5e-2, fp8 (e4m3 operands, per-tensor scales, delayed activation scaling) < 1.5e-1 and fp8 stays
-    closer to bf16 than that.  (28 steps integrate the per-step velocity error: the bars are ~3x the single-forward bars.)"""
+    parity mode < 5e-3, bf16 < 5e-2, fp8 (e4m3 operands, per-tensor scales, delayed activation scaling) and mxfp8 (MX block scales
+    emitted by the producing kernels) < 1.5e-1 and both stay closer to bf16 than that.  (28 steps integrate the per-step velocity error: the bars are ~3x the single-forward bars.)"""
     gold = np.load(os.path.join(golden_dir, "sampler_l.npz"))
     ref = torch.from_numpy(gold["out"])
     _, th, tp = make_inputs(51, 1, 64, 64, text_scale=30.0)
     out = {}
-    for prec in ("parity", "fast", "fp8"):
+    for prec in ("parity", "fast", "fp8", "mxfp8"):
         net, _ = build("l", prec)
         net.text_encoders = _Enc(th, tp)
         gen = torch.Generator().manual_seed(123)
@@ -139,10 +139,11 @@ def test_l_sampler_28_steps_bf16_and_fp8_vs_reference_loop(golden_dir):
         net.train()
     net.set_precision("fast")
     r = {k: rel(v, ref) for k, v in out.items()}
-    r88 = rel(out["fp8"], out["fast"])
-    print(f"[L sampler, 28 steps] vs reference loop: parity {r['parity']:.3e}, bf16 {r['fast']:.3e}, fp8 {r['fp8']:.3e}; fp8 vs bf16 {r88:.3e}")
+    r88, rmx = rel(out["fp8"], out["fast"]), rel(out["mxfp8"], out["fast"])
+    print(f"[L sampler, 28 steps] vs reference loop: parity {r['parity']:.3e}, bf16 {r['fast']:.3e}, fp8 {r['fp8']:.3e}, mxfp8 {r['mxfp8']:.3e}; "
+          f"fp8 vs bf16 {r88:.3e}, mxfp8 vs bf16 {rmx:.3e}")
     assert all(torch.isfinite(v).all() for v in out.values())
-    assert r["parity"] < 5e-3 and r["fast"] < 5e-2 and r["fp8"] < 1.5e-1 and r88 < 1.5e-1
+    assert r["parity"] < 5e-3 and r["fast"] < 5e-2 and r["fp8"] < 1.5e-1 and r88 < 1.5e-1 and r["mxfp8"] < 1.5e-1 and 1e-4 < rmx < 1.5e-1
 
 
 @pytest.mark.parametrize("cname,h,w", [("xs", 64, 64), ("b", 32, 32)])
@@ -174,8 +175,8 @@ def test_mxfp8_mode_vs_mx_oracle(cname, h, w):
     per-tensor fp8 mode.  Measured with these seeded weights: MX and per-tensor e4m3 sit equally far from the bf16 forward (xs 2.6e-2
     both, B depth 6.7e-2 vs 7.1e-2) -- the activations have no outlier channels for the block scales to rescue -- so the check is
     "not worse" (within 10 %), plus agreement with the MX oracle at the same bars as the per-tensor mode."""
-    x, c, cp = make_inputs(21, 4, h, w, text_scale=30.0)        # batch 4: 4 x 154 text rows are a multiple of 8 (scale layout)
-    t = torch.tensor([0.2, 0.9, 0.5, 0.7])
+    x, c, cp = make_inputs(21, 2, h, w, text_scale=30.0)
+    t = torch.tensor([0.2, 0.9])
     net, sd = build(cname, "fast")
     with torch.no_grad():
         v_fast = net(x.cuda(), t, c.clone().cuda(), cp.clone().cuda())

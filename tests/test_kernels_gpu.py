@@ -496,11 +496,11 @@ def _mx_reference(x):
     e = torch.where(amax > 448.0 * torch.ldexp(torch.ones_like(amax), e), e + 1, e).clamp(-127, 127)     # amax / scale <= 448: nothing saturates
     scale = torch.ldexp(torch.ones_like(amax), e)
     q = (xb / scale).clamp(-448.0, 448.0).to(torch.float8_e4m3fn)
-    sc = (e + 127).to(torch.uint8).reshape(rows, K // 64, 2).permute(1, 0, 2).contiguous().reshape(-1)
+    sc = (e + 127).to(torch.uint8).reshape(rows, K // 32)                  # per (row, 32-block); the device layout is compared through ops.mx_scales_to_rows
     return q.reshape(rows, K).view(torch.uint8), sc, (q.float() * scale).reshape(rows, K)
 
 
-@pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (616, 2304, 768, torch.float32),
+@pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (308, 2304, 768, torch.float32),
                                              (16384, 2304, 768, torch.bfloat16)])
 def test_gemm_mxfp8_operands(ops, M, N, K, out_dtype):
     """MX (block-scaled e4m3) operand GEMM: the quantiser is bit-identical to its torch restatement (codes and E8M0 scales, in the
@@ -517,7 +517,7 @@ def test_gemm_mxfp8_operands(ops, M, N, K, out_dtype):
     qw, sw = ops.quant_mxfp8(W)
     for (q, sc, x) in ((qa, sa, A), (qw, sw, W)):
         q_ref, sc_ref, deq = _mx_reference(x)
-        assert torch.equal(q.view(torch.uint8), q_ref) and torch.equal(sc[:sc_ref.numel()], sc_ref)
+        assert torch.equal(q.view(torch.uint8), q_ref) and torch.equal(ops.mx_scales_to_rows(sc, *x.shape), sc_ref)
         assert rel(deq, x.float()) < 4e-2
     y = ops.gemm(qa, qw, bias=bias, out_dtype=out_dtype, scale_a=sa, scale_b=sw, scale_mode=1)
     ref = _mx_reference(A)[2].double() @ _mx_reference(W)[2].double().t() + bias.double()
@@ -540,6 +540,12 @@ def test_gemm_mxfp8_swiglu_epilogue(ops):
     gu = (_mx_reference(A)[2] @ _mx_reference(W)[2].t() + bias).to(torch.bfloat16).float()
     ref = torch.nn.functional.silu(gu[:, :h]) * gu[:, h:]
     assert rel(y.float(), ref) < 6e-3
+    # MX in, MX out: the same activation leaving the epilogue as e4m3 codes + block scales == quantising the bf16 output afterwards
+    q, sc = ops._mx_buffers(M, h, "cuda")
+    ops.gemm(qa, qw, bias=bias, act=ops.ACT_SWIGLU, scale_a=sa, scale_b=sw, scale_mode=1, out=q, out_scales=sc)
+    q_ref, sc_ref = ops.quant_mxfp8(y)
+    assert torch.equal(q.view(torch.uint8), q_ref.view(torch.uint8))
+    assert torch.equal(ops.mx_scales_to_rows(sc, M, h), ops.mx_scales_to_rows(sc_ref, M, h))
 
 
 def test_mx_producers_match_bf16_output_plus_quantise_pass(ops):
@@ -556,8 +562,8 @@ def test_mx_producers_match_bf16_output_plus_quantise_pass(ops):
 
     def same(mx, ref_bf16):
         q, s = ops.quant_mxfp8(ref_bf16)
-        n = s.numel() - 512
-        assert torch.equal(mx.q.view(torch.uint8), q.view(torch.uint8)) and torch.equal(mx.sc[:n], s[:n])
+        assert torch.equal(mx.q.view(torch.uint8), q.view(torch.uint8))
+        assert torch.equal(ops.mx_scales_to_rows(mx.sc, *q.shape), ops.mx_scales_to_rows(s, *q.shape))
         assert rel(mx.dequant(), ref_bf16.float()) < 4e-2
 
     out, mean, rstd = ops.ln_modulate_fwd(x, sc, sh, N, torch.bfloat16)
@@ -570,7 +576,7 @@ def test_mx_producers_match_bf16_output_plus_quantise_pass(ops):
     assert torch.equal(xr, xr2)
     gu = torch.randn((rows, 2 * hid), generator=g, device="cuda").to(torch.bfloat16)
     same(ops.swiglu_fwd_mx(gu, hid), ops.mlp_act_fwd(gu, hid, False))
-    H, M = 4, 26                                                   # S = 90: ragged tiles; 4 x 26 text rows are a multiple of 8
+    H, M = 4, 27                                                   # S = 91: ragged tiles, 108 text rows (no multiple of 8)
     Q, K, V = (torch.randn((B, H, N + M, 64), generator=g, device="cuda").to(torch.bfloat16) for _ in range(3))
     Ox, Oc, _ = ops.attn_fwd(Q, K, V, N, 0.125, 0)
     mxx, mxc = ops.attn_fwd_mx(Q, K, V, N, 0.125)
