@@ -49,6 +49,21 @@ __device__ __forceinline__ void glds16(uint32_t voff, const char* sbase_, uint32
   asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_dst) : "memory", "m0");
 }
 
+// ---- "wide" row-major tiles (gemm_lean.hip, gemm_wide_kernel): a ring slot holds a 64-wide K step, i.e. 128 contiguous bytes =
+// one whole cache line per operand row (the 32-wide halves above fetch half a line per row and DMA instruction lane group; the
+// LDS-DMA path moves 111 GB/s per CU for 128-byte rows against 78 GB/s for 64-byte rows, tools/probes/glds_rate.hip).
+// A 1-KiB piece is 8 rows x 128 B; LDS row r at r * 128 with its 16-byte chunk p holding global chunk p ^ (r & 7).
+template <int ESZ = 2>
+__device__ __forceinline__ uint32_t wide_voff(int c, int lane, int64_t ld, int row0, int rows) {
+  const int r = 8 * c + (lane >> 3), chunk = (lane & 7) ^ (r & 7);
+  return (uint32_t)((int64_t)min(row0 + r, rows - 1) * ld * ESZ + chunk * 16);
+}
+// fragment of k16-step ks (0..3) of the slot: row r0 + (lane & 31), K elements 16 ks + 8 (lane >> 5) + [0, 8)
+__device__ __forceinline__ bf16x8 load_frag_w(const char* tile, int r0, int ks, int lane) {
+  const int r = r0 + (lane & 31), kp = ks * 2 + (lane >> 5);
+  return *LDS_PTR(const bf16x8, tile + r * 128 + ((kp ^ (r & 7)) << 4));
+}
+
 // the same with a per-lane 64-bit source pointer (sources that do not share a wave-uniform base)
 __device__ __forceinline__ void glds16p(const void* gptr, uint32_t lds_dst_) {
   const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);

@@ -4,6 +4,7 @@ Every function launches on torch's current HIP stream and never synchronises.
 PyTorch is used only to own device memory; all arithmetic happens in libmmdit_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
@@ -155,7 +156,8 @@ def _variant(arr, n, outs):
         ab = "t,t" if a.precision == PREC_BF16 else "f,f"
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
     if plan & 128:
-        return f"gemm_lean_kernel<{_CFG[plan & 15]},{int(bool(a.b_kmajor))}>" + ("+swiglu" if a.act == ACT_SWIGLU else "")
+        kern = "gemm_lean_kernel" if os.environ.get("MMDIT_GEMM_WIDE", "1") == "0" else "gemm_wide_kernel"
+        return f"{kern}<{_CFG[plan & 15]},{int(bool(a.b_kmajor))}>" + ("+swiglu" if a.act == ACT_SWIGLU else "")
     return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "") + ("+swiglu" if a.act == ACT_SWIGLU else "")
 
 

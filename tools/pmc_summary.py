@@ -11,7 +11,7 @@ _T = {"unsigned short": "t", "float": "f", "true": "1", "false": "0"}
 
 
 def norm(name):
-    m = re.search(r"(gemm_dma_kernel|gemm_lean_kernel|gemm_kernel)<([^>]*)>", name)   # demangled (csv output)
+    m = re.search(r"(gemm_dma_kernel|gemm_lean_kernel|gemm_wide_kernel|gemm_kernel)<([^>]*)>", name)   # demangled (csv output)
     if m:
         return m.group(1) + "<" + ",".join(_T.get(a.strip(), a.strip()) for a in m.group(2).split(",")) + ">"
     m = re.search(r"::(\w+_kernel)", name)
@@ -20,9 +20,9 @@ def norm(name):
     m = re.search(r"gemm_dma_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])ELb([01])E(\w)(\w)E", name)
     if m:
         return "gemm_dma_kernel<%s,%s,%s,%s,%s,%s,%s,%s>" % m.groups()
-    m = re.search(r"gemm_lean_kernelILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])ELb([01])E", name)
+    m = re.search(r"(gemm_lean_kernel|gemm_wide_kernel)ILi(\d)ELi(\d)ELi(\d)ELi(\d)ELb([01])ELb([01])E", name)
     if m:
-        return "gemm_lean_kernel<%s,%s,%s,%s,%s>" % m.groups()[:5] + ("+swiglu" if m.group(6) == "1" else "")
+        return "%s<%s,%s,%s,%s,%s>" % m.groups()[:6] + ("+swiglu" if m.group(7) == "1" else "")
     m = re.search(r"gemm_kernelI(\w)(\w)Lb([01])ELb([01])ELb([01])E(\w)(\w)E", name)
     if m:
         return "gemm_kernel<%s,%s,%s,%s,%s,%s,%s>" % m.groups()
