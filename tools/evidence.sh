@@ -16,6 +16,8 @@ bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
   echo "== tools/probes/l_config.py 64"; python tools/probes/l_config.py 64 2>&1 | tail -1
   echo "== tools/sampler_bench.py"; python tools/sampler_bench.py 2>&1 | grep sampler
   echo "== tools/sampler_bench.py --B --batch 64"; python tools/sampler_bench.py --B --batch 64 2>&1 | grep sampler
+  echo "== tools/probes/fp8_bench.py"; python tools/probes/fp8_bench.py 2>&1 | grep -v amdgpu | tail -6
+  echo "== tools/probes/blaslt_ref.py"; python tools/probes/blaslt_ref.py 2>&1 | grep -v amdgpu
   echo "== tools/vae_bench.py"; python tools/vae_bench.py 2>&1 | grep -v amdgpu | tail -4
   echo "== bench.py --graph"; python bench.py --no-cpu-baseline --no-roofline --graph 2>/dev/null | cut -c1-200
 ) > gpurun_out/${R}_probe_outputs.txt 2>&1
