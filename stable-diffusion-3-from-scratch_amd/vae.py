@@ -4,10 +4,10 @@ helpers/VAE_T5_CLIP_inference.py:25-43) and `decode(z).sample` in the sampler (m
 
 Mirror of the diffusers interface that those call sites touch: `.config.{latent_channels, scaling_factor, shift_factor}`,
 `.dtype`, `.encode(x).latent_dist.sample()/.mode()`, `.decode(z).sample`, parameters under diffusers' state_dict keys
-(a real `diffusion_pytorch_model.safetensors` loads with `load_state_dict`).  Every convolution is
-im2col (csrc/vae.hip) + the MFMA GEMM (bf16 operands, fp32 accumulate), GroupNorm+SiLU one fused two-pass kernel, the
-mid-block attention GEMM + row softmax + GEMM.  No CPU / PyTorch-math fallback.  First correct path: not yet tuned
-(im2col is materialised; the implicit-GEMM operand gather is the next step)."""
+(a real `diffusion_pytorch_model.safetensors` loads with `load_state_dict`).  Every 3x3 convolution is an implicit GEMM
+inside the LDS-DMA MFMA kernel (zero-bordered NHWC bf16 operand, bf16 operands, fp32 accumulate; conv_in with its 3 / 16
+channels zero-padded to 64), GroupNorm+SiLU a statistics pass + an apply pass that writes the next convolution's operand,
+the mid-block attention GEMM + row softmax + GEMM.  No CPU / PyTorch-math fallback."""
 import math
 from types import SimpleNamespace
 
@@ -23,20 +23,24 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+_CIN_PAD = 64     # conv_in operand channels (the implicit-GEMM K = 9 * C must be a multiple of the 64-wide K tile)
+
+
 class _Conv(nn.Module):
     """nn.Conv2d parameter holder (weight (Cout, Cin, k, k), bias) + the packed bf16 GEMM operand [Cout_p][k*k*Cin_p]."""
 
-    def __init__(self, cin, cout, k):
+    def __init__(self, cin, cout, k, cin_pad=None):
         super().__init__()
         self.weight = nn.Parameter(torch.empty(cout, cin, k, k))
         self.bias = nn.Parameter(torch.empty(cout))
         self.cin, self.cout, self.k = cin, cout, k
+        self.cin_pad = cin_pad      # channel count of the (zero-padded) operand: conv_in runs as an implicit GEMM on 64 channels
         self._packed = None
 
     def packed(self):
         key = (self.weight._version, self.bias._version, self.weight.device)
         if self._packed is None or self._packed[0] != key:
-            cin_p, cout_p = _pad8(self.cin), _pad8(self.cout)
+            cin_p, cout_p = self.cin_pad or _pad8(self.cin), _pad8(self.cout)
             w = torch.zeros((cout_p, self.k, self.k, cin_p), dtype=F32, device=self.weight.device)
             w[:self.cout, :, :, :self.cin] = self.weight.detach().permute(0, 2, 3, 1)
             b = torch.zeros(cout_p, dtype=F32, device=self.weight.device)
@@ -109,7 +113,7 @@ class _Encoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         ch = cfg.block_out_channels
-        self.conv_in = _Conv(cfg.in_channels, ch[0], 3)
+        self.conv_in = _Conv(cfg.in_channels, ch[0], 3, cin_pad=_CIN_PAD)
         self.down_blocks = nn.ModuleList([_Down(ch[max(i - 1, 0)], c, cfg.layers_per_block, i != len(ch) - 1) for i, c in enumerate(ch)])
         self.mid_block = _Mid(ch[-1])
         self.conv_norm_out = _Norm(ch[-1])
@@ -120,7 +124,7 @@ class _Decoder(nn.Module):
     def __init__(self, cfg):
         super().__init__()
         rev = list(reversed(cfg.block_out_channels))
-        self.conv_in = _Conv(cfg.latent_channels, rev[0], 3)
+        self.conv_in = _Conv(cfg.latent_channels, rev[0], 3, cin_pad=_CIN_PAD)
         self.mid_block = _Mid(rev[0])
         self.up_blocks = nn.ModuleList([_Up(rev[max(i - 1, 0)], c, cfg.layers_per_block + 1, i != len(rev) - 1) for i, c in enumerate(rev)])
         self.conv_norm_out = _Norm(rev[-1])
@@ -186,8 +190,8 @@ class AutoencoderKL(nn.Module):
 
     def _conv3(self, xin, a, conv, mode=0, residual=None):
         """3x3 convolution of the activation `a` whose conv operand is `xin`:
-        a zero-bordered bf16 (B, H+2, W+2, Cin) tensor -> implicit GEMM (Cin % 64 == 0: the big layers);
-        bf16 rows (B*H*W, Cin_p) -> materialised im2col + GEMM (conv_in with its 8 / 16 padded channels).
+        a zero-bordered bf16 (B, H+2, W+2, Cin) tensor -> implicit GEMM (Cin % 64 == 0: every layer, conv_in through _conv_in);
+        bf16 rows (B*H*W, Cin_p) -> materialised im2col + GEMM (kept for operands that are not channel-padded).
         mode 0: stride 1 / 1: Downsample2D / 2: Upsample2D (nearest x2 first).  Returns _Act with fp32 (B*Ho*Wo, Cout_p)."""
         w, b = conv.packed()
         if xin.dim() == 4:
@@ -197,6 +201,14 @@ class AutoencoderKL(nn.Module):
         cols, Ho, Wo = ops.vae_im2col3x3(xin.view(a.B, a.H, a.W, xin.shape[1]), mode)
         y = ops.gemm(cols, w, bias=b, residual=residual, out_dtype=F32)
         return _Act(y, a.B, Ho, Wo)
+
+    def _conv_in(self, x, conv):
+        """First convolution (3 image / 16 latent channels): NCHW -> NHWC bf16 with the channels zero-padded to 64, into the
+        zero-bordered operand of the implicit GEMM (K = 9 x 64; the padded channels multiply zero weight columns)."""
+        B, C, H, W = x.shape
+        xb = ops.vae_nchw_to_nhwc(x.contiguous() if x.dtype in (F32, BF16) else x.float().contiguous(), _CIN_PAD)
+        xin = ops.vae_pad_cast(xb.view(B * H * W, _CIN_PAD), B, H, W, self._padded(B, H, W, _CIN_PAD, x.device))
+        return self._conv3(xin, _Act(None, B, H, W), conv)
 
     def _resample_operand(self, a, upsample):
         """fp32 activation -> zero-bordered bf16 conv operand (nearest x2 upsampled for Upsample2D)."""
@@ -243,8 +255,7 @@ class AutoencoderKL(nn.Module):
             raise RuntimeError("the VAE runs on the HIP kernels only (no CPU fallback)")
         B, C, H, W = x.shape
         e = self.encoder
-        xb = ops.vae_nchw_to_nhwc(x.contiguous() if x.dtype in (F32, BF16) else x.float().contiguous(), _pad8(C))
-        a = self._conv3(xb.view(B * H * W, -1), _Act(None, B, H, W), e.conv_in)
+        a = self._conv_in(x, e.conv_in)
         for blk in e.down_blocks:
             for r in blk.resnets:
                 a = self._resnet(a, r)
@@ -262,8 +273,7 @@ class AutoencoderKL(nn.Module):
             raise RuntimeError("the VAE runs on the HIP kernels only (no CPU fallback)")
         B, C, H, W = z.shape
         d = self.decoder
-        zb = ops.vae_nchw_to_nhwc(z.contiguous() if z.dtype in (F32, BF16) else z.float().contiguous(), _pad8(C))
-        a = self._conv3(zb.view(B * H * W, -1), _Act(None, B, H, W), d.conv_in)
+        a = self._conv_in(z, d.conv_in)
         a = self._mid(a, d.mid_block)
         for blk in d.up_blocks:
             for r in blk.resnets:
