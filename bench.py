@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--torch-optimizer", action="store_true", help="development A/B: torch's multi-tensor unscale/clip/AdamW kernels instead of the three HIP launches")
     ap.add_argument("--force-dist", action="store_true", help="development: run the N>1 code path (RCCL group + gradient reducer) with one rank")
     ap.add_argument("--graph", action="store_true", help="replay the optimizer step from a hipGraph captured after the warm-up (single rank)")
+    ap.add_argument("--precision", default="fast", choices=["fast", "parity"], help="development: parity = the 1e-3 mode (fp32 activations, 3-term split-bf16 GEMMs, "
+                    "reference rounding points in attention); the headline metric is quoted on fast (= the reference's bf16 autocast)")
     ap.add_argument("--check-launch", action="store_true", help="rendezvous check only (gloo, no GPU): every rank joins the group, one all-reduce, rank 0 prints the world size")
     args = ap.parse_args()
 
@@ -168,6 +170,8 @@ def main():
                             warmup_steps=1000, use_lr_scheduler=False, device=dev, saveDir="/tmp/bench_ckpt", numSaveSteps=10 ** 9,
                             null_prob_pooled=0.1, null_prob_gemma=0.316, null_prob_bert=0.316, use_amp=True, max_res=256,
                             device_rng=True, use_ema=False, force_reducer=args.force_dist, hip_optimizer=not args.torch_optimizer)
+    if args.precision != "fast":
+        net.set_precision(args.precision)
     net.train()
 
     def sync():
@@ -238,7 +242,7 @@ def main():
         value = world * args.batch * args.steps / elapsed
         out = {"metric": "train images/sec MMDiT-B 256^2 bf16", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16" if args.precision == "fast" else "f32 (split-bf16 MFMA)", "data": "synthetic",
                "config": {"workload": "MMDiT-B (12 blocks, d=768, 12 heads, SwiGLU 4x, RoPE2d) 256^2 images -> 32x32x16 latents, synthetic "
                                       "Gemma-2-2b-shaped text embeds (154x2304) + pooled (768); fwd+bwd+grad-allreduce+clip+AdamW (fp32 master weights)",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
