@@ -77,7 +77,13 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 // v_rcp_f32 (1 ulp) instead of the IEEE division sequence (a dozen VALU instructions per element: the SwiGLU GEMM epilogue evaluates
 // 64 of these per lane and tile); __expf is the hardware exponential already, so the quotient was never correctly rounded anyway
+#ifdef MMDIT_PRECISE_PROBE   // experiment: correctly rounded transcendentals everywhere (does the parity margin depend on them?)
+#define rsqrtf(x) (1.0f / sqrtf(x))
+#define __expf(x) expf(x)
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); }
+#else
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+#endif
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
 // ---- MX (OCP microscaling) e4m3 helpers ------------------------------------------------------------------------------------
