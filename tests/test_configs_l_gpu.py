@@ -146,6 +146,48 @@ def test_l_sampler_28_steps_bf16_and_fp8_vs_reference_loop(golden_dir):
     assert r["parity"] < 5e-3 and r["fast"] < 5e-2 and r["fp8"] < 1.5e-1 and r88 < 1.5e-1 and r["mxfp8"] < 1.5e-1 and 1e-4 < rmx < 1.5e-1
 
 
+def test_config5_end_to_end_mxfp8_sampler_into_hip_vae_decode():
+    """Config 5 wired end to end on the GPU: text embedding stand-in -> MMDiT-L CFG sampler in "mxfp8" precision (4 Euler steps here)
+    -> FLUX-VAE decode on the HIP kernels (seeded synthetic weights: the real ones are not on this box) -> 512^2 image
+    (reference diff_model.py:467-477).  The latent handed to the VAE is recorded: it is the same latent the sampler produces with an
+    identity VAE of the same scaling / shift factors, and the returned image is the clamped HIP decode of exactly that latent."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.helpers.VAE_inference import VAE_inference
+    from oracle import vae_oracle as V
+    dev = torch.device("cuda:0")
+    _, th, tp = make_inputs(52, 1, 64, 64, text_scale=30.0)
+    net, _ = build("l", "mxfp8")
+    real = VAE_inference(dev, state_dict=V.make_state_dict(0, V.VAEConfig())).VAE
+
+    class _Rec:
+        def __init__(self, inner):
+            self.inner, self.config, self.dtype, self.z = inner, real.config, real.dtype, None
+
+        def decode(self, z):
+            self.z = z.detach().clone()
+            return self.inner.decode(z) if self.inner is not None else _Dec(z)
+
+    out = {}
+    try:
+        for name, vae in (("hip", _Rec(real)), ("identity", _Rec(None))):
+            enc = _Enc(th, tp)
+            enc.VAE = vae
+            net.text_encoders = enc
+            img = net.sample_imgs(1, 4, ["x"], cfg_scale=3.0, width=512, height=512, sampler="euler", generator=torch.Generator().manual_seed(7))
+            out[name] = (img, vae.z)
+    finally:
+        del net.text_encoders
+        net.train()
+        net.set_precision("fast")
+    img, z = out["hip"]
+    assert tuple(z.shape) == (1, 16, 64, 64) and torch.isfinite(z.float()).all() and torch.equal(z, out["identity"][1])
+    assert tuple(img.shape)[-3:] == (3, 512, 512) and torch.isfinite(img).all() and float(img.abs().max()) <= 1.0
+    ref = real.decode(z).sample.clamp(-1, 1).float()
+    # (two decodes of one latent agree to ~5e-3, not bitwise: the GroupNorm statistics are fp32 atomic sums, and the bf16 roundings
+    # downstream of a last-bit difference flip)
+    assert rel(img.reshape(ref.shape).to(ref.device), ref) < 2e-2
+
+
 @pytest.mark.parametrize("cname,h,w", [("xs", 64, 64), ("b", 32, 32)])
 def test_fp8_mode_vs_e4m3_oracle(cname, h, w):
     """The HIP fp8 forward against the CPU oracle run with the SAME per-tensor e4m3 quantisation of the same operands
