@@ -1,5 +1,7 @@
 """Row-kernel micro-benchmark on the MMDiT-B image-stream shapes (16384 rows, d = 768): time and algorithmic GB/s.
-python tools/row_bench.py [reps]"""
+python tools/row_bench.py [reps] [--cold]
+--cold: a 1.5 GB copy runs before every timed call, so the kernel's operands come from HBM as they do inside a training step
+(back-to-back calls on the same buffers are partly served by the 256 MB Infinity Cache and flatter the number)."""
 import os
 import sys
 
@@ -9,7 +11,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sd3_amd  # noqa: E402,F401
 from sd3_amd import ops  # noqa: E402
 
-reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+COLD = "--cold" in sys.argv
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+reps = int(_args[0]) if _args else 30
+_flush_src = torch.empty(768 * 2 ** 20, dtype=torch.uint8, device="cuda") if COLD else None
+_flush_dst = torch.empty_like(_flush_src) if COLD else None
 BF, F32 = torch.bfloat16, torch.float32
 B, N, d, H, h = 64, 256, 768, 12, 3072
 M = B * N
@@ -21,13 +27,23 @@ def timed(name, fn, nbytes):
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / reps * 1e-3
+    if COLD:
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        for e0, e1 in ev:
+            _flush_dst.copy_(_flush_src)
+            e0.record()
+            fn()
+            e1.record()
+        torch.cuda.synchronize()
+        t = sum(e0.elapsed_time(e1) for e0, e1 in ev) / reps * 1e-3
+    else:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
     print(f"{name:<22}{t * 1e6:9.1f} us {nbytes / t / 1e9:9.0f} GB/s  ({nbytes / 1e6:.0f} MB)")
 
 
@@ -59,3 +75,9 @@ timed("qk_norm_rope_fwd", lambda: ops.qk_norm_rope_fwd(qkv, wq, wk, cos, sin, B,
 dQ, dK, dV = (rnd(B, H, S, 64, dt=BF) for _ in range(3))
 dwq, dwk = torch.zeros(64, device="cuda"), torch.zeros(64, device="cuda")
 timed("qk_norm_rope_bwd", lambda: ops.qk_norm_rope_bwd(dQ, dK, dV, qkv, wq, wk, cos, sin, B, N, H, S, 0, dwq, dwk, BF), M * 3 * d * 6)
+# one launch over image + text rows vs two launches (how much of a short row kernel is ramp-up / tail?)
+Mc = B * 154
+xa, xb, xab = rnd(M, d), rnd(Mc, d), rnd(M + Mc, d)
+sc2 = rnd(2 * B, d)
+timed("ln_mod_fwd img+txt, 2 launches", lambda: (ops.ln_modulate_fwd(xa, sc, sh, N, BF), ops.ln_modulate_fwd(xb, sc, sh, 154, BF)), (M + Mc) * d * 6)
+timed("ln_mod_fwd img+txt, 1 launch", lambda: ops.ln_modulate_fwd(xab, sc2[:, :], sc2[:, :], (M + Mc) // (2 * B), BF), (M + Mc) * d * 6)
