@@ -81,3 +81,17 @@ xa, xb, xab = rnd(M, d), rnd(Mc, d), rnd(M + Mc, d)
 sc2 = rnd(2 * B, d)
 timed("ln_mod_fwd img+txt, 2 launches", lambda: (ops.ln_modulate_fwd(xa, sc, sh, N, BF), ops.ln_modulate_fwd(xb, sc, sh, 154, BF)), (M + Mc) * d * 6)
 timed("ln_mod_fwd img+txt, 1 launch", lambda: ops.ln_modulate_fwd(xab, sc2[:, :], sc2[:, :], (M + Mc) // (2 * B), BF), (M + Mc) * d * 6)
+# the same two launches forked onto two streams (event fork / join on the GPU): do their ramp-ups and tails overlap?
+_side = torch.cuda.Stream()
+def _two_streams():
+    main = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    ops.ln_modulate_fwd(xa, sc, sh, N, BF)
+    with torch.cuda.stream(_side):
+        _side.wait_event(ev)
+        ops.ln_modulate_fwd(xb, sc, sh, 154, BF)
+        ev2 = torch.cuda.Event()
+        ev2.record(_side)
+    main.wait_event(ev2)
+timed("ln_mod_fwd img+txt, 2 streams", _two_streams, (M + Mc) * d * 6)
