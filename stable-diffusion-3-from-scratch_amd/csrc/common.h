@@ -49,6 +49,19 @@ __device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
 #pragma unroll
   for (int i = 0; i < 4; i++) { v[2 * i] = __builtin_bit_cast(float, w[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, w[i] & 0xffff0000u); }
 }
+// streaming (non-temporal) variants for data at its LAST use (saved activations read by a backward kernel): no point keeping it in L2 / MALL
+__device__ __forceinline__ void ld8_nt(const bf16_t* p, float (&v)[8]) {
+  const u32x4 a = __builtin_nontemporal_load((const u32x4*)p);
+#pragma unroll
+  for (int i = 0; i < 4; i++) { v[2 * i] = __builtin_bit_cast(float, a[i] << 16); v[2 * i + 1] = __builtin_bit_cast(float, a[i] & 0xffff0000u); }
+}
+__device__ __forceinline__ void ld8_nt(const float* p, float (&v)[8]) { ld8(p, v); }
+__device__ __forceinline__ void ld4_nt(const float* p, float (&v)[4]) { const f32x4 a = __builtin_nontemporal_load((const f32x4*)p); v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; }
+__device__ __forceinline__ void ld4_nt(const bf16_t* p, float (&v)[4]) {
+  const u32x2 a = __builtin_nontemporal_load((const u32x2*)p);
+  v[0] = __builtin_bit_cast(float, a[0] << 16); v[1] = __builtin_bit_cast(float, a[0] & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, a[1] << 16); v[3] = __builtin_bit_cast(float, a[1] & 0xffff0000u);
+}
 __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
   *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
   *(float4*)(p + 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
       if constexpr (sizeof(TC) == 2 && NJ == 2)
         fast = !q.aux && !q.residual && !q.gate && !gp.accumulate && !it.atomic && (q.N & 7) == 0 && (q.ldc & 7) == 0 && ((uintptr_t)q.C & 15) == 0 && !(gp.debug & 64);
       if (fast) epilogue_bf16<MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, stage, alpha);
-      else epilogue32<TC, TAUX, MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, it.atomic, alpha);
+      else epilogue32<TC, TAUX, MI, NJ>(acc, q, gp, it.tm * TBM, it.tn * TBN, wm, wn, lane, it.sk, stage, it.atomic, alpha, A_KM && B_KM);
     }
     else if (acc[0][0][0] == 12345.678f) ((float*)gp.p[it.pi].C)[0] = 0.f;   // ablation: keep the accumulators live
   };

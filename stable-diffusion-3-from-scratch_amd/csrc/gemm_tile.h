@@ -121,7 +121,7 @@ __device__ __forceinline__ i32x8 load_frag8(const char* tile, int r0, int lane) 
 // ds_write_b128 / ds_read_b128) and leaves as 8 rows x 128 B (fp32) / 64 B (bf16) per wave instruction.
 template <typename TC, typename TAUX, int MI, int NJ>
 __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn,
-                                           int lane, int sk, char* stage, bool atomic_out, float alpha = 1.f) {
+                                           int lane, int sk, char* stage, bool atomic_out, float alpha = 1.f, bool nt_out = false) {
   TC* C = (TC*)p.C;
   TAUX* AUX = (TAUX*)p.aux;
   const bool first = sk == 0;
@@ -191,6 +191,12 @@ __device__ __forceinline__ void epilogue32(f32x16 (&acc)[MI][NJ], const Problem&
           ld4(cp, c4v);
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] += c4v[e];
+        }
+        if constexpr (sizeof(TC) == 4) {
+          if (nt_out) {   // weight gradients: next read by the optimizer, a whole backward later -- streaming store
+            __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, (f32x4*)cp);
+            continue;
+          }
         }
         st4(cp, v);
       }
@@ -311,7 +317,7 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
         const int r = it * 8 + rr;
         const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
         const int row = m0 + wm * (MI * 32) + i * 32 + r;
-        if (row < p.M) *(u32x4*)(GU + (int64_t)row * p.ld_aux + col) = t;
+        if (row < p.M) __builtin_nontemporal_store(t, (u32x4*)(GU + (int64_t)row * p.ld_aux + col));   // read again only in backward: streaming store
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -350,7 +356,7 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
         const int r = it * 16 + rr;
         const u32x4 t = *LDS_PTR(const u32x4, stage + r * 64 + ((rc ^ (r & 3)) << 4));
         const int row = m0 + wm * (MI * 32) + i * 32 + r;
-        if (row < p.M) *(u32x4*)(Hout + (int64_t)row * p.ldc + hc + rc * 8) = t;
+        if (row < p.M) *(u32x4*)(Hout + (int64_t)row * p.ldc + hc + rc * 8) = t;   // (a streaming store here costs more in the down-projection that reads h next than it saves: 31.44 -> 31.6 ms/step)
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region

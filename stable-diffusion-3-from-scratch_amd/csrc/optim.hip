@@ -98,6 +98,12 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, con
   p -= step_size * m / denom;
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4_nt;
+__device__ __forceinline__ float4 ntl4(const float* p, int i) { const f32x4_nt v = __builtin_nontemporal_load((const f32x4_nt*)p + i); return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void nts4(float* p, int i, const float4& v) { __builtin_nontemporal_store(f32x4_nt{v.x, v.y, v.z, v.w}, (f32x4_nt*)p + i); }
+#define NTL(P_, i_) ntl4(P_, i_)
+#define NTS(P_, i_, v_) nts4(P_, i_, v_)
+
 __global__ __launch_bounds__(TPB) void adamw_kernel(const mmdit_adamw_tensor* __restrict__ tensors, const int* __restrict__ chunk_tensor, const int64_t* __restrict__ chunk_off,
                                                      const float* __restrict__ coef_found, const float* __restrict__ step_count, AdamConst k) {   // (k is a by-value copy: lr / decay may be replaced below)
   float coef = 1.f;
@@ -127,21 +133,23 @@ __global__ __launch_bounds__(TPB) void adamw_kernel(const mmdit_adamw_tensor* __
     for (int i = threadIdx.x; i < n4; i += 2 * TPB) {
       const bool two = i + TPB < n4;
       const int i2 = two ? i + TPB : i;
-      float4 p0 = ((float4*)P)[i], g0 = ((const float4*)G)[i], m0 = ((float4*)M)[i], v0 = ((float4*)V)[i];
-      float4 p1 = ((float4*)P)[i2], g1 = ((const float4*)G)[i2], m1 = ((float4*)M)[i2], v1 = ((float4*)V)[i2];
+      // every byte of the 10 GB this kernel moves is touched exactly once per step: streaming (non-temporal) loads and stores keep it
+      // out of the way of what the next kernels want in L2 / Infinity Cache
+      float4 p0 = NTL(P, i), g0 = NTL(G, i), m0 = NTL(M, i), v0 = NTL(V, i);
+      float4 p1 = NTL(P, i2), g1 = NTL(G, i2), m1 = NTL(M, i2), v1 = NTL(V, i2);
       adam1(p0.x, g0.x * coef, m0.x, v0.x, k, step_size, bc2_sqrt);
       adam1(p0.y, g0.y * coef, m0.y, v0.y, k, step_size, bc2_sqrt);
       adam1(p0.z, g0.z * coef, m0.z, v0.z, k, step_size, bc2_sqrt);
       adam1(p0.w, g0.w * coef, m0.w, v0.w, k, step_size, bc2_sqrt);
-      ((float4*)P)[i] = p0; ((float4*)M)[i] = m0; ((float4*)V)[i] = v0;
-      if (S) ((uint2*)S)[i] = make_uint2(pack_bf2(p0.x, p0.y), pack_bf2(p0.z, p0.w));
+      NTS(P, i, p0); NTS(M, i, m0); NTS(V, i, v0);
+      if (S) __builtin_nontemporal_store(u32x2{pack_bf2(p0.x, p0.y), pack_bf2(p0.z, p0.w)}, (u32x2*)S + i);
       if (two) {
         adam1(p1.x, g1.x * coef, m1.x, v1.x, k, step_size, bc2_sqrt);
         adam1(p1.y, g1.y * coef, m1.y, v1.y, k, step_size, bc2_sqrt);
         adam1(p1.z, g1.z * coef, m1.z, v1.z, k, step_size, bc2_sqrt);
         adam1(p1.w, g1.w * coef, m1.w, v1.w, k, step_size, bc2_sqrt);
-        ((float4*)P)[i2] = p1; ((float4*)M)[i2] = m1; ((float4*)V)[i2] = v1;
-        if (S) ((uint2*)S)[i2] = make_uint2(pack_bf2(p1.x, p1.y), pack_bf2(p1.z, p1.w));
+        NTS(P, i2, p1); NTS(M, i2, m1); NTS(V, i2, v1);
+        if (S) __builtin_nontemporal_store(u32x2{pack_bf2(p1.x, p1.y), pack_bf2(p1.z, p1.w)}, (u32x2*)S + i2);
       }
     }
     done = n4 << 2;

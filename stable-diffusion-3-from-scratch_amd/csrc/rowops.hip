@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
         ld4(gate + (int64_t)b * ld_gate + ch * 4, g);
 #pragma unroll
         for (int e = 0; e < 4; e++) v[it][e] = v[it][e] + g[e] * av[e];
-        st4(xo + (int64_t)row * d + ch * 4, v[it]);
+        __builtin_nontemporal_store(f32x4{v[it][0], v[it][1], v[it][2], v[it][3]}, (f32x4*)(xo + (int64_t)row * d + ch * 4));   // next read a GEMM, an attention and a GEMM later
       }
       s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
     }
@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ 
       int ch = lane + 64 * it;
       if (ch < nch) {
         float dy[4], xv[4];
-        ld4(dout + row * d + ch * 4, dy);
-        ld4(x + row * d + ch * 4, xv);
+        ld4_nt(dout + row * d + ch * 4, dy);      // (dy, the saved residual row and acc are at their last use: streaming loads)
+        ld4_nt(x + row * d + ch * 4, xv);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           xh[it][e] = (xv[e] - mean) * rstd;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ 
         st4(dx + row * d + ch * 4, o);
         if constexpr (GATED) {
           float av[4], da[4];
-          ld4(acc + row * d + ch * 4, av);
+          ld4_nt(acc + row * d + ch * 4, av);
 #pragma unroll
           for (int e = 0; e < 4; e++) { da[e] = o[e] * gt[it][e]; sg[it][e] += o[e] * av[e]; sb[it][e] += da[e]; }
           st4(dacc + row * d + ch * 4, da);
@@ -424,9 +424,9 @@ __global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __rest
       const int row = row0 + k * rstride;
       if (row < rows) {
         const int n = row % tokens, b = row / tokens;
-        ld8(gbase + (((int64_t)b * heads + head) * s_total + tok0 + n) * 64 + chunk * 8, dz[k]);
+        ld8_nt(gbase + (((int64_t)b * heads + head) * s_total + tok0 + n) * 64 + chunk * 8, dz[k]);      // (single use; the saved qkv below: last use)
         if (part < 2) {
-          ld8(qkv + (((int64_t)row * 3 + part) * heads + head) * 64 + chunk * 8, x[k]);
+          ld8_nt(qkv + (((int64_t)row * 3 + part) * heads + head) * 64 + chunk * 8, x[k]);
           if (rcos && !same_token) {
             ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[k]);
             ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[k]);
@@ -567,9 +567,9 @@ __global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ 
       for (int k = 0; k < 2; k++) {
         const int r = r0 + 8 * k;
         if (r < rend) {
-          ld8(dh + (int64_t)r * hidden + c, d[k]);
-          ld8(gu + r * ldi + c, g[k]);
-          if constexpr (!GELU) ld8(gu + r * ldi + hidden + c, u[k]);
+          ld8_nt(dh + (int64_t)r * hidden + c, d[k]);       // (dh and the saved pre-activations are at their last use)
+          ld8_nt(gu + r * ldi + c, g[k]);
+          if constexpr (!GELU) ld8_nt(gu + r * ldi + hidden + c, u[k]);
         }
       }
 #pragma unroll
