@@ -112,6 +112,11 @@ int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
  * precision, act, accumulate, aux dtype) share one grid, e.g. the image and the text stream of a block
  * (Attention.py:130-135 issues them as separate Linears) or all weight-gradient GEMMs of a block. */
 int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream);
+/* Which outputs of a K-decomposed launch (stream_k / split_k requests: the weight gradients) must be ZERO when the launch starts,
+ * i.e. receive atomically added partial tiles: bit i of *mask = problem i.  With the round + tail schedule these are only the
+ * problems that own tiles of the split tail (MMDiT-B: one of a block's eight weight gradients); whole-K tiles are stored, not added,
+ * and need no zero-fill.  Same planner as the launch itself (nothing is launched). */
+int mmdit_gemm_zero_mask(const mmdit_gemm_args* args, int count, unsigned* mask);
 /* Which kernel mmdit_gemm_grouped would launch for these problems (no launch): 64 = register-staged kernel (gemm.hip);
  * otherwise the LDS-DMA kernel (gemm_dma.hip) with tile configuration (value & 15): 0 = 128x128, 1 = 256x128,
  * 2 = 256x256, 3 = 320x256 (lean kernel only), plus 16 if the stream-K decomposition is used, plus 32 for the full-rounds +

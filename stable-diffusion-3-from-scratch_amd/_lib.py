@@ -46,6 +46,7 @@ _SIGNATURES = {
     "mmdit_gemm": ([ctypes.POINTER(GemmArgs), _vp], _i),
     "mmdit_gemm_grouped": ([ctypes.POINTER(GemmArgs), _i, _vp], _i),
     "mmdit_gemm_plan": ([ctypes.POINTER(GemmArgs), _i], _i),
+    "mmdit_gemm_zero_mask": ([ctypes.POINTER(GemmArgs), _i, ctypes.POINTER(ctypes.c_uint)], _i),
     "mmdit_fp8_amax": ([_vp, _i, _i64, _vp, _vp], _i),
     "mmdit_fp8_quantize": ([_vp, _i, _i64, _vp, _vp, _vp, _vp], _i),
     "mmdit_fp8_quantize_delayed": ([_vp, _i, _i64, _vp, _i, ctypes.c_float, _vp, _vp], _i),

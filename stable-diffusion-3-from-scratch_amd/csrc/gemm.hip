@@ -280,7 +280,7 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
 
 static inline int split_k_of(const mmdit_gemm_args* a) { return a->split_k > 1 ? a->split_k : 1; }
 
-static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only) {
+static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only, unsigned* zero_mask = nullptr) {
   MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
   const mmdit_gemm_args* a0 = &args[0];
   GroupParams gp;
@@ -460,6 +460,17 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     MMDIT_CHECK_ARG(dma && a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE && !a0->accumulate && split_k <= 64);
     for (int i = 0; i < count; i++) MMDIT_CHECK_ARG(!args[i].aux && !args[i].gate);
   }
+  if (zero_mask) {
+    // which outputs receive ATOMIC partial tiles (and therefore must be zero when the launch starts): every problem under stream-K or
+    // a caller-requested split-K; with the round + tail schedule only the problems that own tiles of the split tail; none otherwise
+    unsigned mask = 0;
+    for (int i = 0; i < count; i++) {
+      const Problem& q = gp.p[i];
+      const bool atomic = dma && (gp.stream_k || (gp.split_k > 1 && q.tile_start + q.tiles_m * q.tiles_n > gp.full_tiles));
+      if (atomic) mask |= 1u << order[i];
+    }
+    *zero_mask = mask;
+  }
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean ? 128 : 0)) : 64;   // see mmdit_gemm_plan
   hipStream_t s = (hipStream_t)stream;
   if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
@@ -472,6 +483,13 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
 extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) { return gemm_grouped_impl(args, count, stream, false); }
 
 extern "C" int mmdit_gemm_plan(const mmdit_gemm_args* args, int count) { return gemm_grouped_impl(args, count, nullptr, true); }
+
+extern "C" int mmdit_gemm_zero_mask(const mmdit_gemm_args* args, int count, unsigned* mask) {
+  MMDIT_CHECK_ARG(mask);
+  *mask = 0;
+  const int rc = gemm_grouped_impl(args, count, nullptr, true, mask);
+  return rc < 0 || rc > 255 ? rc : 0;   // (plan codes are small non-negative integers; anything else is a status)
+}
 
 extern "C" int mmdit_gemm(const mmdit_gemm_args* a, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(a);

@@ -16,6 +16,7 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
 # (entries: (kernel variant, algorithmic FLOPs, start event, end event)); None = no instrumentation.
 PROFILE = None
+_ZERO_ALL = os.environ.get("MMDIT_ZERO_ALL", "0") == "1"     # A/B: zero-fill every K-decomposed GEMM output (from the pass's zero pool)
 
 
 class _ZeroPool:
@@ -116,7 +117,13 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
             out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=A.device)
     if out is None:
         if split_k > 1 or stream_k:
-            out = zeros((M, N), A.device)   # slices accumulate atomically
+            # K-decomposed launch: partial tiles may be added atomically.  gemm_grouped asks the planner which outputs really
+            # receive atomics and zero-fills only those (whole-K tiles are stored): no memset of every weight gradient
+            if _ZERO_ALL:
+                out = zeros((M, N), A.device)
+            else:
+                out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+                out._mmdit_zero_check = True
         else:
             out = torch.empty((M, N), dtype=out_dtype or torch.float32, device=A.device)
     a.A, a.a_dtype, a.a_kmajor, a.lda = _p(A), _dt(A), int(a_kmajor), (K_ if conv is not None else A.stride(0))
@@ -167,6 +174,14 @@ def gemm_grouped(problems):
     n = len(problems)
     arr = (GemmArgs * n)()
     outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
+    if any(getattr(o, "_mmdit_zero_check", False) for o in outs):
+        mask = ctypes.c_uint(0)
+        check(_lib.lib().mmdit_gemm_zero_mask(arr, n, ctypes.byref(mask)), "mmdit_gemm_zero_mask")
+        for i, o in enumerate(outs):
+            if getattr(o, "_mmdit_zero_check", False):
+                if (mask.value >> i) & 1:
+                    o.zero_()
+                del o._mmdit_zero_check
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -490,6 +490,36 @@ def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
     assert rel(y.float(), A.float() @ W.float().t() + bias) < 6e-2
 
 
+def test_gemm_zero_mask_marks_exactly_the_outputs_that_receive_atomics(ops):
+    """mmdit_gemm_zero_mask: in a K-decomposed grouped launch (a block's weight gradients) only the problems that own tiles of the
+    split tail are accumulated atomically.  Every other output is pre-filled with NaN here and must come out fully overwritten and
+    correct; the flagged ones start from zero."""
+    import ctypes
+    from sd3_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(9)
+    rnd = lambda *s: torch.randn(s, generator=g, device="cuda").to(torch.bfloat16)
+    Mx, Mc, d = 4096, 2432, 768
+    probs = []
+    for N, K in ((3 * d, d), (d, d), (8 * d, d), (d, 4 * d)):
+        for Mr in (Mx, Mc):
+            probs.append(dict(A=rnd(Mr, N), B=rnd(Mr, K), a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
+    n = len(probs)
+    arr = (_lib.GemmArgs * n)()
+    outs = [torch.empty((p["A"].shape[1], p["B"].shape[1]), dtype=torch.float32, device="cuda") for p in probs]
+    for i, p in enumerate(probs):
+        ops._fill_gemm(arr[i], out=outs[i], **p)
+    mask = ctypes.c_uint(0)
+    assert _lib.lib().mmdit_gemm_zero_mask(arr, n, ctypes.byref(mask)) == 0
+    flagged = [(mask.value >> i) & 1 for i in range(n)]
+    assert 0 < sum(flagged) < n, flagged                    # 288 tiles on 256 workgroups: a tail exists, and it is not everything
+    for o, f in zip(outs, flagged):
+        o.fill_(0.0 if f else float("nan"))
+    ops.gemm_grouped([dict(out=o, **p) for o, p in zip(outs, probs)])
+    for o, p in zip(outs, probs):
+        ref = p["A"].float().t() @ p["B"].float()
+        assert torch.isfinite(o).all() and rel(o, ref) < 2e-5
+
+
 def _mx_reference(x):
     """torch restatement of mmdit_mxfp8_quantize: (e4m3 codes as uint8 (rows, K), E8M0 bytes in the GEMM layout [K/64][rows][2], dequantised fp32)."""
     rows, K = x.shape
