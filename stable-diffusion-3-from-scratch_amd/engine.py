@@ -167,18 +167,27 @@ def _zeros_views(shapes, dev, prefix=None):
 
 
 def _wgrad_flush(m, pending):
-    """pending: list of (setter, descriptor).  Grouped launches (<= 12 problems each), on the side stream."""
+    """pending: list of (setter, descriptor).  Grouped launches (<= 12 problems each; on the side stream with MMDIT_WGRAD_STREAM=1).
+    On a GPU every output is a view of ONE flat fp32 arena, in `pending` order (a data-parallel reducer averages the block's weight
+    gradients in place through it: no gather copy); the arena is NOT zero-filled -- ops.gemm_grouped asks the planner which
+    outputs receive atomic partial tiles and zeroes only those."""
     arena = None
     if not pending:
         return arena
-    overlap = _WG_OVERLAP and pending[0][1]["A"].is_cuda
-    if overlap:
+    gpu = pending[0][1]["A"].is_cuda
+    overlap = _WG_OVERLAP and gpu
+    if gpu:
         dev = pending[0][1]["A"].device
-        # outputs come from the main stream's pool (one zeroed arena: stream-K adds partial tiles atomically);
+        shapes = [(d["A"].shape[1], d["B"].shape[1]) for _, d in pending]
+        sizes = [(a * b + 3) // 4 * 4 for a, b in shapes]          # 16-byte aligned slices
+        arena = torch.empty(sum(sizes), dtype=F32, device=dev)
+        off = 0
+        for (_, d), (a, b), n in zip(pending, shapes, sizes):
+            d["out"] = arena[off:off + a * b].view(a, b)
+            d["out"]._mmdit_zero_check = True
+            off += n
+    if overlap:
         # inputs must outlive the side-stream reads (record_stream below)
-        outs, arena = _zeros_views([(d["A"].shape[1], d["B"].shape[1]) for _, d in pending], dev, prefix=len(pending))
-        for (_, d), o in zip(pending, outs):
-            d["out"] = o
         side = wgrad_stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         ctx = torch.cuda.stream(side)
