@@ -179,6 +179,22 @@ int mmdit_ln_modulate_fwd_res(const float* x, const void* acc, int acc_dtype, co
                               const float* scale, const float* shift, int64_t ld_mod,
                               int rows, int d, int rows_per_batch,
                               void* out, int out_dtype, float* mean, float* rstd, mmdit_stream_t stream);
+/* The image and the text stream of a block run the same adaLN kernels on different rows, modulation vectors and rows-per-sample: the
+ * *_pair entry points take both problems (same d, same dtypes) in ONE launch -- these 20-45 us kernels pay ~8 us of ramp-up and tail
+ * per launch.  Field meaning as in mmdit_ln_modulate_fwd_res / mmdit_ln_modulate_bwd_gated (acc == NULL in BOTH problems: the plain
+ * mmdit_ln_modulate_fwd / _bwd arithmetic; dbias may be NULL). */
+typedef struct mmdit_ln_fwd_problem {
+  const float* x; const void* acc; const float* gate; int64_t ld_gate; float* x_out;
+  const float* scale; const float* shift; int64_t ld_mod; int rows, rows_per_batch;
+  void* out; float* mean; float* rstd;
+} mmdit_ln_fwd_problem;
+int mmdit_ln_modulate_fwd_pair(const mmdit_ln_fwd_problem* p0, const mmdit_ln_fwd_problem* p1, int d, int acc_dtype, int out_dtype, mmdit_stream_t stream);
+typedef struct mmdit_ln_bwd_problem {
+  const void* dout; const float* x; const float* mean; const float* rstd; const float* scale; int64_t ld_mod; const float* dres; int rows, rows_per_batch;
+  float* dx; float* dscale; float* dshift; int64_t ld_dmod;
+  const void* acc; const float* gate; int64_t ld_gate; void* dacc; float* dgate; int64_t ld_dgate; float* dbias; int64_t ld_dbias;
+} mmdit_ln_bwd_problem;
+int mmdit_ln_modulate_bwd_pair(const mmdit_ln_bwd_problem* p0, const mmdit_ln_bwd_problem* p1, int d, int dout_dtype, mmdit_stream_t stream);
 int mmdit_gate_residual_fwd(const float* x, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate,
                             int rows, int d, int rows_per_batch, float* out, mmdit_stream_t stream);
 int mmdit_ln_modulate_bwd(const void* dout, int dout_dtype, const float* x, const float* mean, const float* rstd,

@@ -23,12 +23,12 @@ __device__ __forceinline__ float bf16_round(float x) { return __builtin_bit_cast
 // MX (TO = unsigned char, d % 32 == 0): the normalised row leaves as e4m3 codes + E8M0 block scales (a 32-block is the 4 values of 8
 // adjacent lanes of one iteration), bit-identical to the bf16 output followed by mmdit_mxfp8_quantize.
 template <int NIT, typename TO, typename TA, bool RES, bool MX = false>
-__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int64_t ld_mod, int rows, int d, int rpb, TO* __restrict__ out,
-                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o,
-                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, float* __restrict__ xo,
-                                                         unsigned char* __restrict__ mx_scales = nullptr) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void ln_mod_fwd_body(int block, const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                int64_t ld_mod, int rows, int d, int rpb, TO* __restrict__ out,
+                                                float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, float* __restrict__ xo,
+                                                unsigned char* __restrict__ mx_scales) {
+  const int lane = threadIdx.x & 63, row = block * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nch = d >> 2;
   const int b = row / rpb;
@@ -93,6 +93,30 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict
   }
 }
 
+template <int NIT, typename TO, typename TA, bool RES, bool MX = false>
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int64_t ld_mod, int rows, int d, int rpb, TO* __restrict__ out,
+                                                         float* __restrict__ mean_o, float* __restrict__ rstd_o,
+                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, float* __restrict__ xo,
+                                                         unsigned char* __restrict__ mx_scales = nullptr) {
+  ln_mod_fwd_body<NIT, TO, TA, RES, MX>((int)blockIdx.x, x, scale, shift, ld_mod, rows, d, rpb, out, mean_o, rstd_o, acc, gate, ld_gate, xo, mx_scales);
+}
+
+// Two independent adaLN problems of the same width in ONE launch (the image and the text stream of a block): these kernels run 20-45 us
+// on 75-180 MB, of which ~8 us is ramp-up and tail -- one launch over both streams instead of two saves ~5 us per pair
+// (tools/row_bench.py --cold).  Blocks [0, nblk0) work on problem 0, the rest on problem 1.
+struct LnFwdProb {
+  const float* x; const float* scale; const float* shift; int64_t ld_mod; int rows, rpb; void* out; float* mean; float* rstd;
+  const void* acc; const float* gate; int64_t ld_gate; float* xo;
+};
+template <int NIT, typename TO, typename TA, bool RES>
+__global__ __launch_bounds__(256) void ln_mod_fwd_pair_kernel(LnFwdProb p0, LnFwdProb p1, int nblk0, int d) {
+  const bool first = (int)blockIdx.x < nblk0;     // (workgroup-uniform)
+  const LnFwdProb& p = first ? p0 : p1;
+  ln_mod_fwd_body<NIT, TO, TA, RES, false>(first ? (int)blockIdx.x : (int)blockIdx.x - nblk0, p.x, p.scale, p.shift, p.ld_mod, p.rows, d, p.rpb, (TO*)p.out, p.mean, p.rstd,
+                                           (const TA*)p.acc, p.gate, p.ld_gate, p.xo, nullptr);
+}
+
 // out = x + gate[b] * acc (the gated residual update on its own: used where no norm consumes the result)
 template <typename TA>
 __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __restrict__ x, const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate,
@@ -117,14 +141,14 @@ __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __r
 // gradient) -- dx is in registers here, so the separate pass over it (mmdit_gate_residual_bwd) disappears.
 constexpr int LN_BWD_RCH = 16;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
 template <int NIT, typename TG, typename TA, bool GATED>
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
-                                                         const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
-                                                         const float* __restrict__ dres, int d, int rpb, int nchunk,
-                                                         float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod,
-                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, TA* __restrict__ dacc,
-                                                         float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias) {
+__device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
+                                                const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
+                                                const float* __restrict__ dres, int d, int rpb, int nchunk,
+                                                float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod,
+                                                const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, TA* __restrict__ dacc,
+                                                float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+  const int b = block / nchunk, chunk = block % nchunk;
   const int nch = d >> 2;
   const float* sc = scale + (int64_t)b * ld_mod;
   float a1[NIT][4], ds[NIT][4], dh[NIT][4];
@@ -219,6 +243,31 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ 
       if (dbias) flush(sb, dbias + (int64_t)b * ld_dbias);
     }
   }
+}
+
+template <int NIT, typename TG, typename TA, bool GATED>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
+                                                         const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
+                                                         const float* __restrict__ dres, int d, int rpb, int nchunk,
+                                                         float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod,
+                                                         const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, TA* __restrict__ dacc,
+                                                         float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias) {
+  ln_mod_bwd_body<NIT, TG, TA, GATED>((int)blockIdx.x, dout, x, mean_i, rstd_i, scale, ld_mod, dres, d, rpb, nchunk, dx, dscale, dshift, ld_dmod, acc, gate, ld_gate, dacc,
+                                      dgate, ld_dgate, dbias, ld_dbias);
+}
+
+// two adaLN backward problems of the same width in one launch (see ln_mod_fwd_pair_kernel)
+struct LnBwdProb {
+  const void* dout; const float* x; const float* mean; const float* rstd; const float* scale; int64_t ld_mod; const float* dres; int rpb, nchunk;
+  float* dx; float* dscale; float* dshift; int64_t ld_dmod;
+  const void* acc; const float* gate; int64_t ld_gate; void* dacc; float* dgate; int64_t ld_dgate; float* dbias; int64_t ld_dbias;
+};
+template <int NIT, typename TG, typename TA, bool GATED>
+__global__ __launch_bounds__(256) void ln_mod_bwd_pair_kernel(LnBwdProb p0, LnBwdProb p1, int nblk0, int d) {
+  const bool first = (int)blockIdx.x < nblk0;     // (workgroup-uniform)
+  const LnBwdProb& p = first ? p0 : p1;
+  ln_mod_bwd_body<NIT, TG, TA, GATED>(first ? (int)blockIdx.x : (int)blockIdx.x - nblk0, (const TG*)p.dout, p.x, p.mean, p.rstd, p.scale, p.ld_mod, p.dres, d, p.rpb, p.nchunk,
+                                      p.dx, p.dscale, p.dshift, p.ld_dmod, (const TA*)p.acc, p.gate, p.ld_gate, (TA*)p.dacc, p.dgate, p.ld_dgate, p.dbias, p.ld_dbias);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -874,6 +923,57 @@ extern "C" int mmdit_ln_modulate_bwd_gated(const void* dout, int dout_dtype, con
   if (dout_dtype == MMDIT_BF16) return ln_mod_bwd_launch<bf16_t, bf16_t, true>(dout, x, mean, rstd, scale, ld_mod, dres, rows, d, rpb, dx, dscale, dshift, ld_dmod, acc, gate, ld_gate, dacc, dgate, ld_dgate, dbias, ld_dbias, s);
   if (dout_dtype == MMDIT_F32) return ln_mod_bwd_launch<float, float, true>(dout, x, mean, rstd, scale, ld_mod, dres, rows, d, rpb, dx, dscale, dshift, ld_dmod, acc, gate, ld_gate, dacc, dgate, ld_dgate, dbias, ld_dbias, s);
   return MMDIT_ERR_DTYPE;
+}
+
+extern "C" int mmdit_ln_modulate_fwd_pair(const mmdit_ln_fwd_problem* a, const mmdit_ln_fwd_problem* b, int d, int acc_dtype, int out_dtype, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(a && b && d > 0 && d % 4 == 0 && d <= 4096);
+  const bool res = a->acc != nullptr;
+  MMDIT_CHECK_ARG((b->acc != nullptr) == res && (!res || acc_dtype == out_dtype));
+  LnFwdProb q[2];
+  const mmdit_ln_fwd_problem* src[2] = {a, b};
+  for (int i = 0; i < 2; i++) {
+    const mmdit_ln_fwd_problem* p = src[i];
+    MMDIT_CHECK_ARG(p->x && p->scale && p->shift && p->out && p->mean && p->rstd && p->rows > 0 && p->rows_per_batch > 0 && p->ld_mod % 4 == 0);
+    if (res) MMDIT_CHECK_ARG(p->gate && p->x_out && p->ld_gate % 4 == 0);
+    q[i] = LnFwdProb{p->x, p->scale, p->shift, p->ld_mod, p->rows, p->rows_per_batch, p->out, p->mean, p->rstd, p->acc, p->gate, p->ld_gate, p->x_out};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d), nb0 = (a->rows + 3) / 4, nb1 = (b->rows + 3) / 4;
+  dim3 grid(nb0 + nb1);
+#define LNP(TO, RES) NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_pair_kernel<NIT, TO, TO, RES>), grid, dim3(256), 0, s, q[0], q[1], nb0, d))
+  if (out_dtype == MMDIT_BF16) { if (res) { LNP(bf16_t, true); } else { LNP(bf16_t, false); } }
+  else if (out_dtype == MMDIT_F32) { if (res) { LNP(float, true); } else { LNP(float, false); } }
+  else return MMDIT_ERR_DTYPE;
+#undef LNP
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_ln_modulate_bwd_pair(const mmdit_ln_bwd_problem* a, const mmdit_ln_bwd_problem* b, int d, int dout_dtype, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(a && b && d > 0 && d % 4 == 0 && d <= 4096);
+  const bool gated = a->acc != nullptr;
+  MMDIT_CHECK_ARG((b->acc != nullptr) == gated);
+  LnBwdProb q[2];
+  const mmdit_ln_bwd_problem* src[2] = {a, b};
+  int nb[2];
+  for (int i = 0; i < 2; i++) {
+    const mmdit_ln_bwd_problem* p = src[i];
+    MMDIT_CHECK_ARG(p->dout && p->x && p->mean && p->rstd && p->scale && p->dx && p->dscale && p->dshift && p->rows > 0 && p->rows_per_batch > 0 &&
+                    p->rows % p->rows_per_batch == 0 && p->ld_mod % 4 == 0);
+    if (gated) MMDIT_CHECK_ARG(p->gate && p->dacc && p->dgate && p->ld_gate % 4 == 0);
+    const int nchunk = (p->rows_per_batch + LN_BWD_RCH - 1) / LN_BWD_RCH;
+    nb[i] = (p->rows / p->rows_per_batch) * nchunk;
+    q[i] = LnBwdProb{p->dout, p->x, p->mean, p->rstd, p->scale, p->ld_mod, p->dres, p->rows_per_batch, nchunk, p->dx, p->dscale, p->dshift, p->ld_dmod,
+                     p->acc, p->gate, p->ld_gate, p->dacc, p->dgate, p->ld_dgate, p->dbias, p->ld_dbias};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int nit = nit_for(d);
+  dim3 grid(nb[0] + nb[1]);
+#define LNP(T, G) NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_pair_kernel<NIT, T, T, G>), grid, dim3(256), 0, s, q[0], q[1], nb[0], d))
+  if (dout_dtype == MMDIT_BF16) { if (gated) { LNP(bf16_t, true); } else { LNP(bf16_t, false); } }
+  else if (dout_dtype == MMDIT_F32) { if (gated) { LNP(float, true); } else { LNP(float, false); } }
+  else return MMDIT_ERR_DTYPE;
+#undef LNP
+  return mmdit_launch_status();
 }
 
 extern "C" int mmdit_text_rmsnorm_fwd(const void* x, int x_dtype, const float* w1, const float* w2, const float* s1, const float* s2,
