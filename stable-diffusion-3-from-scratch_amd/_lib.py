@@ -40,6 +40,20 @@ class GemmArgs(ctypes.Structure):
 
 
 # argument types of every entry point, in header order
+class LnFwdProblem(ctypes.Structure):      # mirrors mmdit_ln_fwd_problem (include/mmdit_hip.h)
+    _fields_ = [("x", ctypes.c_void_p), ("acc", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("ld_gate", ctypes.c_int64), ("x_out", ctypes.c_void_p),
+                ("scale", ctypes.c_void_p), ("shift", ctypes.c_void_p), ("ld_mod", ctypes.c_int64), ("rows", ctypes.c_int), ("rows_per_batch", ctypes.c_int),
+                ("out", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p)]
+
+
+class LnBwdProblem(ctypes.Structure):      # mirrors mmdit_ln_bwd_problem
+    _fields_ = [("dout", ctypes.c_void_p), ("x", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("scale", ctypes.c_void_p),
+                ("ld_mod", ctypes.c_int64), ("dres", ctypes.c_void_p), ("rows", ctypes.c_int), ("rows_per_batch", ctypes.c_int),
+                ("dx", ctypes.c_void_p), ("dscale", ctypes.c_void_p), ("dshift", ctypes.c_void_p), ("ld_dmod", ctypes.c_int64),
+                ("acc", ctypes.c_void_p), ("gate", ctypes.c_void_p), ("ld_gate", ctypes.c_int64), ("dacc", ctypes.c_void_p), ("dgate", ctypes.c_void_p),
+                ("ld_dgate", ctypes.c_int64), ("dbias", ctypes.c_void_p), ("ld_dbias", ctypes.c_int64)]
+
+
 _SIGNATURES = {
     "mmdit_abi_version": ([], _i),
     "mmdit_build_arch": ([], ctypes.c_char_p),
@@ -57,6 +71,8 @@ _SIGNATURES = {
     "mmdit_cast": ([_vp, _i, _vp, _i, _i64, _vp], _i),
     "mmdit_ln_modulate_fwd": ([_vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_fwd_res": ([_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
+    "mmdit_ln_modulate_fwd_pair": ([ctypes.POINTER(LnFwdProblem), ctypes.POINTER(LnFwdProblem), _i, _i, _i, _vp], _i),
+    "mmdit_ln_modulate_bwd_pair": ([ctypes.POINTER(LnBwdProblem), ctypes.POINTER(LnBwdProblem), _i, _i, _vp], _i),
     "mmdit_gate_residual_fwd": ([_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp], _i),
     "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),
     "mmdit_ln_modulate_bwd_gated": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], _i),

@@ -360,6 +360,65 @@ def ln_modulate_fwd_res(x, acc, gate, scale, shift, rows_per_batch, out_dtype):
     return x1, out, mean, rstd
 
 
+def ln_modulate_fwd_pair(pa, pb, out_dtype):
+    """Two adaLN forward problems of the same width in ONE launch (the image and the text stream of a block; mmdit_ln_modulate_fwd_pair).
+    pa / pb: dicts with x, scale, shift, rpb and -- both or neither -- acc, gate (the pending gated residual update, as in
+    ln_modulate_fwd_res).  Returns [(x1, out, mean, rstd), (x1, out, mean, rstd)] (x1 is x itself without acc)."""
+    res = pa.get("acc") is not None
+    assert (pb.get("acc") is not None) == res
+    d = pa["x"].shape[1]
+    probs, outs = (_lib.LnFwdProblem * 2)(), []
+    for q, p in zip(probs, (pa, pb)):
+        x = _c(p["x"])
+        rows = x.shape[0]
+        dev = x.device
+        x1 = torch.empty((rows, d), dtype=torch.float32, device=dev) if res else x
+        out = torch.empty((rows, d), dtype=out_dtype, device=dev)
+        mean = torch.empty((rows,), dtype=torch.float32, device=dev)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=dev)
+        q.x, q.scale, q.shift, q.ld_mod, q.rows, q.rows_per_batch = _p(x), _p(p["scale"]), _p(p["shift"]), p["scale"].stride(0), rows, p["rpb"]
+        q.out, q.mean, q.rstd = _p(out), _p(mean), _p(rstd)
+        if res:
+            acc = _c(p["acc"])
+            q.acc, q.gate, q.ld_gate, q.x_out = _p(acc), _p(p["gate"]), p["gate"].stride(0), _p(x1)
+            p["_keep"] = (x, acc)
+        else:
+            p["_keep"] = (x,)
+        outs.append((x1, out, mean, rstd))
+    acc_dt = _dt(pa["acc"]) if res else _DT[out_dtype]
+    check(_lib.lib().mmdit_ln_modulate_fwd_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), d, acc_dt, _DT[out_dtype], _s()), "mmdit_ln_modulate_fwd_pair")
+    return outs
+
+
+def ln_modulate_bwd_pair(pa, pb):
+    """Two adaLN backward problems in one launch (mmdit_ln_modulate_bwd_pair).  pa / pb: dicts with dout, x, mean, rstd, scale, dres (or
+    None), rpb, dscale, dshift and -- both or neither -- gated = (acc, gate, dgate, dbias | None).  Returns [dx or (dx, dacc)] * 2."""
+    gated = pa.get("gated") is not None
+    assert (pb.get("gated") is not None) == gated
+    d = pa["x"].shape[1]
+    probs, outs, keep = (_lib.LnBwdProblem * 2)(), [], []
+    for q, p in zip(probs, (pa, pb)):
+        dout, x = _c(p["dout"]), p["x"]
+        rows, dev = x.shape[0], x.device
+        dx = torch.empty((rows, d), dtype=torch.float32, device=dev)
+        q.dout, q.x, q.mean, q.rstd, q.scale, q.ld_mod = _p(dout), _p(x), _p(p["mean"]), _p(p["rstd"]), _p(p["scale"]), p["scale"].stride(0)
+        q.dres, q.rows, q.rows_per_batch = _p(p.get("dres")), rows, p["rpb"]
+        q.dx, q.dscale, q.dshift, q.ld_dmod = _p(dx), _p(p["dscale"]), _p(p["dshift"]), p["dscale"].stride(0)
+        keep.append(dout)
+        if gated:
+            acc, gate, dgate, dbias = p["gated"]
+            acc = _c(acc)
+            dacc = torch.empty((rows, d), dtype=acc.dtype, device=dev)
+            q.acc, q.gate, q.ld_gate, q.dacc, q.dgate, q.ld_dgate = _p(acc), _p(gate), gate.stride(0), _p(dacc), _p(dgate), dgate.stride(0)
+            q.dbias, q.ld_dbias = _p(dbias), (dbias.stride(0) if dbias is not None else 0)
+            keep.append(acc)
+            outs.append((dx, dacc))
+        else:
+            outs.append(dx)
+    check(_lib.lib().mmdit_ln_modulate_bwd_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), d, _dt(pa["dout"]), _s()), "mmdit_ln_modulate_bwd_pair")
+    return outs
+
+
 def gate_residual_fwd(x, acc, gate, rows_per_batch):
     """x + gate[b] * acc (fp32)."""
     rows, d = x.shape

@@ -520,6 +520,51 @@ def test_gemm_zero_mask_marks_exactly_the_outputs_that_receive_atomics(ops):
         assert torch.isfinite(o).all() and rel(o, ref) < 2e-5
 
 
+@pytest.mark.parametrize("res", [False, True])
+def test_ln_modulate_pair_launch_equals_two_launches(ops, res):
+    """mmdit_ln_modulate_fwd_pair / _bwd_pair (image + text stream of a block in one launch) are the single-problem kernels run on two
+    problems: outputs bit-identical, the atomically accumulated per-sample sums equal up to the order of the atomics."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    B, N, Mt, d = 4, 64, 39, 256
+    rnd = lambda *s: torch.randn(s, generator=g, device="cuda")
+    P = []
+    for rpb in (N, Mt):
+        rows = B * rpb
+        P.append(dict(x=rnd(rows, d) * 2, scale=rnd(B, d) * 0.3, shift=rnd(B, d) * 0.3, rpb=rpb, acc=rnd(rows, d).to(torch.bfloat16), gate=rnd(B, d),
+                      dout=rnd(rows, d).to(torch.bfloat16), dres=rnd(rows, d)))
+    fw = lambda p: (ops.ln_modulate_fwd_res(p["x"], p["acc"], p["gate"], p["scale"], p["shift"], p["rpb"], torch.bfloat16) if res
+                    else (p["x"],) + ops.ln_modulate_fwd(p["x"], p["scale"], p["shift"], p["rpb"], torch.bfloat16))
+    single = [fw(p) for p in P]
+    sel = lambda p: {k: p[k] for k in (("x", "scale", "shift", "rpb", "acc", "gate") if res else ("x", "scale", "shift", "rpb"))}
+    pair = ops.ln_modulate_fwd_pair(sel(P[0]), sel(P[1]), torch.bfloat16)
+    for a, b in zip(single, pair):
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    # backward
+    outs = {}
+    for mode in ("single", "pair"):
+        args = []
+        for p, f in zip(P, single):
+            x1, _, mean, rstd = f
+            a = dict(dout=p["dout"], x=x1, mean=mean, rstd=rstd, scale=p["scale"], dres=p["dres"], rpb=p["rpb"],
+                     dscale=torch.zeros_like(p["scale"]), dshift=torch.zeros_like(p["scale"]))
+            if res:
+                a["gated"] = (p["acc"], p["gate"], torch.zeros_like(p["gate"]), torch.zeros_like(p["gate"]))
+            args.append(a)
+        if mode == "single":
+            r = [ops.ln_modulate_bwd(a["dout"], a["x"], a["mean"], a["rstd"], a["scale"], a["dres"], a["rpb"], a["dscale"], a["dshift"], gated=a.get("gated")) for a in args]
+        else:
+            r = ops.ln_modulate_bwd_pair(args[0], args[1])
+        outs[mode] = (r, args)
+    for (ra, aa), (rb, ab) in zip(zip(*outs["single"]), zip(*outs["pair"])):
+        for u, v in zip(ra if isinstance(ra, tuple) else (ra,), rb if isinstance(rb, tuple) else (rb,)):
+            assert torch.equal(u, v)
+        for k in ("dscale", "dshift"):
+            assert rel(ab[k], aa[k]) < 1e-5
+        if res:
+            assert rel(ab["gated"][2], aa["gated"][2]) < 1e-5 and rel(ab["gated"][3], aa["gated"][3]) < 1e-5
+
+
 def _mx_reference(x):
     """torch restatement of mmdit_mxfp8_quantize: (e4m3 codes as uint8 (rows, K), E8M0 bytes in the GEMM layout [K/64][rows][2], dequantised fp32)."""
     rows, K = x.shape
