@@ -184,7 +184,7 @@ def _wgrad_flush(m, pending):
         off = 0
         for (_, d), (a, b), n in zip(pending, shapes, sizes):
             d["out"] = arena[off:off + a * b].view(a, b)
-            d["out"]._mmdit_zero_check = True
+            d["out"]._mmdit_zero_check = arena     # (the arena itself: neighbouring outputs that need a zero-fill share one launch)
             off += n
     if overlap:
         # inputs must outlive the side-stream reads (record_stream below)

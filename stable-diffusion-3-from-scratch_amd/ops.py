@@ -174,14 +174,28 @@ def gemm_grouped(problems):
     n = len(problems)
     arr = (GemmArgs * n)()
     outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
-    if any(getattr(o, "_mmdit_zero_check", False) for o in outs):
+    if any(getattr(o, "_mmdit_zero_check", None) is not None for o in outs):
         mask = ctypes.c_uint(0)
         check(_lib.lib().mmdit_gemm_zero_mask(arr, n, ctypes.byref(mask)), "mmdit_gemm_zero_mask")
+        spans = []          # [arena, first element, end element): flagged outputs that are neighbours in one arena share a fill launch
         for i, o in enumerate(outs):
-            if getattr(o, "_mmdit_zero_check", False):
-                if (mask.value >> i) & 1:
-                    o.zero_()
-                del o._mmdit_zero_check
+            arena = getattr(o, "_mmdit_zero_check", None)
+            if arena is None:
+                continue
+            del o._mmdit_zero_check
+            if not (mask.value >> i) & 1:
+                continue
+            if arena is True:
+                o.zero_()
+                continue
+            b = (o.data_ptr() - arena.data_ptr()) // 4
+            e = (b + o.numel() + 3) // 4 * 4
+            if spans and spans[-1][0] is arena and spans[-1][2] == b:
+                spans[-1][2] = e
+            else:
+                spans.append([arena, b, e])
+        for arena, b, e in spans:
+            arena[b:min(e, arena.numel())].zero_()
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

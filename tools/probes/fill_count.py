@@ -1,4 +1,4 @@
-"""Which host call sites launch fill / memset kernels in a steady-state training step?  (torch profiler with stacks)"""
+"""Which host call sites launch fill / memset / copy kernels in a steady-state training step?  (torch profiler with stacks)"""
 import os, sys, collections
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -24,7 +24,7 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     torch.cuda.synchronize()
 cnt, kern = collections.Counter(), collections.Counter()
 for e in prof.events():
-    if e.name.startswith("aten::") and any(k in e.name for k in ("zero", "fill", "full")):
+    if e.name.startswith("aten::") and any(k in e.name for k in ("zero", "fill", "full", "copy_", "clone", "contiguous", "cat")):
         site = next((f for f in (e.stack or []) if "sd3_amd" in f or "stable-diffusion" in f), "?")
         cnt[(e.name, site.strip()[-110:])] += 1
     if "Fill" in e.name or "fill" in e.name.lower() and "aten" not in e.name:
