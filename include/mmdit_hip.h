@@ -244,6 +244,16 @@ int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void* dV, int d
                            const float* rope_cos, const float* rope_sin,
                            int batch, int tokens, int heads, int s_total, int tok0,
                            void* dqkv, int dqkv_dtype, float* dwq, float* dwk, mmdit_stream_t stream);
+/* The image and the text rows of a block in ONE launch (both write / read the same joint Q, K, V at their own token offset; the text
+ * problem has rope_cos = rope_sin = NULL): same arithmetic as two mmdit_qk_norm_rope_fwd / _bwd calls, one ramp-up and tail. */
+typedef struct mmdit_qk_problem {
+  const void* qkv; const float* wq; const float* wk; const float* rope_cos; const float* rope_sin; int tokens, tok0;
+  void* dqkv; float* dwq; float* dwk;      /* backward only */
+} mmdit_qk_problem;
+int mmdit_qk_norm_rope_fwd_pair(const mmdit_qk_problem* p0, const mmdit_qk_problem* p1, int qkv_dtype, int batch, int heads, int s_total,
+                                void* Q, void* K, void* V, mmdit_stream_t stream);
+int mmdit_qk_norm_rope_bwd_pair(const mmdit_qk_problem* p0, const mmdit_qk_problem* p1, const void* dQ, const void* dK, const void* dV, int dq_dtype,
+                                int qkv_dtype, int dqkv_dtype, int batch, int heads, int s_total, mmdit_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * Joint softmax attention core, non-causal, head_dim 64, bf16 operands, fp32 accumulate.
@@ -272,6 +282,9 @@ int mmdit_swiglu_fwd(const void* gu, void* h, int dtype, int rows, int hidden, m
 int mmdit_swiglu_bwd(const void* dh, const void* gu, void* dgu, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t stream);
 int mmdit_gelu_fwd(const void* u, void* h, int dtype, int rows, int hidden, mmdit_stream_t stream);
 int mmdit_gelu_bwd(const void* dh, const void* u, void* du, int dtype, int rows, int hidden, float* dbias, mmdit_stream_t stream);
+/* mmdit_swiglu_bwd / mmdit_gelu_bwd (gelu != 0) of two problems of the same hidden width -- the image and the text MLP of a block -- in one launch */
+typedef struct mmdit_mlp_bwd_problem { const void* dh; const void* gu; void* dgu; int rows; float* dbias; } mmdit_mlp_bwd_problem;
+int mmdit_mlp_act_bwd_pair(const mmdit_mlp_bwd_problem* p0, const mmdit_mlp_bwd_problem* p1, int dtype, int hidden, int gelu, mmdit_stream_t stream);
 /* d(pre) = dy * silu'(pre): y_proj's SiLU (Transformer_Block_Dual.py:25-28). dbias accumulates column sums. */
 int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, int dpre_dtype, int rows, int cols, float* dbias, int rows_per_bias,
                    mmdit_stream_t stream);   /* rows_per_bias > 0: dbias is (rows / rows_per_bias, cols), one row per group of rows (stacked blocks) */

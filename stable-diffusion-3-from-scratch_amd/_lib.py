@@ -54,6 +54,15 @@ class LnBwdProblem(ctypes.Structure):      # mirrors mmdit_ln_bwd_problem
                 ("ld_dgate", ctypes.c_int64), ("dbias", ctypes.c_void_p), ("ld_dbias", ctypes.c_int64)]
 
 
+class QkProblem(ctypes.Structure):        # mirrors mmdit_qk_problem
+    _fields_ = [("qkv", ctypes.c_void_p), ("wq", ctypes.c_void_p), ("wk", ctypes.c_void_p), ("rope_cos", ctypes.c_void_p), ("rope_sin", ctypes.c_void_p),
+                ("tokens", ctypes.c_int), ("tok0", ctypes.c_int), ("dqkv", ctypes.c_void_p), ("dwq", ctypes.c_void_p), ("dwk", ctypes.c_void_p)]
+
+
+class MlpBwdProblem(ctypes.Structure):     # mirrors mmdit_mlp_bwd_problem
+    _fields_ = [("dh", ctypes.c_void_p), ("gu", ctypes.c_void_p), ("dgu", ctypes.c_void_p), ("rows", ctypes.c_int), ("dbias", ctypes.c_void_p)]
+
+
 _SIGNATURES = {
     "mmdit_abi_version": ([], _i),
     "mmdit_build_arch": ([], ctypes.c_char_p),
@@ -73,6 +82,9 @@ _SIGNATURES = {
     "mmdit_ln_modulate_fwd_res": ([_vp, _vp, _i, _vp, _i64, _vp, _vp, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_ln_modulate_fwd_pair": ([ctypes.POINTER(LnFwdProblem), ctypes.POINTER(LnFwdProblem), _i, _i, _i, _vp], _i),
     "mmdit_ln_modulate_bwd_pair": ([ctypes.POINTER(LnBwdProblem), ctypes.POINTER(LnBwdProblem), _i, _i, _vp], _i),
+    "mmdit_qk_norm_rope_fwd_pair": ([ctypes.POINTER(QkProblem), ctypes.POINTER(QkProblem), _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
+    "mmdit_qk_norm_rope_bwd_pair": ([ctypes.POINTER(QkProblem), ctypes.POINTER(QkProblem), _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp], _i),
+    "mmdit_mlp_act_bwd_pair": ([ctypes.POINTER(MlpBwdProblem), ctypes.POINTER(MlpBwdProblem), _i, _i, _i, _vp], _i),
     "mmdit_gate_residual_fwd": ([_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _vp], _i),
     "mmdit_ln_modulate_bwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp], _i),
     "mmdit_ln_modulate_bwd_gated": ([_vp, _i, _vp, _vp, _vp, _vp, _i64, _vp, _i, _i, _i, _vp, _vp, _vp, _i64, _vp, _i, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp], _i),

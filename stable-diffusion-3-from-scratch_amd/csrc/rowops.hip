@@ -376,28 +376,28 @@ __device__ __forceinline__ float group8_sum(float v) {
 // head, 8-element chunk), no per-element index divisions, norm weights in registers), rows blockIdx.x, + gridDim.x, ... two in
 // flight; with the grid a multiple of the tokens per sample all rows of a workgroup are the same token and the RoPE factors are
 // loaded once.
+// (bid, rstride) = this workgroup's index and the number of workgroups of ITS problem (the pair kernel runs two problems in one grid)
 template <typename TI>
-__global__ __launch_bounds__(1024) void qk_norm_rope_fwd_kernel(const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
-                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                                int rows, int tokens, int heads, int s_total, int tok0,
-                                                                bf16_t* __restrict__ Q, bf16_t* __restrict__ K, bf16_t* __restrict__ V) {
+__device__ __forceinline__ void qk_norm_rope_fwd_body(int bid, int rstride, const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                      const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                      int rows, int tokens, int heads, int s_total, int tok0,
+                                                      bf16_t* __restrict__ Q, bf16_t* __restrict__ K, bf16_t* __restrict__ V) {
   const int hc = threadIdx.x % (8 * heads), part = threadIdx.x / (8 * heads), head = hc >> 3, chunk = hc & 7;
   bf16_t* obase = part == 0 ? Q : part == 1 ? K : V;
   float w[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) w[e] = 0.f;
   if (part < 2) ld8((part == 0 ? wq : wk) + chunk * 8, w);
-  const int rstride = gridDim.x;
   const bool same_token = rcos && rstride % tokens == 0;
   float cs[2][8], sn[2][8];
   if (same_token && part < 2) {
-    const int n = blockIdx.x % tokens;
+    const int n = bid % tokens;
     ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[0]);
     ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[0]);
 #pragma unroll
     for (int e = 0; e < 8; e++) { cs[1][e] = cs[0][e]; sn[1][e] = sn[0][e]; }
   }
-  for (int row0 = blockIdx.x; row0 < rows; row0 += 2 * rstride) {
+  for (int row0 = bid; row0 < rows; row0 += 2 * rstride) {
     float x[2][8];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -436,16 +436,36 @@ __global__ __launch_bounds__(1024) void qk_norm_rope_fwd_kernel(const TI* __rest
     }
   }
 }
+template <typename TI>
+__global__ __launch_bounds__(1024) void qk_norm_rope_fwd_kernel(const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                                int rows, int tokens, int heads, int s_total, int tok0,
+                                                                bf16_t* __restrict__ Q, bf16_t* __restrict__ K, bf16_t* __restrict__ V) {
+  qk_norm_rope_fwd_body<TI>((int)blockIdx.x, (int)gridDim.x, qkv, wq, wk, rcos, rsin, rows, tokens, heads, s_total, tok0, Q, K, V);
+}
+// the image and the text rows of a block in one launch (workgroups [0, g0) = problem 0): same Q / K / V, different token ranges
+struct QkProb {
+  const void* qkv; const float* wq; const float* wk; const float* rcos; const float* rsin; int rows, tokens, tok0;
+  const void* dQ; const void* dK; const void* dV; void* dqkv; float* dwq; float* dwk;      // (backward only)
+};
+template <typename TI>
+__global__ __launch_bounds__(1024) void qk_norm_rope_fwd_pair_kernel(QkProb p0, QkProb p1, int g0, int heads, int s_total,
+                                                                     bf16_t* __restrict__ Q, bf16_t* __restrict__ K, bf16_t* __restrict__ V) {
+  const bool first = (int)blockIdx.x < g0;     // (workgroup-uniform)
+  const QkProb& p = first ? p0 : p1;
+  qk_norm_rope_fwd_body<TI>(first ? (int)blockIdx.x : (int)blockIdx.x - g0, first ? g0 : (int)gridDim.x - g0, (const TI*)p.qkv, p.wq, p.wk, p.rcos, p.rsin,
+                            p.rows, p.tokens, heads, s_total, p.tok0, Q, K, V);
+}
 
 // Backward: a workgroup has 24 * heads threads = one qkv row (thread = (part, head, 8-element chunk): no per-element index
 // divisions, the q/k norm weights stay in registers) and walks rows blockIdx.x, + gridDim.x, ... two at a time; the grid is
 // small (2 workgroups per CU) because every workgroup ends with 128 global atomics on the same two cache lines.
 template <typename TG, typename TI, typename TO>
-__global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
-                                                                const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
-                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
-                                                                int rows, int tokens, int heads, int s_total, int tok0,
-                                                                TO* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk) {
+__device__ __forceinline__ void qk_norm_rope_bwd_body(int bid, int rstride, const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
+                                                      const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                      const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                      int rows, int tokens, int heads, int s_total, int tok0,
+                                                      TO* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk) {
   __shared__ float sdw[2][64];
   for (int i = threadIdx.x; i < 128; i += blockDim.x) sdw[i >> 6][i & 63] = 0.f;
   __syncthreads();
@@ -455,18 +475,17 @@ __global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __rest
 #pragma unroll
   for (int e = 0; e < 8; e++) { w[e] = 0.f; aw[e] = 0.f; }
   if (part < 2) ld8((part == 0 ? wq : wk) + chunk * 8, w);
-  const int rstride = gridDim.x;
   // grid a multiple of the tokens per sample: every row of this workgroup is the same token, its RoPE factors are loaded once
   const bool same_token = rcos && rstride % tokens == 0;
   float cs[2][8], sn[2][8];
   if (same_token && part < 2) {
-    const int n = blockIdx.x % tokens;
+    const int n = bid % tokens;
     ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[0]);
     ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[0]);
 #pragma unroll
     for (int e = 0; e < 8; e++) { cs[1][e] = cs[0][e]; sn[1][e] = sn[0][e]; }
   }
-  for (int row0 = blockIdx.x; row0 < rows; row0 += 2 * rstride) {
+  for (int row0 = bid; row0 < rows; row0 += 2 * rstride) {
     float dz[2][8], x[2][8];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
@@ -523,6 +542,21 @@ __global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __rest
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 128; i += blockDim.x) atomicAdd((i < 64 ? dwq : dwk) + (i & 63), sdw[i >> 6][i & 63]);
+}
+template <typename TG, typename TI, typename TO>
+__global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
+                                                                const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
+                                                                const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                                int rows, int tokens, int heads, int s_total, int tok0,
+                                                                TO* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk) {
+  qk_norm_rope_bwd_body<TG, TI, TO>((int)blockIdx.x, (int)gridDim.x, dQ, dK, dV, qkv, wq, wk, rcos, rsin, rows, tokens, heads, s_total, tok0, dqkv, dwq, dwk);
+}
+template <typename TG, typename TI, typename TO>
+__global__ __launch_bounds__(1024) void qk_norm_rope_bwd_pair_kernel(QkProb p0, QkProb p1, int g0, int heads, int s_total) {
+  const bool first = (int)blockIdx.x < g0;     // (workgroup-uniform)
+  const QkProb& p = first ? p0 : p1;
+  qk_norm_rope_bwd_body<TG, TI, TO>(first ? (int)blockIdx.x : (int)blockIdx.x - g0, first ? g0 : (int)gridDim.x - g0, (const TG*)p.dQ, (const TG*)p.dK, (const TG*)p.dV,
+                                    (const TI*)p.qkv, p.wq, p.wk, p.rcos, p.rsin, p.rows, p.tokens, heads, s_total, p.tok0, (TO*)p.dqkv, p.dwq, p.dwk);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -598,8 +632,8 @@ constexpr int MB_RCH = 128;
 // activation backward: a workgroup covers 256 columns x MB_RCH rows (32 column groups of 8 x 8 row lanes, two rows in flight
 // per thread); the bias-gradient column sums cost one atomic per column and workgroup.  grid = (hidden / 256, rows / MB_RCH)
 template <typename T, bool GELU>
-__global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ gu, T* __restrict__ dgu,
-                                                          int rows, int hidden, float* __restrict__ dbias) {
+__device__ __forceinline__ void mlp_act_bwd_body(int by, const T* __restrict__ dh, const T* __restrict__ gu, T* __restrict__ dgu,
+                                                 int rows, int hidden, float* __restrict__ dbias) {
   __shared__ float sbuf[8 * 256];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 256 + tx * 8;
@@ -608,9 +642,9 @@ __global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ 
   float sg[8], su[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { sg[e] = 0.f; su[e] = 0.f; }
-  const int rend = min(rows, (int)(blockIdx.y + 1) * MB_RCH);
+  const int rend = min(rows, (by + 1) * MB_RCH);
   if (act) {
-    for (int r0 = blockIdx.y * MB_RCH + ty; r0 < rend; r0 += 16) {
+    for (int r0 = by * MB_RCH + ty; r0 < rend; r0 += 16) {
       float d[2][8], g[2][8], u[2][8];
 #pragma unroll
       for (int k = 0; k < 2; k++) {
@@ -660,6 +694,19 @@ __global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ 
       __syncthreads();
     }
   }
+}
+template <typename T, bool GELU>
+__global__ __launch_bounds__(256) void mlp_act_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ gu, T* __restrict__ dgu,
+                                                          int rows, int hidden, float* __restrict__ dbias) {
+  mlp_act_bwd_body<T, GELU>((int)blockIdx.y, dh, gu, dgu, rows, hidden, dbias);
+}
+// two problems of the same hidden width (the image and the text MLP of a block) in one launch: blockIdx.y in [0, nby0) = problem 0
+struct MlpBwdProb { const void* dh; const void* gu; void* dgu; int rows; float* dbias; };
+template <typename T, bool GELU>
+__global__ __launch_bounds__(256) void mlp_act_bwd_pair_kernel(MlpBwdProb p0, MlpBwdProb p1, int nby0, int hidden) {
+  const bool first = (int)blockIdx.y < nby0;     // (workgroup-uniform)
+  const MlpBwdProb& p = first ? p0 : p1;
+  mlp_act_bwd_body<T, GELU>(first ? (int)blockIdx.y : (int)blockIdx.y - nby0, (const T*)p.dh, (const T*)p.gu, (T*)p.dgu, p.rows, hidden, p.dbias);
 }
 
 constexpr int GR_RCH = 64;
@@ -1052,6 +1099,74 @@ extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void
   else if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(bf16_t, float, float);
   else return MMDIT_ERR_DTYPE;
 #undef QKB
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_qk_norm_rope_fwd_pair(const mmdit_qk_problem* a, const mmdit_qk_problem* b, int qkv_dtype, int batch, int heads, int s_total,
+                                           void* Q, void* K, void* V, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(a && b && Q && K && V && batch > 0 && heads > 0 && 24 * heads <= 1024);
+  const mmdit_qk_problem* src[2] = {a, b};
+  QkProb q[2];
+  int g[2];
+  for (int i = 0; i < 2; i++) {
+    const mmdit_qk_problem* p = src[i];
+    MMDIT_CHECK_ARG(p->qkv && p->wq && p->wk && p->tokens > 0 && p->tok0 >= 0 && p->tok0 + p->tokens <= s_total && (p->rope_cos == nullptr) == (p->rope_sin == nullptr));
+    const int rows = batch * p->tokens;
+    g[i] = rows < 1024 ? rows : 1024;
+    if (p->rope_cos && p->tokens <= 1024) g[i] = (g[i] / p->tokens > 0 ? g[i] / p->tokens : 1) * p->tokens;
+    q[i] = QkProb{p->qkv, p->wq, p->wk, p->rope_cos, p->rope_sin, rows, p->tokens, p->tok0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(g[0] + g[1]);
+  if (qkv_dtype == MMDIT_BF16) hipLaunchKernelGGL((qk_norm_rope_fwd_pair_kernel<bf16_t>), grid, dim3(24 * heads), 0, s, q[0], q[1], g[0], heads, s_total, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
+  else if (qkv_dtype == MMDIT_F32) hipLaunchKernelGGL((qk_norm_rope_fwd_pair_kernel<float>), grid, dim3(24 * heads), 0, s, q[0], q[1], g[0], heads, s_total, (bf16_t*)Q, (bf16_t*)K, (bf16_t*)V);
+  else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_qk_norm_rope_bwd_pair(const mmdit_qk_problem* a, const mmdit_qk_problem* b, const void* dQ, const void* dK, const void* dV, int dq_dtype,
+                                           int qkv_dtype, int dqkv_dtype, int batch, int heads, int s_total, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(a && b && dQ && dK && dV && batch > 0 && heads > 0 && 24 * heads <= 1024);
+  const mmdit_qk_problem* src[2] = {a, b};
+  QkProb q[2];
+  int g[2];
+  for (int i = 0; i < 2; i++) {
+    const mmdit_qk_problem* p = src[i];
+    MMDIT_CHECK_ARG(p->qkv && p->wq && p->wk && p->dqkv && p->dwq && p->dwk && p->tokens > 0 && p->tok0 >= 0 && p->tok0 + p->tokens <= s_total &&
+                    (p->rope_cos == nullptr) == (p->rope_sin == nullptr));
+    const int rows = batch * p->tokens;
+    g[i] = rows < 512 ? rows : 512;          // (<= 2 workgroups per CU and problem: see qk_norm_rope_bwd_kernel)
+    if (p->rope_cos && p->tokens <= 1024) g[i] = (g[i] / p->tokens > 0 ? g[i] / p->tokens : 1) * p->tokens;
+    q[i] = QkProb{p->qkv, p->wq, p->wk, p->rope_cos, p->rope_sin, rows, p->tokens, p->tok0, dQ, dK, dV, p->dqkv, p->dwq, p->dwk};
+  }
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(g[0] + g[1]);
+#define QKP(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_pair_kernel<TG, TI, TO>), grid, dim3(24 * heads), 0, s, q[0], q[1], g[0], heads, s_total)
+  if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_BF16 && dqkv_dtype == MMDIT_BF16) QKP(bf16_t, bf16_t, bf16_t);
+  else if (dq_dtype == MMDIT_F32 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKP(float, float, float);
+  else if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKP(bf16_t, float, float);
+  else return MMDIT_ERR_DTYPE;
+#undef QKP
+  return mmdit_launch_status();
+}
+
+extern "C" int mmdit_mlp_act_bwd_pair(const mmdit_mlp_bwd_problem* a, const mmdit_mlp_bwd_problem* b, int dtype, int hidden, int gelu, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(a && b && hidden > 0 && hidden % 8 == 0);
+  const mmdit_mlp_bwd_problem* src[2] = {a, b};
+  MlpBwdProb q[2];
+  int nby[2];
+  for (int i = 0; i < 2; i++) {
+    MMDIT_CHECK_ARG(src[i]->dh && src[i]->gu && src[i]->dgu && src[i]->rows > 0);
+    q[i] = MlpBwdProb{src[i]->dh, src[i]->gu, src[i]->dgu, src[i]->rows, src[i]->dbias};
+    nby[i] = (src[i]->rows + MB_RCH - 1) / MB_RCH;
+  }
+  dim3 grid((hidden + 255) / 256, nby[0] + nby[1]);
+  hipStream_t s = (hipStream_t)stream;
+#define MBP(T, G) hipLaunchKernelGGL((mlp_act_bwd_pair_kernel<T, G>), grid, dim3(256), 0, s, q[0], q[1], nby[0], hidden)
+  if (dtype == MMDIT_BF16) { if (gelu) MBP(bf16_t, true); else MBP(bf16_t, false); }
+  else if (dtype == MMDIT_F32) { if (gelu) MBP(float, true); else MBP(float, false); }
+  else return MMDIT_ERR_DTYPE;
+#undef MBP
   return mmdit_launch_status();
 }
 

@@ -334,8 +334,11 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     sv.qkv_x, sv.qkv_c = _group(m, [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T)], fp8=True)
     sv.Q = torch.empty((B, H, S, 64), dtype=BF16, device=dev)
     sv.K, sv.V = torch.empty_like(sv.Q), torch.empty_like(sv.Q)
-    ops.qk_norm_rope_fwd(sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, sv.Q, sv.K, sv.V)
-    ops.qk_norm_rope_fwd(sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, sv.Q, sv.K, sv.V)
+    if _LN_PAIR and dev.type == "cuda":      # image + text rows in one launch
+        ops.qk_norm_rope_fwd_pair((sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], N, 0), (sv.qkv_c, w.wq_c, w.wk_c, None, None, Mt, N), B, H, S, sv.Q, sv.K, sv.V)
+    else:
+        ops.qk_norm_rope_fwd(sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, sv.Q, sv.K, sv.V)
+        ops.qk_norm_rope_fwd(sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, sv.Q, sv.K, sv.V)
     if mxf:
         sv.Oxa, sv.Oca = ops.attn_fwd_mx(sv.Q, sv.K, sv.V, N, 64 ** -0.5)
     else:
@@ -466,12 +469,17 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None,
     ops.colsum(bpart, bdown)   # finish both bias gradients: sum the per-batch partial rows
     dh = _group(m, probs)
     defer(g.mlp_x, "Wdown", dacc_x, sv.h_x)
-    dgu_x = ops.mlp_act_bwd(dh[0], sv.gu_x, w.mlp_x.hidden, g.mlp_x.bup, w.mlp_x.gelu)
+    pair = both and _LN_PAIR and dev.type == "cuda" and w.mlp_x.hidden == w.mlp_c.hidden and w.mlp_x.gelu == w.mlp_c.gelu
+    if pair:     # image + text activation backward in one launch
+        dgu_x, dgu_c = ops.mlp_act_bwd_pair((dh[0], sv.gu_x, g.mlp_x.bup), (dh[1], sv.gu_c, g.mlp_c.bup), w.mlp_x.hidden, w.mlp_x.gelu)
+    else:
+        dgu_x = ops.mlp_act_bwd(dh[0], sv.gu_x, w.mlp_x.hidden, g.mlp_x.bup, w.mlp_x.gelu)
     probs = [dict(A=dgu_x, B=w.mlp_x.Wup, b_kmajor=True, out_dtype=m.T)]
     defer(g.mlp_x, "Wup", dgu_x, sv.ln2x)
     if both:
         defer(g.mlp_c, "Wdown", dacc_c, sv.h_c)
-        dgu_c = ops.mlp_act_bwd(dh[1], sv.gu_c, w.mlp_c.hidden, g.mlp_c.bup, w.mlp_c.gelu)
+        if not pair:
+            dgu_c = ops.mlp_act_bwd(dh[1], sv.gu_c, w.mlp_c.hidden, g.mlp_c.bup, w.mlp_c.gelu)
         probs.append(dict(A=dgu_c, B=w.mlp_c.Wup, b_kmajor=True, out_dtype=m.T))
         defer(g.mlp_c, "Wup", dgu_c, sv.ln2c)
     dln2 = _group(m, probs)
@@ -508,8 +516,12 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None,
 
     # ---- attention core + QK norm / RoPE
     dQ, dK, dV = ops.attn_bwd(sv.Q, sv.K, sv.V, sv.Ox, sv.Oc, dOx, dOc, sv.lse, N, 64 ** -0.5, m.T)
-    dqkv_x = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, g.wq_x, g.wk_x, m.T)
-    dqkv_c = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, g.wq_c, g.wk_c, m.T)
+    if _LN_PAIR and dev.type == "cuda":
+        dqkv_x, dqkv_c = ops.qk_norm_rope_bwd_pair(dQ, dK, dV, (sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], N, 0, g.wq_x, g.wk_x),
+                                                   (sv.qkv_c, w.wq_c, w.wk_c, None, None, Mt, N, g.wq_c, g.wk_c), B, H, S, m.T)
+    else:
+        dqkv_x = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, g.wq_x, g.wk_x, m.T)
+        dqkv_c = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, g.wq_c, g.wk_c, m.T)
     dln1 = _group(m, [dict(A=dqkv_x, B=w.Wqkv_x, b_kmajor=True, out_dtype=m.T), dict(A=dqkv_c, B=w.Wqkv_c, b_kmajor=True, out_dtype=m.T)])
     defer(g, "Wqkv_x", dqkv_x, sv.ln1x)
     defer(g, "Wqkv_c", dqkv_c, sv.ln1c)

@@ -490,6 +490,32 @@ def qk_norm_rope_bwd(dQ, dK, dV, qkv, wq, wk, rope_cos, rope_sin, batch, tokens,
     return dqkv
 
 
+def qk_norm_rope_fwd_pair(img, txt, batch, heads, s_total, Q, K, V):
+    """The image and the text rows of a block in one launch (mmdit_qk_norm_rope_fwd_pair).  img / txt = (qkv, wq, wk, rope_cos, rope_sin,
+    tokens, tok0); both write the joint Q / K / V."""
+    probs, keep = (_lib.QkProblem * 2)(), []
+    for q, (qkv, wq, wk, rc, rs, tokens, tok0) in zip(probs, (img, txt)):
+        qkv = _c(qkv)
+        keep.append(qkv)
+        q.qkv, q.wq, q.wk, q.rope_cos, q.rope_sin, q.tokens, q.tok0 = _p(qkv), _p(wq), _p(wk), _p(rc), _p(rs), tokens, tok0
+    check(_lib.lib().mmdit_qk_norm_rope_fwd_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), _dt(img[0]), batch, heads, s_total, _p(Q), _p(K), _p(V), _s()),
+          "mmdit_qk_norm_rope_fwd_pair")
+
+
+def qk_norm_rope_bwd_pair(dQ, dK, dV, img, txt, batch, heads, s_total, out_dtype):
+    """Backward of both streams in one launch (mmdit_qk_norm_rope_bwd_pair).  img / txt = (qkv, wq, wk, rope_cos, rope_sin, tokens, tok0, dwq, dwk);
+    returns (dqkv_img, dqkv_txt)."""
+    probs, outs = (_lib.QkProblem * 2)(), []
+    for q, (qkv, wq, wk, rc, rs, tokens, tok0, dwq, dwk) in zip(probs, (img, txt)):
+        dqkv = torch.empty(qkv.shape, dtype=out_dtype, device=qkv.device)
+        q.qkv, q.wq, q.wk, q.rope_cos, q.rope_sin, q.tokens, q.tok0 = _p(qkv), _p(wq), _p(wk), _p(rc), _p(rs), tokens, tok0
+        q.dqkv, q.dwq, q.dwk = _p(dqkv), _p(dwq), _p(dwk)
+        outs.append(dqkv)
+    check(_lib.lib().mmdit_qk_norm_rope_bwd_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), _p(dQ), _p(dK), _p(dV), _dt(dQ), _dt(img[0]), _DT[out_dtype],
+                                                 batch, heads, s_total, _s()), "mmdit_qk_norm_rope_bwd_pair")
+    return outs
+
+
 def attn_fwd(Q, K, V, n_img, scale, mode):
     batch, heads, S, hd = Q.shape
     if hd != 64:
@@ -527,6 +553,19 @@ def mlp_act_bwd(dh, gu, hidden, dbias, gelu=False):
     fn = _lib.lib().mmdit_gelu_bwd if gelu else _lib.lib().mmdit_swiglu_bwd
     check(fn(_p(_c(dh)), _p(gu), _p(dgu), _dt(gu), rows, hidden, _p(dbias), _s()), "mmdit_mlp_act_bwd")
     return dgu
+
+
+def mlp_act_bwd_pair(a, b, hidden, gelu=False):
+    """mlp_act_bwd of two problems of the same hidden width in one launch (mmdit_mlp_act_bwd_pair).  a / b = (dh, gu, dbias); returns [dgu, dgu]."""
+    probs, outs, keep = (_lib.MlpBwdProblem * 2)(), [], []
+    for q, (dh, gu, dbias) in zip(probs, (a, b)):
+        dh = _c(dh)
+        dgu = torch.empty_like(gu)
+        q.dh, q.gu, q.dgu, q.rows, q.dbias = _p(dh), _p(gu), _p(dgu), gu.shape[0], _p(dbias)
+        keep.append(dh)
+        outs.append(dgu)
+    check(_lib.lib().mmdit_mlp_act_bwd_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), _dt(a[1]), hidden, int(gelu), _s()), "mmdit_mlp_act_bwd_pair")
+    return outs
 
 
 def silu_bwd(dy, pre, out_dtype, dbias, rows_per_bias=0):

@@ -193,6 +193,60 @@ def test_qk_norm_rope(ops, dt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Bt,H,h2,w2,Mtxt", [(2, 3, 4, 6, 10), (8, 12, 16, 16, 154)])
+def test_qk_norm_rope_pair_launch_equals_two_launches(ops, dt, Bt, H, h2, w2, Mtxt):
+    """mmdit_qk_norm_rope_{fwd,bwd}_pair (image + text rows of a block in one launch) == the two single-stream launches: outputs
+    bit-identical, the atomically accumulated norm-weight gradients equal up to the order of the atomics."""
+    N = h2 * w2
+    S, d = N + Mtxt, H * 64
+    cos, sin = _rope_tables(h2, w2)
+    wqx, wkx, wqc, wkc = (1 + 0.1 * rnd(64, seed=i) for i in (1, 2, 3, 4))
+    qkv_x, qkv_c = rnd(Bt * N, 3 * d, seed=5).to(dt), rnd(Bt * Mtxt, 3 * d, seed=6).to(dt)
+    outs = []
+    for pair in (False, True):
+        Q = torch.zeros((Bt, H, S, 64), dtype=torch.bfloat16, device="cuda")
+        K, V = torch.zeros_like(Q), torch.zeros_like(Q)
+        if pair:
+            ops.qk_norm_rope_fwd_pair((qkv_x, wqx, wkx, cos, sin, N, 0), (qkv_c, wqc, wkc, None, None, Mtxt, N), Bt, H, S, Q, K, V)
+        else:
+            ops.qk_norm_rope_fwd(qkv_x, wqx, wkx, cos, sin, Bt, N, H, S, 0, Q, K, V)
+            ops.qk_norm_rope_fwd(qkv_c, wqc, wkc, None, None, Bt, Mtxt, H, S, N, Q, K, V)
+        outs.append((Q, K, V))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    dQ, dK, dV = (rnd(Bt, H, S, 64, seed=i).to(dt) for i in (7, 8, 9))
+    res = []
+    for pair in (False, True):
+        dw = [torch.zeros(64, device="cuda") for _ in range(4)]
+        if pair:
+            dx, dc = ops.qk_norm_rope_bwd_pair(dQ, dK, dV, (qkv_x, wqx, wkx, cos, sin, N, 0, dw[0], dw[1]), (qkv_c, wqc, wkc, None, None, Mtxt, N, dw[2], dw[3]), Bt, H, S, dt)
+        else:
+            dx = ops.qk_norm_rope_bwd(dQ, dK, dV, qkv_x, wqx, wkx, cos, sin, Bt, N, H, S, 0, dw[0], dw[1], dt)
+            dc = ops.qk_norm_rope_bwd(dQ, dK, dV, qkv_c, wqc, wkc, None, None, Bt, Mtxt, H, S, N, dw[2], dw[3], dt)
+        res.append((dx, dc, dw))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2], res[1][2]):
+        assert rel(b, a) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("gelu", [False, True])
+def test_mlp_act_bwd_pair_launch_equals_two_launches(ops, dt, gelu):
+    hidden = 1536
+    P = []
+    for i, rows in enumerate((300, 77)):
+        P.append((rnd(rows, hidden, seed=10 + i).to(dt), rnd(rows, hidden if gelu else 2 * hidden, seed=20 + i).to(dt)))
+    db1 = [torch.zeros(P[0][1].shape[1], device="cuda") for _ in P]
+    single = [ops.mlp_act_bwd(dh, gu, hidden, db, gelu) for (dh, gu), db in zip(P, db1)]
+    db2 = [torch.zeros(P[0][1].shape[1], device="cuda") for _ in P]
+    pair = ops.mlp_act_bwd_pair((P[0][0], P[0][1], db2[0]), (P[1][0], P[1][1], db2[1]), hidden, gelu)
+    for a, b in zip(single, pair):
+        assert torch.equal(a, b)
+    for a, b in zip(db1, db2):
+        assert rel(b, a) < 1e-5
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("gelu", [False, True])
 def test_mlp_act(ops, dt, gelu):
     rows, hidden = 300, 1536
