@@ -329,6 +329,11 @@ def test_gate_residual_bwd_colsum_silu(ops, dt):
     cs = torch.zeros(d, device="cuda")
     ops.colsum(acc, cs)
     assert rel(cs, acc.float().sum(0)) < 2e-5
+    for r_small in (5, 64, 200):         # few rows: the 8-row-chunk launch shape (per-sample partial sums of a block)
+        part = rnd(r_small, 2 * d, seed=6)
+        cs2 = torch.zeros(2 * d, device="cuda")
+        ops.colsum(part, cs2)
+        assert rel(cs2, part.sum(0)) < 2e-5
     pre = rnd(Bt, d, seed=4)
     dyy = rnd(Bt, d, seed=5)
     pr = pre.clone().requires_grad_(True)
