@@ -3,7 +3,8 @@ python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench.err
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace -d gpurun_out/prof_$R -o run -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/${R}_prof.log 2>&1
 DB=$(find gpurun_out/prof_$R -name "*.db" | head -1)
-python tools/rocpd_stats.py $DB 11 > gpurun_out/${R}_bench_kernel_stats.txt
+# steps in the trace: 3 eager warm-up steps (capture needs >= 3) + 2 warm replays + 10 timed replays
+python tools/rocpd_stats.py $DB 15 > gpurun_out/${R}_bench_kernel_stats.txt
 python tools/rocpd_gaps.py $DB > gpurun_out/${R}_step_gaps.txt 2>&1
 rm -rf gpurun_out/prof_$R
 bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
@@ -19,5 +20,6 @@ bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
   echo "== tools/probes/fp8_bench.py"; python tools/probes/fp8_bench.py 2>&1 | grep -v amdgpu | tail -6
   echo "== tools/probes/blaslt_ref.py"; python tools/probes/blaslt_ref.py 2>&1 | grep -v amdgpu
   echo "== tools/vae_bench.py"; python tools/vae_bench.py 2>&1 | grep -v amdgpu | tail -4
-  echo "== bench.py --graph"; python bench.py --no-cpu-baseline --no-roofline --graph 2>/dev/null | cut -c1-200
+  echo "== bench.py --eager"; python bench.py --no-cpu-baseline --no-roofline --eager 2>/dev/null | cut -c1-200
+  echo "== bench.py (hipGraph replay, default)"; python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
 ) > gpurun_out/${R}_probe_outputs.txt 2>&1
