@@ -460,7 +460,9 @@ __global__ __launch_bounds__(1024) void qk_norm_rope_fwd_pair_kernel(QkProb p0, 
 // Backward: a workgroup has 24 * heads threads = one qkv row (thread = (part, head, 8-element chunk): no per-element index
 // divisions, the q/k norm weights stay in registers) and walks rows blockIdx.x, + gridDim.x, ... two at a time; the grid is
 // small (2 workgroups per CU) because every workgroup ends with 128 global atomics on the same two cache lines.
-template <typename TG, typename TI, typename TO>
+// FAST: every problem of the launch either has no RoPE or walks ONE token per row lane (lanes % tokens == 0): a single copy of the RoPE
+// factors, loaded once -- 16 registers fewer than the general path, which kept the kernel at the 128-VGPR cap with spills
+template <bool FAST, typename TG, typename TI, typename TO>
 __device__ __forceinline__ void qk_norm_rope_bwd_body(int bid, int rstride, const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
                                                       const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
                                                       const float* __restrict__ rcos, const float* __restrict__ rsin,
@@ -469,21 +471,26 @@ __device__ __forceinline__ void qk_norm_rope_bwd_body(int bid, int rstride, cons
   __shared__ float sdw[2][64];
   for (int i = threadIdx.x; i < 128; i += blockDim.x) sdw[i >> 6][i & 63] = 0.f;
   __syncthreads();
-  const int hc = threadIdx.x % (8 * heads), part = threadIdx.x / (8 * heads), head = hc >> 3, chunk = hc & 7;
+  // a workgroup is RL row lanes of 24 * heads threads: RL rows per iteration share ONE set of 128 global atomics at the end
+  const int per_row = 24 * heads, rlane = threadIdx.x / per_row, t = threadIdx.x - rlane * per_row;
+  { const int RL = blockDim.x / per_row; bid = bid * RL + rlane; rstride *= RL; }
+  const int hc = t % (8 * heads), part = t / (8 * heads), head = hc >> 3, chunk = hc & 7;
   const TG* gbase = part == 0 ? dQ : part == 1 ? dK : dV;
   float w[8], aw[8];
 #pragma unroll
   for (int e = 0; e < 8; e++) { w[e] = 0.f; aw[e] = 0.f; }
   if (part < 2) ld8((part == 0 ? wq : wk) + chunk * 8, w);
   // grid a multiple of the tokens per sample: every row of this workgroup is the same token, its RoPE factors are loaded once
-  const bool same_token = rcos && rstride % tokens == 0;
-  float cs[2][8], sn[2][8];
+  const bool same_token = FAST ? rcos != nullptr : (rcos && rstride % tokens == 0);
+  float cs[FAST ? 1 : 2][8], sn[FAST ? 1 : 2][8];
   if (same_token && part < 2) {
     const int n = bid % tokens;
     ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[0]);
     ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[0]);
+    if constexpr (!FAST) {
 #pragma unroll
-    for (int e = 0; e < 8; e++) { cs[1][e] = cs[0][e]; sn[1][e] = sn[0][e]; }
+      for (int e = 0; e < 8; e++) { cs[1][e] = cs[0][e]; sn[1][e] = sn[0][e]; }
+    }
   }
   for (int row0 = bid; row0 < rows; row0 += 2 * rstride) {
     float dz[2][8], x[2][8];
@@ -495,9 +502,11 @@ __device__ __forceinline__ void qk_norm_rope_bwd_body(int bid, int rstride, cons
         ld8_nt(gbase + (((int64_t)b * heads + head) * s_total + tok0 + n) * 64 + chunk * 8, dz[k]);      // (single use; the saved qkv below: last use)
         if (part < 2) {
           ld8_nt(qkv + (((int64_t)row * 3 + part) * heads + head) * 64 + chunk * 8, x[k]);
-          if (rcos && !same_token) {
-            ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[k]);
-            ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[k]);
+          if constexpr (!FAST) {
+            if (rcos && !same_token) {
+              ld8(rcos + (int64_t)n * 64 + chunk * 8, cs[k]);
+              ld8(rsin + (int64_t)n * 64 + chunk * 8, sn[k]);
+            }
           }
         }
       }
@@ -515,8 +524,8 @@ __device__ __forceinline__ void qk_norm_rope_bwd_body(int bid, int rstride, cons
 #pragma unroll
           for (int p = 0; p < 4; p++) {
             float da = dz[k][2 * p], db = dz[k][2 * p + 1];
-            dz[k][2 * p] = da * cs[k][2 * p] + db * sn[k][2 * p + 1];
-            dz[k][2 * p + 1] = db * cs[k][2 * p + 1] - da * sn[k][2 * p];
+            dz[k][2 * p] = da * cs[FAST ? 0 : k][2 * p] + db * sn[FAST ? 0 : k][2 * p + 1];
+            dz[k][2 * p + 1] = db * cs[FAST ? 0 : k][2 * p + 1] - da * sn[FAST ? 0 : k][2 * p];
           }
         }
         float dot = 0.f;
@@ -543,19 +552,19 @@ __device__ __forceinline__ void qk_norm_rope_bwd_body(int bid, int rstride, cons
   __syncthreads();
   for (int i = threadIdx.x; i < 128; i += blockDim.x) atomicAdd((i < 64 ? dwq : dwk) + (i & 63), sdw[i >> 6][i & 63]);
 }
-template <typename TG, typename TI, typename TO>
+template <bool FAST, typename TG, typename TI, typename TO>
 __global__ __launch_bounds__(1024) void qk_norm_rope_bwd_kernel(const TG* __restrict__ dQ, const TG* __restrict__ dK, const TG* __restrict__ dV,
                                                                 const TI* __restrict__ qkv, const float* __restrict__ wq, const float* __restrict__ wk,
                                                                 const float* __restrict__ rcos, const float* __restrict__ rsin,
                                                                 int rows, int tokens, int heads, int s_total, int tok0,
                                                                 TO* __restrict__ dqkv, float* __restrict__ dwq, float* __restrict__ dwk) {
-  qk_norm_rope_bwd_body<TG, TI, TO>((int)blockIdx.x, (int)gridDim.x, dQ, dK, dV, qkv, wq, wk, rcos, rsin, rows, tokens, heads, s_total, tok0, dqkv, dwq, dwk);
+  qk_norm_rope_bwd_body<FAST, TG, TI, TO>((int)blockIdx.x, (int)gridDim.x, dQ, dK, dV, qkv, wq, wk, rcos, rsin, rows, tokens, heads, s_total, tok0, dqkv, dwq, dwk);
 }
-template <typename TG, typename TI, typename TO>
+template <bool FAST, typename TG, typename TI, typename TO>
 __global__ __launch_bounds__(1024) void qk_norm_rope_bwd_pair_kernel(QkProb p0, QkProb p1, int g0, int heads, int s_total) {
   const bool first = (int)blockIdx.x < g0;     // (workgroup-uniform)
   const QkProb& p = first ? p0 : p1;
-  qk_norm_rope_bwd_body<TG, TI, TO>(first ? (int)blockIdx.x : (int)blockIdx.x - g0, first ? g0 : (int)gridDim.x - g0, (const TG*)p.dQ, (const TG*)p.dK, (const TG*)p.dV,
+  qk_norm_rope_bwd_body<FAST, TG, TI, TO>(first ? (int)blockIdx.x : (int)blockIdx.x - g0, first ? g0 : (int)gridDim.x - g0, (const TG*)p.dQ, (const TG*)p.dK, (const TG*)p.dV,
                                     (const TI*)p.qkv, p.wq, p.wk, p.rcos, p.rsin, p.rows, p.tokens, heads, s_total, p.tok0, (TO*)p.dqkv, p.dwq, p.dwk);
 }
 
@@ -1082,6 +1091,30 @@ extern "C" int mmdit_qk_norm_rope_fwd(const void* qkv, int qkv_dtype, const floa
   return mmdit_launch_status();
 }
 
+// Launch shape of the QK-norm/RoPE backward: RL row lanes per workgroup (as many as fit 1024 threads; every workgroup ends with 128
+// global atomics on the same two cache lines, so fewer, fatter workgroups), `lanes` rows in flight per iteration pair, a multiple of the
+// tokens per sample when RoPE applies (same token for all rows of a lane: factors loaded once).
+static int qk_bwd_rl(int heads, int min_rows) {
+  static const int env = [] { const char* e = getenv("MMDIT_QK_RL"); return e ? atoi(e) : 0; }();
+  int rl = 1024 / (24 * heads);
+  if (env > 0 && env < rl) rl = env;
+  if (rl < 1 || min_rows < 2048) rl = 1;
+  return rl;
+}
+static int qk_bwd_grid(int rows, int tokens, bool rope, int& rl) {
+  static const int lanes_max = [] { const char* e = getenv("MMDIT_QK_LANES"); return e ? atoi(e) : 768; }();
+  if (rl == 1) {
+    int g = rows < 512 ? rows : 512;
+    if (rope && tokens <= 1024 && rows >= tokens) g = (g / tokens > 0 ? g / tokens : 1) * tokens;
+    return g;
+  }
+  if (!rope || tokens > lanes_max) return lanes_max / rl;
+  int k = lanes_max / tokens;
+  while (k > 1 && (k * tokens) % rl) k--;
+  if ((k * tokens) % rl) return lanes_max / rl;       // (lanes then walk all tokens: factors reloaded per row)
+  return k * tokens / rl;
+}
+
 extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void* dV, int dq_dtype, const void* qkv, int qkv_dtype,
                                       const float* wq, const float* wk, const float* rope_cos, const float* rope_sin,
                                       int batch, int tokens, int heads, int s_total, int tok0, void* dqkv, int dqkv_dtype, float* dwq, float* dwk, mmdit_stream_t stream) {
@@ -1090,11 +1123,11 @@ extern "C" int mmdit_qk_norm_rope_bwd(const void* dQ, const void* dK, const void
   hipStream_t s = (hipStream_t)stream;
   MMDIT_CHECK_ARG(heads >= 1 && 24 * heads <= 1024);   // one row per workgroup of 24*heads threads
   const int rows = batch * tokens;
-  // <= 2 workgroups per CU (atomics, see the kernel), rounded to a multiple of the tokens per sample when RoPE applies
-  int g = rows < 512 ? rows : 512;
-  if (rope_cos && tokens <= 1024 && rows >= tokens) g = (g / tokens > 0 ? g / tokens : 1) * tokens;
-  dim3 grid(g);
-#define QKB(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<TG, TI, TO>), grid, dim3(24 * heads), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, rows, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk)
+  int rl = qk_bwd_rl(heads, rows);
+  dim3 grid(qk_bwd_grid(rows, tokens, rope_cos != nullptr, rl));
+  const bool fast = !rope_cos || ((int)grid.x * rl) % tokens == 0;
+#define QKB(TG, TI, TO) do { if (fast) hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<true, TG, TI, TO>), grid, dim3(24 * heads * rl), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, rows, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk); \
+  else hipLaunchKernelGGL((qk_norm_rope_bwd_kernel<false, TG, TI, TO>), grid, dim3(24 * heads * rl), 0, s, (const TG*)dQ, (const TG*)dK, (const TG*)dV, (const TI*)qkv, wq, wk, rope_cos, rope_sin, rows, tokens, heads, s_total, tok0, (TO*)dqkv, dwq, dwk); } while (0)
   if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_BF16 && dqkv_dtype == MMDIT_BF16) QKB(bf16_t, bf16_t, bf16_t);
   else if (dq_dtype == MMDIT_F32 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(float, float, float);
   else if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKB(bf16_t, float, float);
@@ -1135,14 +1168,16 @@ extern "C" int mmdit_qk_norm_rope_bwd_pair(const mmdit_qk_problem* a, const mmdi
     const mmdit_qk_problem* p = src[i];
     MMDIT_CHECK_ARG(p->qkv && p->wq && p->wk && p->dqkv && p->dwq && p->dwk && p->tokens > 0 && p->tok0 >= 0 && p->tok0 + p->tokens <= s_total &&
                     (p->rope_cos == nullptr) == (p->rope_sin == nullptr));
-    const int rows = batch * p->tokens;
-    g[i] = rows < 512 ? rows : 512;          // (<= 2 workgroups per CU and problem: see qk_norm_rope_bwd_kernel)
-    if (p->rope_cos && p->tokens <= 1024) g[i] = (g[i] / p->tokens > 0 ? g[i] / p->tokens : 1) * p->tokens;
-    q[i] = QkProb{p->qkv, p->wq, p->wk, p->rope_cos, p->rope_sin, rows, p->tokens, p->tok0, dQ, dK, dV, p->dqkv, p->dwq, p->dwk};
+    q[i] = QkProb{p->qkv, p->wq, p->wk, p->rope_cos, p->rope_sin, batch * p->tokens, p->tokens, p->tok0, dQ, dK, dV, p->dqkv, p->dwq, p->dwk};
   }
+  int rl = qk_bwd_rl(heads, q[0].rows < q[1].rows ? q[0].rows : q[1].rows);     // (one block shape for both problems)
+  for (int i = 0; i < 2; i++) g[i] = qk_bwd_grid(q[i].rows, q[i].tokens, q[i].rcos != nullptr, rl);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(g[0] + g[1]);
-#define QKP(TG, TI, TO) hipLaunchKernelGGL((qk_norm_rope_bwd_pair_kernel<TG, TI, TO>), grid, dim3(24 * heads), 0, s, q[0], q[1], g[0], heads, s_total)
+  bool fast = true;
+  for (int i = 0; i < 2; i++) fast = fast && (!q[i].rcos || (g[i] * rl) % q[i].tokens == 0);
+#define QKP(TG, TI, TO) do { if (fast) hipLaunchKernelGGL((qk_norm_rope_bwd_pair_kernel<true, TG, TI, TO>), grid, dim3(24 * heads * rl), 0, s, q[0], q[1], g[0], heads, s_total); \
+  else hipLaunchKernelGGL((qk_norm_rope_bwd_pair_kernel<false, TG, TI, TO>), grid, dim3(24 * heads * rl), 0, s, q[0], q[1], g[0], heads, s_total); } while (0)
   if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_BF16 && dqkv_dtype == MMDIT_BF16) QKP(bf16_t, bf16_t, bf16_t);
   else if (dq_dtype == MMDIT_F32 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKP(float, float, float);
   else if (dq_dtype == MMDIT_BF16 && qkv_dtype == MMDIT_F32 && dqkv_dtype == MMDIT_F32) QKP(bf16_t, float, float);
