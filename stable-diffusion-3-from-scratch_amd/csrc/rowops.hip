@@ -139,7 +139,10 @@ __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __r
 // (X_out = acc * gate[b] + X_in, Transformer_Block_Dual.py:64-76: dx is d(X_out)): dacc = dx * gate[b] for the producing GEMM's
 // dgrad / wgrad, dgate[b] += sum_rows dx * acc, dbias[b] += sum_rows dacc (per-batch partial rows of the projection's bias
 // gradient) -- dx is in registers here, so the separate pass over it (mmdit_gate_residual_bwd) disappears.
-constexpr int LN_BWD_RCH = 16;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
+#ifndef LN_BWD_RCH_V
+#define LN_BWD_RCH_V 16
+#endif
+constexpr int LN_BWD_RCH = LN_BWD_RCH_V;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
 template <int NIT, typename TG, typename TA, bool GATED>
 __device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
                                                 const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
@@ -151,16 +154,21 @@ __device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict_
   const int b = block / nchunk, chunk = block % nchunk;
   const int nch = d >> 2;
   const float* sc = scale + (int64_t)b * ld_mod;
-  float a1[NIT][4], ds[NIT][4], dh[NIT][4];
-  float gt[GATED ? NIT : 1][4], sg[GATED ? NIT : 1][4], sb[GATED ? NIT : 1][4];
+  // the sample's (1 + scale) and gate rows live in LDS and are re-read per row (2 x NIT ds_read_b128): as loop-invariant registers they
+  // cost 8 * NIT VGPRs, which put the gated d = 768 kernel at 150 VGPRs = 3 waves per SIMD; without them it fits 4
+  __shared__ float s_a1[NIT * 256], s_gt[GATED ? NIT * 256 : 4];
+  for (int c = threadIdx.x; c < NIT * 256; c += 256) {
+    s_a1[c] = c < d ? sc[c] + 1.f : 0.f;
+    if constexpr (GATED) s_gt[c] = c < d ? gate[(int64_t)b * ld_gate + c] : 0.f;
+  }
+  __syncthreads();
+  float ds[NIT][4], dh[NIT][4];
+  float sg[GATED ? NIT : 1][4], sb[GATED ? NIT : 1][4];
 #pragma unroll
   for (int it = 0; it < NIT; it++) {
-    int ch = lane + 64 * it;
-    if (ch < nch) { ld4(sc + ch * 4, a1[it]); } else { a1[it][0] = a1[it][1] = a1[it][2] = a1[it][3] = 0.f; }
 #pragma unroll
-    for (int e = 0; e < 4; e++) { a1[it][e] += 1.f; ds[it][e] = 0.f; dh[it][e] = 0.f; }
+    for (int e = 0; e < 4; e++) { ds[it][e] = 0.f; dh[it][e] = 0.f; }
     if constexpr (GATED) {
-      if (ch < nch) { ld4(gate + (int64_t)b * ld_gate + ch * 4, gt[it]); } else { gt[it][0] = gt[it][1] = gt[it][2] = gt[it][3] = 0.f; }
 #pragma unroll
       for (int e = 0; e < 4; e++) { sg[it][e] = 0.f; sb[it][e] = 0.f; }
     }
@@ -171,17 +179,19 @@ __device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict_
     const float mean = mean_i[row], rstd = rstd_i[row];
     float g[NIT][4], xh[NIT][4];
     float c1 = 0.f, c2 = 0.f;
+    asm volatile("" ::: "memory");      // (keeps the LDS reads of s_a1 / s_gt inside the row loop)
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       int ch = lane + 64 * it;
       if (ch < nch) {
-        float dy[4], xv[4];
+        float dy[4], xv[4], a1[4];
         ld4_nt(dout + row * d + ch * 4, dy);      // (dy, the saved residual row and acc are at their last use: streaming loads)
         ld4_nt(x + row * d + ch * 4, xv);
+        ld4(s_a1 + ch * 4, a1);
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           xh[it][e] = (xv[e] - mean) * rstd;
-          g[it][e] = dy[e] * a1[it][e];
+          g[it][e] = dy[e] * a1[e];
           c1 += g[it][e]; c2 += g[it][e] * xh[it][e];
           ds[it][e] += dy[e] * xh[it][e]; dh[it][e] += dy[e];
         }
@@ -198,10 +208,11 @@ __device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict_
         for (int e = 0; e < 4; e++) o[e] += rstd * (g[it][e] - c1 - xh[it][e] * c2);
         st4(dx + row * d + ch * 4, o);
         if constexpr (GATED) {
-          float av[4], da[4];
+          float av[4], da[4], gt[4];
           ld4_nt(acc + row * d + ch * 4, av);
+          ld4(s_gt + ch * 4, gt);
 #pragma unroll
-          for (int e = 0; e < 4; e++) { da[e] = o[e] * gt[it][e]; sg[it][e] += o[e] * av[e]; sb[it][e] += da[e]; }
+          for (int e = 0; e < 4; e++) { da[e] = o[e] * gt[e]; sg[it][e] += o[e] * av[e]; sb[it][e] += da[e]; }
           st4(dacc + row * d + ch * 4, da);
         }
       }
@@ -262,8 +273,11 @@ struct LnBwdProb {
   float* dx; float* dscale; float* dshift; int64_t ld_dmod;
   const void* acc; const float* gate; int64_t ld_gate; void* dacc; float* dgate; int64_t ld_dgate; float* dbias; int64_t ld_dbias;
 };
+#ifndef LN_BWD_ATTR
+#define LN_BWD_ATTR
+#endif
 template <int NIT, typename TG, typename TA, bool GATED>
-__global__ __launch_bounds__(256) void ln_mod_bwd_pair_kernel(LnBwdProb p0, LnBwdProb p1, int nblk0, int d) {
+__global__ __launch_bounds__(256) LN_BWD_ATTR void ln_mod_bwd_pair_kernel(LnBwdProb p0, LnBwdProb p1, int nblk0, int d) {
   const bool first = (int)blockIdx.x < nblk0;     // (workgroup-uniform)
   const LnBwdProb& p = first ? p0 : p1;
   ln_mod_bwd_body<NIT, TG, TA, GATED>(first ? (int)blockIdx.x : (int)blockIdx.x - nblk0, (const TG*)p.dout, p.x, p.mean, p.rstd, p.scale, p.ld_mod, p.dres, d, p.rpb, p.nchunk,

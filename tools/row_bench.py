@@ -60,6 +60,15 @@ dout, dres = rnd(M, d, dt=BF), rnd(M, d)
 dsc, dsh = torch.zeros(B, d, device="cuda"), torch.zeros(B, d, device="cuda")
 if mean is not None:
     timed("ln_mod_bwd", lambda: ops.ln_modulate_bwd(dout, x, mean, rstd, sc, dres, N, dsc, dsh), M * d * 14)
+    # gated form (the one the training step runs): + acc read, dacc write, dgate / dbias column sums
+    accb, gate_, dgate_, dbias_ = rnd(M, d, dt=BF), rnd(B, d), torch.zeros(B, d, device="cuda"), torch.zeros(B, d, device="cuda")
+    timed("ln_mod_bwd gated", lambda: ops.ln_modulate_bwd(dout, x, mean, rstd, sc, dres, N, dsc, dsh, gated=(accb, gate_, dgate_, dbias_)), M * d * 18)
+    Mt_ = B * 154
+    xt_, doutt_, drest_, acct_ = rnd(Mt_, d), rnd(Mt_, d, dt=BF), rnd(Mt_, d), rnd(Mt_, d, dt=BF)
+    yt_ = ops.ln_modulate_fwd(xt_, sc, sh, 154, BF)
+    pa_ = dict(dout=dout, x=x, mean=mean, rstd=rstd, scale=sc, dres=dres, rpb=N, dscale=dsc, dshift=dsh, gated=(accb, gate_, dgate_, dbias_))
+    pb_ = dict(dout=doutt_, x=xt_, mean=yt_[1], rstd=yt_[2], scale=sc, dres=drest_, rpb=154, dscale=dsc, dshift=dsh, gated=(acct_, gate_, dgate_, dbias_))
+    timed("ln_mod_bwd gated img+txt pair", lambda: ops.ln_modulate_bwd_pair(pa_, pb_), (M + Mt_) * d * 18)
 # swiglu fwd / bwd
 gu = rnd(M, 2 * h, dt=BF)
 timed("swiglu_fwd", lambda: ops.mlp_act_fwd(gu, h), M * h * 6)
