@@ -167,10 +167,12 @@ def main():
     torch.manual_seed(1234)
     net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu", device=dev,
                      positional_encoding="RoPE2d", checkpoint_MLP=False, checkpoint_attn=False, **B_CFG)
-    trainer = model_trainer(net, batchSize=args.batch, accumulation_steps=1, totalSteps=10 ** 9, lr=1e-4, ema_update_freq=10 ** 9, ema_decay=0.999,
-                            warmup_steps=1000, use_lr_scheduler=False, device=dev, saveDir="/tmp/bench_ckpt", numSaveSteps=10 ** 9,
-                            null_prob_pooled=0.1, null_prob_gemma=0.316, null_prob_bert=0.316, use_amp=True, max_res=256,
-                            device_rng=True, use_ema=False, force_reducer=args.force_dist, hip_optimizer=not args.torch_optimizer)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # (the trainer prints the reference's "Number of parameters" line: stdout carries the JSON line only)
+        trainer = model_trainer(net, batchSize=args.batch, accumulation_steps=1, totalSteps=10 ** 9, lr=1e-4, ema_update_freq=10 ** 9, ema_decay=0.999,
+                                warmup_steps=1000, use_lr_scheduler=False, device=dev, saveDir="/tmp/bench_ckpt", numSaveSteps=10 ** 9,
+                                null_prob_pooled=0.1, null_prob_gemma=0.316, null_prob_bert=0.316, use_amp=True, max_res=256,
+                                device_rng=True, use_ema=False, force_reducer=args.force_dist, hip_optimizer=not args.torch_optimizer)
     if args.precision != "fast":
         net.set_precision(args.precision)
     net.train()

@@ -1122,7 +1122,8 @@ static int qk_bwd_grid(int rows, int tokens, bool rope, int& rl) {
     if (rope && tokens <= 1024 && rows >= tokens) g = (g / tokens > 0 ? g / tokens : 1) * tokens;
     return g;
   }
-  if (!rope || tokens > lanes_max) return lanes_max / rl;
+  if (!rope) return lanes_max / rl;
+  if (tokens > lanes_max) return tokens <= 2048 && tokens % rl == 0 ? tokens / rl : lanes_max / rl;      // (one lane per token: 512^2 images, 1024 tokens)
   int k = lanes_max / tokens;
   while (k > 1 && (k * tokens) % rl) k--;
   if ((k * tokens) % rl) return lanes_max / rl;       // (lanes then walk all tokens: factors reloaded per row)

@@ -150,7 +150,7 @@ def _rot_half(x):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Bt,H,h2,w2,Mtxt", [(2, 3, 4, 6, 10), (16, 12, 16, 16, 154)])    # (the second: >= 2048 rows, several row lanes per workgroup in the backward)
+@pytest.mark.parametrize("Bt,H,h2,w2,Mtxt", [(2, 3, 4, 6, 10), (16, 12, 16, 16, 154), (16, 16, 32, 32, 154)])    # (>= 2048 rows: several row lanes per workgroup in the backward; the last: MMDiT-L at 512^2)
 def test_qk_norm_rope(ops, dt, Bt, H, h2, w2, Mtxt):
     N = h2 * w2
     S = N + Mtxt
@@ -193,7 +193,7 @@ def test_qk_norm_rope(ops, dt, Bt, H, h2, w2, Mtxt):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Bt,H,h2,w2,Mtxt", [(2, 3, 4, 6, 10), (16, 12, 16, 16, 154)])
+@pytest.mark.parametrize("Bt,H,h2,w2,Mtxt", [(2, 3, 4, 6, 10), (16, 12, 16, 16, 154), (16, 16, 32, 32, 154)])
 def test_qk_norm_rope_pair_launch_equals_two_launches(ops, dt, Bt, H, h2, w2, Mtxt):
     """mmdit_qk_norm_rope_{fwd,bwd}_pair (image + text rows of a block in one launch) == the two single-stream launches: outputs
     bit-identical, the atomically accumulated norm-weight gradients equal up to the order of the atomics."""
