@@ -405,7 +405,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     return X2, C2, sv
 
 
-_LN_PAIR = _os.environ.get("MMDIT_LN_PAIR", "1") != "0"      # image + text adaLN kernels in one launch (A/B switch)
+_LN_PAIR = _os.environ.get("MMDIT_LN_PAIR", "1") != "0"      # image + text rows of the adaLN / QK-norm+RoPE / MLP-activation-backward kernels in one launch (A/B switch)
 _MX_FUSE = _os.environ.get("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
 _FUSE_GATE = _os.environ.get("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
 
