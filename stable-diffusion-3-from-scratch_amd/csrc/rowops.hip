@@ -139,10 +139,7 @@ __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __r
 // (X_out = acc * gate[b] + X_in, Transformer_Block_Dual.py:64-76: dx is d(X_out)): dacc = dx * gate[b] for the producing GEMM's
 // dgrad / wgrad, dgate[b] += sum_rows dx * acc, dbias[b] += sum_rows dacc (per-batch partial rows of the projection's bias
 // gradient) -- dx is in registers here, so the separate pass over it (mmdit_gate_residual_bwd) disappears.
-#ifndef LN_BWD_RCH_V
-#define LN_BWD_RCH_V 16
-#endif
-constexpr int LN_BWD_RCH = LN_BWD_RCH_V;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
+constexpr int LN_BWD_RCH = 16;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
 template <int NIT, typename TG, typename TA, bool GATED>
 __device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
                                                 const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
@@ -273,11 +270,8 @@ struct LnBwdProb {
   float* dx; float* dscale; float* dshift; int64_t ld_dmod;
   const void* acc; const float* gate; int64_t ld_gate; void* dacc; float* dgate; int64_t ld_dgate; float* dbias; int64_t ld_dbias;
 };
-#ifndef LN_BWD_ATTR
-#define LN_BWD_ATTR
-#endif
 template <int NIT, typename TG, typename TA, bool GATED>
-__global__ __launch_bounds__(256) LN_BWD_ATTR void ln_mod_bwd_pair_kernel(LnBwdProb p0, LnBwdProb p1, int nblk0, int d) {
+__global__ __launch_bounds__(256) void ln_mod_bwd_pair_kernel(LnBwdProb p0, LnBwdProb p1, int nblk0, int d) {
   const bool first = (int)blockIdx.x < nblk0;     // (workgroup-uniform)
   const LnBwdProb& p = first ? p0 : p1;
   ln_mod_bwd_body<NIT, TG, TA, GATED>(first ? (int)blockIdx.x : (int)blockIdx.x - nblk0, (const TG*)p.dout, p.x, p.mean, p.rstd, p.scale, p.ld_mod, p.dres, d, p.rpb, p.nchunk,
