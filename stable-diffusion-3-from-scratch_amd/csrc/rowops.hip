@@ -311,10 +311,22 @@ __global__ __launch_bounds__(256) void text_rms_fwd_kernel(const TI* __restrict_
   }
 }
 
+// Both halves of the 154 tokens in one launch (blockIdx.y = half); a workgroup is 8 waves x 4 rows.  Every workgroup ends with d
+// global atomics on the SAME d addresses (the weight gradient is not per sample), so the waves are first combined in LDS
+// (ds_add_f32) and the workgroups are as fat as the register budget allows: 154 atomics per address and launch instead of 2 x 308.
+struct TextRmsBwdHalf { const void* dout; const float* w; const float* sp; int rows, cnt, off; float* dw; float* dsp; };
 template <int NIT, typename TI, typename TG>
-__global__ __launch_bounds__(256) void text_rms_bwd_kernel(const TG* __restrict__ dout, const TI* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ sp, int rows, int cnt, int tokens, int off, int d,
-                                                           float* __restrict__ dw, float* __restrict__ dsp) {
+__global__ __launch_bounds__(512) void text_rms_bwd_kernel(TextRmsBwdHalf h0, TextRmsBwdHalf h1, const TI* __restrict__ x, int tokens, int d) {
+  const TextRmsBwdHalf& hp = blockIdx.y == 0 ? h0 : h1;     // (workgroup-uniform)
+  const TG* __restrict__ dout = (const TG*)hp.dout;
+  const float* __restrict__ w = hp.w;
+  const float* __restrict__ sp = hp.sp;
+  const int rows = hp.rows, cnt = hp.cnt, off = hp.off;
+  float* __restrict__ dw = hp.dw;
+  float* __restrict__ dsp = hp.dsp;
+  __shared__ float red[NIT * 256];
+  for (int c = threadIdx.x; c < NIT * 256; c += 512) red[c] = 0.f;
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = d >> 2;
   const float s = sp[0];
@@ -327,7 +339,7 @@ __global__ __launch_bounds__(256) void text_rms_bwd_kernel(const TG* __restrict_
 #pragma unroll
     for (int e = 0; e < 4; e++) accw[it][e] = 0.f;
   }
-  for (int m = blockIdx.x * 16 + wave; m < min(rows, (int)(blockIdx.x + 1) * 16); m += 4) {   // 16 rows per workgroup: enough workgroups to fill the chip
+  for (int m = blockIdx.x * 32 + wave; m < min(rows, (int)(blockIdx.x + 1) * 32); m += 8) {   // 32 rows per workgroup, 4 per wave
     const TI* xr = x + ((int64_t)(m / cnt) * tokens + off + m % cnt) * d;
     float v[NIT][4];
     float q = 0.f;
@@ -348,25 +360,16 @@ __global__ __launch_bounds__(256) void text_rms_bwd_kernel(const TG* __restrict_
       }
     }
   }
-  // the four waves are combined through LDS first: one atomic per column and workgroup (atomics are the expensive part)
-  __shared__ float red[3][NIT * 256];
-  if (wave > 0) {
 #pragma unroll
-    for (int it = 0; it < NIT; it++)
+  for (int it = 0; it < NIT; it++) {
+    const int ch = lane + 64 * it;
+    if (ch < nch) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) red[wave - 1][(lane + 64 * it) * 4 + e] = accw[it][e];
-  }
-  __syncthreads();
-  if (wave == 0) {
-#pragma unroll
-    for (int it = 0; it < NIT; it++) {
-      int ch = lane + 64 * it;
-      if (ch < nch) {
-#pragma unroll
-        for (int e = 0; e < 4; e++) atomicAdd(dw + ch * 4 + e, accw[it][e] + red[0][ch * 4 + e] + red[1][ch * 4 + e] + red[2][ch * 4 + e]);
-      }
+      for (int e = 0; e < 4; e++) atomicAdd(&red[ch * 4 + e], accw[it][e]);
     }
   }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 512) atomicAdd(dw + c, red[c]);
   accs = wave_sum(accs);
   if (lane == 0) atomicAdd(dsp, accs);
 }
@@ -1067,19 +1070,21 @@ extern "C" int mmdit_text_rmsnorm_bwd(const void* dout1, const void* dout2, int 
   MMDIT_CHECK_ARG(dout1 && dout2 && x && w1 && w2 && s1 && s2 && dw1 && dw2 && ds1 && ds2 && batch > 0 && split > 0 && split < tokens && d % 4 == 0 && d <= 4096);
   hipStream_t s = (hipStream_t)stream;
   const int nit = nit_for(d);
+  TextRmsBwdHalf h[2];
+  int maxrows = 0;
   for (int half = 0; half < 2; half++) {
-    const int cnt = half ? tokens - split : split, off = half ? split : 0, rows = batch * cnt;
-    const float* w = half ? w2 : w1; const float* sp = half ? s2 : s1; const void* dout = half ? dout2 : dout1;
-    float* dw = half ? dw2 : dw1; float* dsp = half ? ds2 : ds1;
-    dim3 grid((rows + 15) / 16);
-#define TRB(TI, TG) NIT_SWITCH(nit, hipLaunchKernelGGL((text_rms_bwd_kernel<NIT, TI, TG>), grid, dim3(256), 0, s, (const TG*)dout, (const TI*)x, w, sp, rows, cnt, tokens, off, d, dw, dsp))
-    if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_F32) { TRB(float, float); }
-    else if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_BF16) { TRB(float, bf16_t); }
-    else if (x_dtype == MMDIT_BF16 && dout_dtype == MMDIT_BF16) { TRB(bf16_t, bf16_t); }
-    else if (x_dtype == MMDIT_BF16 && dout_dtype == MMDIT_F32) { TRB(bf16_t, float); }
-    else return MMDIT_ERR_DTYPE;
-#undef TRB
+    const int cnt = half ? tokens - split : split, rows = batch * cnt;
+    h[half] = TextRmsBwdHalf{half ? dout2 : dout1, half ? w2 : w1, half ? s2 : s1, rows, cnt, half ? split : 0, half ? dw2 : dw1, half ? ds2 : ds1};
+    maxrows = rows > maxrows ? rows : maxrows;
   }
+  dim3 grid((maxrows + 31) / 32, 2);     // (a half with fewer rows: its surplus workgroups find an empty row range)
+#define TRB(TI, TG) NIT_SWITCH(nit, hipLaunchKernelGGL((text_rms_bwd_kernel<NIT, TI, TG>), grid, dim3(512), 0, s, h[0], h[1], (const TI*)x, tokens, d))
+  if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_F32) { TRB(float, float); }
+  else if (x_dtype == MMDIT_F32 && dout_dtype == MMDIT_BF16) { TRB(float, bf16_t); }
+  else if (x_dtype == MMDIT_BF16 && dout_dtype == MMDIT_BF16) { TRB(bf16_t, bf16_t); }
+  else if (x_dtype == MMDIT_BF16 && dout_dtype == MMDIT_F32) { TRB(bf16_t, float); }
+  else return MMDIT_ERR_DTYPE;
+#undef TRB
   return mmdit_launch_status();
 }
 

@@ -104,3 +104,9 @@ def _two_streams():
         ev2.record(_side)
     main.wait_event(ev2)
 timed("ln_mod_fwd img+txt, 2 streams", _two_streams, (M + Mc) * d * 6)
+# text pre-norm backward (both halves of the 154 tokens, d = 2304; once per step)
+xt = rnd(B, 154, 2304, dt=BF)
+w1_, w2_ = rnd(2304), rnd(2304)
+s1_, s2_ = torch.ones(1, device="cuda"), torch.ones(1, device="cuda")
+g1_, g2_ = rnd(B * 77, 2304, dt=BF), rnd(B * 77, 2304, dt=BF)
+timed("text_rmsnorm_bwd (2 halves)", lambda: ops.text_rmsnorm_bwd(g1_, g2_, xt, w1_, w2_, s1_, s2_, 77), B * 154 * 2304 * 4)
