@@ -938,6 +938,11 @@ inline int grid_cap(int64_t n, int bs) { int64_t g = (n + bs - 1) / bs; return (
     else NIT_CASE(16, __VA_ARGS__)                              \
   } while (0)
 
+// The adaLN forward keeps its range checks as well: its unguarded variant is 8 % faster (33.6 -> 31 us for image + text), but the
+// different instruction selection rounds a few outputs differently, and the MX-emitting variant of the kernel must stay bit-identical
+// to "plain kernel + quantise pass" (test_mxfp8_mode_vs_mx_oracle) while the parity mode sits 1.3 % under its 1e-3 bar.
+#define LN_FWD_NIT (NIT < 0 ? -NIT : NIT)
+
 extern "C" int mmdit_abi_version(void) { return 1; }
 extern "C" const char* mmdit_build_arch(void) { return "gfx950"; }
 
@@ -947,8 +952,8 @@ extern "C" int mmdit_ln_modulate_fwd(const float* x, const float* scale, const f
   hipStream_t s = (hipStream_t)stream;
   const int nit = nit_for(d);
   dim3 grid((rows + 3) / 4);
-  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, bf16_t, bf16_t, false>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd, nullptr, nullptr, 0, nullptr)); }
-  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, float, float, false>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd, nullptr, nullptr, 0, nullptr)); }
+  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<LN_FWD_NIT, bf16_t, bf16_t, false>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd, nullptr, nullptr, 0, nullptr)); }
+  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<LN_FWD_NIT, float, float, false>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd, nullptr, nullptr, 0, nullptr)); }
   else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }
@@ -961,8 +966,8 @@ extern "C" int mmdit_ln_modulate_fwd_res(const float* x, const void* acc, int ac
   hipStream_t s = (hipStream_t)stream;
   const int nit = nit_for(d);
   dim3 grid((rows + 3) / 4);
-  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, bf16_t, bf16_t, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd, (const bf16_t*)acc, gate, ld_gate, x_out)); }
-  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, float, float, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd, (const float*)acc, gate, ld_gate, x_out)); }
+  if (out_dtype == MMDIT_BF16) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<LN_FWD_NIT, bf16_t, bf16_t, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (bf16_t*)out, mean, rstd, (const bf16_t*)acc, gate, ld_gate, x_out)); }
+  else if (out_dtype == MMDIT_F32) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<LN_FWD_NIT, float, float, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, (float*)out, mean, rstd, (const float*)acc, gate, ld_gate, x_out)); }
   else return MMDIT_ERR_DTYPE;
   return mmdit_launch_status();
 }
@@ -977,8 +982,8 @@ extern "C" int mmdit_ln_modulate_fwd_mx(const float* x, const void* acc, int acc
   dim3 grid((rows + 3) / 4);
   unsigned char* q = (unsigned char*)q_fp8;
   unsigned char* sc = (unsigned char*)scales_e8m0;
-  if (acc) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, unsigned char, bf16_t, true, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, q, mean, rstd, (const bf16_t*)acc, gate, ld_gate, x_out, sc)); }
-  else { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<NIT, unsigned char, bf16_t, false, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, q, mean, rstd, nullptr, nullptr, 0, nullptr, sc)); }
+  if (acc) { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<LN_FWD_NIT, unsigned char, bf16_t, true, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, q, mean, rstd, (const bf16_t*)acc, gate, ld_gate, x_out, sc)); }
+  else { NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_kernel<LN_FWD_NIT, unsigned char, bf16_t, false, true>), grid, dim3(256), 0, s, x, scale, shift, ld_mod, rows, d, rpb, q, mean, rstd, nullptr, nullptr, 0, nullptr, sc)); }
   return mmdit_launch_status();
 }
 
@@ -1040,7 +1045,7 @@ extern "C" int mmdit_ln_modulate_fwd_pair(const mmdit_ln_fwd_problem* a, const m
   hipStream_t s = (hipStream_t)stream;
   const int nit = nit_for(d), nb0 = (a->rows + 3) / 4, nb1 = (b->rows + 3) / 4;
   dim3 grid(nb0 + nb1);
-#define LNP(TO, RES) NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_pair_kernel<NIT, TO, TO, RES>), grid, dim3(256), 0, s, q[0], q[1], nb0, d))
+#define LNP(TO, RES) NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_fwd_pair_kernel<LN_FWD_NIT, TO, TO, RES>), grid, dim3(256), 0, s, q[0], q[1], nb0, d))
   if (out_dtype == MMDIT_BF16) { if (res) { LNP(bf16_t, true); } else { LNP(bf16_t, false); } }
   else if (out_dtype == MMDIT_F32) { if (res) { LNP(float, true); } else { LNP(float, false); } }
   else return MMDIT_ERR_DTYPE;
