@@ -218,6 +218,16 @@ __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Probl
   const int wr = lane & 31, wc = lane >> 5;          // write side: row, 8-B half of the 16-B chunk
   const int rr = lane >> 3, rc = lane & 7;           // read side: row within the 8-row pass, 16-B chunk (8 columns)
   const int colw = n0 + wn * 64;                     // first column of this wave
+  // the wave's bias values, loaded back to back up front from a clamped column (see epilogue_swiglu)
+  float bv[NJ * 4][4];
+  if (bias) {
+#pragma unroll
+    for (int q = 0; q < NJ * 4; q++) {
+      const int c = colw + (q >> 2) * 32 + 8 * (q & 3) + 4 * wc;
+      ld4(bias + (c < p.N ? c : 0), bv[q]);
+      if (c >= p.N) bv[q][0] = bv[q][1] = bv[q][2] = bv[q][3] = 0.f;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; i++) {
 #pragma unroll
@@ -226,11 +236,8 @@ __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Probl
       for (int g = 0; g < 4; g++) {
         float v[4] = {acc[i][j][g * 4] * alpha, acc[i][j][g * 4 + 1] * alpha, acc[i][j][g * 4 + 2] * alpha, acc[i][j][g * 4 + 3] * alpha};
         if (bias) {
-          const int c = colw + j * 32 + 8 * g + 4 * wc;
-          float b4[4] = {0.f, 0.f, 0.f, 0.f};
-          if (c < p.N) ld4(bias + c, b4);
 #pragma unroll
-          for (int e = 0; e < 4; e++) v[e] += b4[e];
+          for (int e = 0; e < 4; e++) v[e] += bv[j * 4 + g][e];
         }
         if (gp.act == MMDIT_ACT_SILU) {
 #pragma unroll
@@ -276,6 +283,17 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
   const int h = p.N >> 1;
   const int wr = lane & 31, wc = lane >> 5;
   const int hc = tn * 128 + wn * 32;                 // first hidden index of this wave
+  // the wave's bias values, loaded back to back up front: inside the conversion loop every load sat in its own branch with its own
+  // wait (four serialized L2 round trips per epilogue)
+  float bgv[4][4], buv[4][4];
+  if (bias) {
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int c = hc + 8 * g + 4 * wc;
+      ld4(bias + c, bgv[g]);
+      ld4(bias + h + c, buv[g]);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < MI; i++) {
     u32x2 pa[4];
@@ -284,14 +302,8 @@ __device__ __forceinline__ void epilogue_swiglu(f32x16 (&acc)[MI][2], const Prob
       float vg[4] = {acc[i][0][g * 4] * alpha, acc[i][0][g * 4 + 1] * alpha, acc[i][0][g * 4 + 2] * alpha, acc[i][0][g * 4 + 3] * alpha};
       float vu[4] = {acc[i][1][g * 4] * alpha, acc[i][1][g * 4 + 1] * alpha, acc[i][1][g * 4 + 2] * alpha, acc[i][1][g * 4 + 3] * alpha};
       if (bias) {
-        const int c = hc + 8 * g + 4 * wc;
-        float b4[4];
-        ld4(bias + c, b4);
 #pragma unroll
-        for (int e = 0; e < 4; e++) vg[e] += b4[e];
-        ld4(bias + h + c, b4);
-#pragma unroll
-        for (int e = 0; e < 4; e++) vu[e] += b4[e];
+        for (int e = 0; e < 4; e++) { vg[e] += bgv[g][e]; vu[e] += buv[g][e]; }
       }
       const u32x2 pg = {pack_bf2(vg[0], vg[1]), pack_bf2(vg[2], vg[3])}, pu = {pack_bf2(vu[0], vu[1]), pack_bf2(vu[2], vu[3])};
       if (GU) {
