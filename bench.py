@@ -118,8 +118,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true", help="development A/B: torch's multi-tensor unscale/clip/AdamW kernels instead of the three HIP launches")
     ap.add_argument("--force-dist", action="store_true", help="development: run the N>1 code path (RCCL group + gradient reducer) with one rank")
-    ap.add_argument("--graph", action="store_true", help="(default on one rank) replay the optimizer step from a hipGraph captured after the warm-up")
-    ap.add_argument("--eager", action="store_true", help="issue every launch of every step from the host (the default with more than one rank: collectives are not captured)")
+    ap.add_argument("--graph", action="store_true", help="(default) replay the optimizer step from a hipGraph captured after the warm-up; with this flag a failed capture is an error instead of an eager fallback")
+    ap.add_argument("--eager", action="store_true", help="issue every launch of every step from the host")
     ap.add_argument("--precision", default="fast", choices=["fast", "parity"], help="development: parity = the 1e-3 mode (fp32 activations, 3-term split-bf16 GEMMs, "
                     "reference rounding points in attention); the headline metric is quoted on fast (= the reference's bf16 autocast)")
     ap.add_argument("--check-launch", action="store_true", help="rendezvous check only (gloo, no GPU): every rank joins the group, one all-reduce, rank 0 prints the world size")
@@ -187,42 +187,60 @@ def main():
     for _ in range(args.warmup):
         step += 1
         trainer.train_step(step)
-    # One rank: the timed steps replay a hipGraph of the whole optimizer step (data generation + forward + backward + clip + AdamW, ~430
-    # launches, one host call) -- the step is GPU-bound when the host is idle (eager 31.06 vs graph 30.77 ms/step same box), but a busy
-    # host core stretches the ~26 ms of eager enqueue past the GPU's 31 ms.  More ranks: eager (the gradient all-reduce is not captured).
-    use_graph = (args.graph or world == 1) and not args.eager
-    if args.graph:
-        assert world == 1, "--graph: single rank only"
-    launch = "eager"
+    # The timed steps replay a hipGraph of the whole optimizer step (forward + backward + per-block gradient all-reduce on its side
+    # stream + clip + AdamW, ~430 launches, one host call per step): the eager step needs ~26 ms of host enqueue per 30 ms of GPU
+    # work, so any host jitter stalls the GPU -- and with N ranks every stall is propagated to all of them by the next collective.
+    # The eager rate of the same trainer is measured first and reported next to it (`ms_per_step_eager`); --eager times host launches.
+    use_graph = not args.eager
+    launch, eager_ms = "eager", None
+    params = [p for p in net.parameters() if p.requires_grad]
+
+    def param_checksum():
+        return float(torch.stack(torch._foreach_norm([p.detach() for p in params])).double().sum())
+
     if use_graph:
-        if args.warmup < 3:          # capture needs the steady state (bf16 weight copies, zero pool, optimizer state)
-            for _ in range(3 - args.warmup):
-                step += 1
-                trainer.train_step(step)
+        while step < 3:              # capture needs the steady state (bf16 weight copies, zero pool, optimizer state)
+            step += 1
+            trainer.train_step(step)
+        sync()
+        t0 = time.perf_counter()
+        n_eager = min(args.steps, 10)
+        for _ in range(n_eager):
+            step += 1
+            trainer.train_step(step)
+        sync()
+        eager_ms = (time.perf_counter() - t0) / n_eager * 1e3
         try:
             trainer.capture_graph(step + 1)
             launch = "hipGraph replay"
-        except Exception as e:       # never lose the measurement to the capture: fall back to eager launches
+        except Exception as e:       # never lose the measurement to the capture (capture_graph has put the host state back): eager launches
             if args.graph:
                 raise
             print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr, flush=True)
-            trainer._graph = None
         if trainer._graph is not None:
             for _ in range(2):          # (the first replays also warm the graph's own memory)
                 step += 1
                 trainer.train_step(step)
+    warmup_effective = step
+    sync()
+    check0 = param_checksum()
     sync()
     t0 = time.perf_counter()
+    losses = []
     for _ in range(args.steps):
         step += 1
-        loss = trainer.train_step(step)
+        losses.append(trainer.train_step(step).clone())     # (a device-side copy: nothing is read back inside the timed region)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         et = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et)
-    loss_val = float(loss)
+    loss_first, loss_val = float(losses[0]), float(losses[-1])
+    check1 = param_checksum()
+    # the line must prove that the timed steps trained: a finite, plausible loss in every timed step and parameters that moved
+    if not all(1e-3 < float(l) < 10 for l in losses) or check1 == check0:
+        raise RuntimeError(f"bench: the timed steps did not train (losses {[float(l) for l in losses]}, parameter norm sum {check0} -> {check1})")
 
     roofline = None
     if not args.no_roofline:
@@ -267,7 +285,9 @@ def main():
                "config": {"workload": "MMDiT-B (12 blocks, d=768, 12 heads, SwiGLU 4x, RoPE2d) 256^2 images -> 32x32x16 latents, synthetic "
                                       "Gemma-2-2b-shaped text embeds (154x2304) + pooled (768); fwd+bwd+grad-allreduce+clip+AdamW (fp32 master weights)",
                           "per_gpu_batch": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}"},
-               "mfma_roofline_frac_step": round(value * TRAIN_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16), 4), "final_loss": round(loss_val, 5),
+               "mfma_roofline_frac_step": round(value * TRAIN_GFLOP_PER_IMG * 1e9 / (world * PEAK_BF16), 4),
+               "loss_first": round(loss_first, 5), "final_loss": round(loss_val, 5), "param_norm_sum": [round(check0, 6), round(check1, 6)],
+               "warmup_effective": warmup_effective, "ms_per_step_eager": None if eager_ms is None else round(eager_ms, 3),
                "optimizer": "hip (unscale+clip+AdamW, 3 launches)" if trainer.hip_optimizer else "torch (multi-tensor)",
                "launch": launch}
         if trainer.hip_optimizer:
@@ -279,6 +299,8 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 or args.force_dist:
         dist.barrier()
+        trainer._graph = None        # (the graph holds the captured collectives: release it before the communicator)
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -46,8 +46,14 @@ extern "C" {
 
 typedef void* mmdit_stream_t;   /* hipStream_t */
 
-/* library/ABI version and build target ("gfx950") */
+/* library/ABI version and build target ("gfx950").  MMDIT_ABI_VERSION changes with every struct-layout or signature change; the
+ * Python binding (_lib.py) refuses a library whose version or struct sizes differ from what it was written for, so a scratch build
+ * (MMDIT_LIB=...) with another layout fails loudly instead of reading past a struct.  mmdit_struct_size(which): sizeof of
+ * 0 mmdit_gemm_args, 1 mmdit_ln_fwd_problem, 2 mmdit_ln_bwd_problem, 3 mmdit_qk_problem, 4 mmdit_mlp_bwd_problem,
+ * 5 mmdit_adamw_tensor, 6 mmdit_cast_tensor; -1 for an unknown id. */
+#define MMDIT_ABI_VERSION 3
 int mmdit_abi_version(void);
+int mmdit_struct_size(int which);
 const char* mmdit_build_arch(void);
 
 /* ---------------------------------------------------------------------------
@@ -295,6 +301,15 @@ int mmdit_silu_bwd(const void* dy, int dy_dtype, const float* pre, void* dpre, i
 int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc_dtype, const float* gate, int64_t ld_gate,
                             int rows, int d, int rows_per_batch, void* dacc, int dacc_dtype,
                             float* dgate, int64_t ld_dgate, float* dbias, int64_t ld_dbias, mmdit_stream_t stream);
+
+/* Rectified-flow loss of the training step (model_trainer.py:429-446): label = eps - x0 (rounded to bf16 when x0 / eps are bf16, as
+ * torch's bf16 subtraction rounds it), loss[0] = coef * sum_i (v[i] - label[i])^2 with coef = 1 / (n * accumulation_steps) from the
+ * caller, and -- for the backward -- dv[i] = 2 * coef * (v[i] - label[i]) (NULL: not written).  Two launches: <= 256 workgroups write one
+ * partial sum each into partials[256] (fixed order inside a workgroup), one workgroup adds them in index order: bit-reproducible, no
+ * atomics, no zero-initialised workspace (torch's multi-block mean() clears a semaphore with hipMemsetAsync, which a hipGraph replay on
+ * ROCm 7 does not keep in stream order: DESIGN.md 5).  n % 8 == 0. */
+int mmdit_flow_loss(const float* v, const void* x0, const void* eps, int in_dtype, int64_t n, float coef, float* dv, float* partials,
+                    float* loss, mmdit_stream_t stream);
 
 /* Column sums: out[c] += sum_r x[r,c]  (bias gradients). */
 int mmdit_colsum(const void* x, int dtype, int rows, int cols, int64_t ld, float* out, mmdit_stream_t stream);

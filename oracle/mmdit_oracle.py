@@ -411,16 +411,37 @@ class OracleTrainer:
 
 
 @torch.no_grad()
-def euler_cfg_sample(sd, cfg: OracleConfig, noise, text_hidden, text_pooled, num_steps: int, cfg_scale: float):
-    """sample_imgs, sampler='euler' (diff_model.py:384-429), up to (not including) VAE decode."""
+def cfg_sample(sd, cfg: OracleConfig, noise, text_hidden, text_pooled, num_steps: int, cfg_scale: float, sampler: str = "euler", generator=None):
+    """sample_imgs (diff_model.py:367-460) up to (not including) the VAE decode: "euler" (430-432), "euler_stochastic" (434-449:
+    per-step noise drawn on the CPU from `generator`, sigma = t(1-t)/(1-t+0.008), scaled by sqrt(dt)) and "heun" (451-462: second
+    velocity at t - dt on the Euler prediction, trapezoidal update)."""
     B = noise.shape[0]
     out = noise.clone()
     null = torch.tensor([0] * B + [1] * B).bool()
     th = text_hidden.repeat(2 * B, 1, 1)
     tp = text_pooled.repeat(2 * B, 1)
+    dt = 1 / num_steps
+
+    def velocity(x, tt):
+        v = forward(sd, cfg, x.repeat(2, 1, 1, 1), tt, th, tp, null, null, null)
+        return (1 + cfg_scale) * v[:B] - cfg_scale * v[B:]
+
     for t in torch.linspace(1, 1.0 / num_steps, num_steps):
         tt = t.repeat(2 * B)
-        v = forward(sd, cfg, out.repeat(2, 1, 1, 1), tt, th, tp, null, null, null)
-        v = (1 + cfg_scale) * v[:B] - cfg_scale * v[B:]
-        out = out - v * (1 / num_steps)
+        v = velocity(out, tt)
+        if sampler == "euler":
+            out = out - v * dt
+        elif sampler == "euler_stochastic":
+            sigma = (tt * (1 - tt) / (1 - tt + 0.008))[:B, None, None, None]
+            out = out - v * dt + sigma * torch.randn(v.shape, generator=generator) * (dt ** 0.5)
+        elif sampler == "heun":
+            v2 = velocity(out - v * dt, tt - dt)
+            out = out - (dt / 2) * (v + v2)
+        else:
+            raise ValueError("Invalid sampler specified. Choose 'euler', 'euler_stochastic', or 'heun'.")
     return out
+
+
+def euler_cfg_sample(sd, cfg: OracleConfig, noise, text_hidden, text_pooled, num_steps: int, cfg_scale: float):
+    """sample_imgs, sampler='euler' (diff_model.py:384-432), up to (not including) VAE decode."""
+    return cfg_sample(sd, cfg, noise, text_hidden, text_pooled, num_steps, cfg_scale, "euler")

@@ -65,6 +65,7 @@ class MlpBwdProblem(ctypes.Structure):     # mirrors mmdit_mlp_bwd_problem
 
 _SIGNATURES = {
     "mmdit_abi_version": ([], _i),
+    "mmdit_struct_size": ([_i], _i),
     "mmdit_build_arch": ([], ctypes.c_char_p),
     "mmdit_gemm": ([ctypes.POINTER(GemmArgs), _vp], _i),
     "mmdit_gemm_grouped": ([ctypes.POINTER(GemmArgs), _i, _vp], _i),
@@ -100,6 +101,7 @@ _SIGNATURES = {
     "mmdit_gelu_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),
     "mmdit_silu_bwd": ([_vp, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp], _i),
     "mmdit_gate_residual_bwd": ([_vp, _vp, _i, _vp, _i64, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp], _i),
+    "mmdit_flow_loss": ([_vp, _vp, _vp, _i, _i64, _f, _vp, _vp, _vp, _vp], _i),
     "mmdit_colsum": ([_vp, _i, _i, _i, _i64, _vp, _vp], _i),
     "mmdit_vae_nchw_to_nhwc": ([_vp, _i, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_float, _vp, _vp], _i),
     "mmdit_vae_nhwc_to_nchw": ([_vp, _i, _i, _i, _i, _i, ctypes.c_float, ctypes.c_float, _vp, _vp], _i),
@@ -118,6 +120,10 @@ _SIGNATURES = {
     "mmdit_cast_multi": ([_vp, _vp, _vp, _i, _vp], _i),
 }
 ADAMW_CHUNK = 65536   # MMDIT_ADAMW_CHUNK
+ABI_VERSION = 3       # MMDIT_ABI_VERSION of include/mmdit_hip.h this binding mirrors
+# struct ids of mmdit_struct_size() -> ctypes mirrors (None: laid out with numpy record dtypes in optim.py / ops.py: 48 / 24 bytes)
+_STRUCTS = [("mmdit_gemm_args", GemmArgs), ("mmdit_ln_fwd_problem", LnFwdProblem), ("mmdit_ln_bwd_problem", LnBwdProblem),
+            ("mmdit_qk_problem", QkProblem), ("mmdit_mlp_bwd_problem", MlpBwdProblem), ("mmdit_adamw_tensor", None), ("mmdit_cast_tensor", None)]
 
 _lib = None
 
@@ -150,6 +156,12 @@ def lib():
             fn = getattr(L, name)  # AttributeError -> symbol missing: fail loudly
             fn.argtypes = argtypes
             fn.restype = restype
+        # a library built for another ABI (a stale scratch build behind MMDIT_LIB, an old .so next to a new binding) must not be called
+        if L.mmdit_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH}: ABI version {L.mmdit_abi_version()}, this binding is written for {ABI_VERSION}: rebuild (python __graft_entry__.py build)")
+        for which, (name, struct) in enumerate(_STRUCTS):
+            if struct is not None and L.mmdit_struct_size(which) != ctypes.sizeof(struct):
+                raise RuntimeError(f"{LIB_PATH}: sizeof({name}) = {L.mmdit_struct_size(which)}, the binding's ctypes mirror has {ctypes.sizeof(struct)} bytes")
         _lib = L
     return _lib
 

@@ -943,7 +943,19 @@ inline int grid_cap(int64_t n, int bs) { int64_t g = (n + bs - 1) / bs; return (
 // to "plain kernel + quantise pass" (test_mxfp8_mode_vs_mx_oracle) while the parity mode sits 1.3 % under its 1e-3 bar.
 #define LN_FWD_NIT (NIT < 0 ? -NIT : NIT)      // (also the text RMSNorm forward, 12 us per launch: same reason, nothing to gain)
 
-extern "C" int mmdit_abi_version(void) { return 1; }
+extern "C" int mmdit_abi_version(void) { return MMDIT_ABI_VERSION; }
+extern "C" int mmdit_struct_size(int which) {
+  switch (which) {
+    case 0: return (int)sizeof(mmdit_gemm_args);
+    case 1: return (int)sizeof(mmdit_ln_fwd_problem);
+    case 2: return (int)sizeof(mmdit_ln_bwd_problem);
+    case 3: return (int)sizeof(mmdit_qk_problem);
+    case 4: return (int)sizeof(mmdit_mlp_bwd_problem);
+    case 5: return (int)sizeof(mmdit_adamw_tensor);
+    case 6: return (int)sizeof(mmdit_cast_tensor);
+    default: return -1;
+  }
+}
 extern "C" const char* mmdit_build_arch(void) { return "gfx950"; }
 
 extern "C" int mmdit_ln_modulate_fwd(const float* x, const float* scale, const float* shift, int64_t ld_mod, int rows, int d, int rpb,
@@ -1314,6 +1326,59 @@ extern "C" int mmdit_gate_residual_bwd(const float* dy, const void* acc, int acc
   if (acc_dtype == MMDIT_BF16 && dacc_dtype == MMDIT_BF16) hipLaunchKernelGGL((gate_res_bwd_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, dy, (const bf16_t*)acc, gate, ld_gate, d, rpb, nchunk, (bf16_t*)dacc, dgate, ld_dgate, dbias, ld_dbias);
   else if (acc_dtype == MMDIT_F32 && dacc_dtype == MMDIT_F32) hipLaunchKernelGGL((gate_res_bwd_kernel<float, float>), grid, dim3(256), 0, s, dy, (const float*)acc, gate, ld_gate, d, rpb, nchunk, (float*)dacc, dgate, ld_dgate, dbias, ld_dbias);
   else return MMDIT_ERR_DTYPE;
+  return mmdit_launch_status();
+}
+
+namespace {
+// rectified-flow loss: see mmdit_flow_loss in the header.  Grid-stride over groups of 8 elements, per-lane fp32 sums, wave reduction,
+// the four wave sums of a workgroup added in wave order by lane 0.
+template <typename T>
+__global__ __launch_bounds__(256) void flow_loss_partial_kernel(const float* __restrict__ v, const T* __restrict__ x0, const T* __restrict__ eps, int64_t n8, float coef2,
+                                                                float* __restrict__ dv, float* __restrict__ partials) {
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    float a[8], b[8], c[8], g[8];
+    ld8(v + i * 8, a);
+    ld8(x0 + i * 8, b);
+    ld8(eps + i * 8, c);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      float lab = c[e] - b[e];
+      if (sizeof(T) == 2) lab = bf2f(f2bf(lab));      // torch computes eps - x0 in bf16 (one rounding), then casts to v's dtype
+      const float d = a[e] - lab;
+      s += d * d;
+      g[e] = coef2 * d;
+    }
+    if (dv) st8(dv + i * 8, g);
+  }
+  __shared__ float sm[4];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = ((sm[0] + sm[1]) + sm[2]) + sm[3];
+}
+__global__ __launch_bounds__(64) void flow_loss_final_kernel(const float* __restrict__ partials, int count, float coef, float* __restrict__ loss) {
+  // 64 lanes x 4 partials in a fixed order, then the butterfly: the same summation tree in every run
+  float s = 0.f;
+  for (int i = threadIdx.x; i < count; i += 64) s += partials[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) loss[0] = s * coef;
+}
+}  // namespace
+
+extern "C" int mmdit_flow_loss(const float* v, const void* x0, const void* eps, int in_dtype, int64_t n, float coef, float* dv, float* partials,
+                               float* loss, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(v && x0 && eps && partials && loss && n > 0 && n % 8 == 0);
+  const int64_t n8 = n / 8;
+  const int grid = (int)((n8 + 255) / 256 < 256 ? (n8 + 255) / 256 : 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (in_dtype == MMDIT_BF16)
+    hipLaunchKernelGGL((flow_loss_partial_kernel<bf16_t>), dim3(grid), dim3(256), 0, s, v, (const bf16_t*)x0, (const bf16_t*)eps, n8, 2.f * coef, dv, partials);
+  else if (in_dtype == MMDIT_F32)
+    hipLaunchKernelGGL((flow_loss_partial_kernel<float>), dim3(grid), dim3(256), 0, s, v, (const float*)x0, (const float*)eps, n8, 2.f * coef, dv, partials);
+  else
+    return MMDIT_ERR_DTYPE;
+  hipLaunchKernelGGL(flow_loss_final_kernel, dim3(1), dim3(64), 0, s, (const float*)partials, grid, coef, loss);
   return mmdit_launch_status();
 }
 

@@ -150,12 +150,18 @@ def wgrad_join(device):
         torch.cuda.current_stream(device).wait_stream(st)
 
 
+ARENA_QUANTUM = 1024     # flat gradient arenas are multiples of this many elements: a reducer can cut them into equal shards for any
+                         # world size that divides it (reducer.GradReducer: reduce-scatter / all-gather algorithms)
+
+
 def _zeros_views(shapes, dev, prefix=None):
     """One zero-filled fp32 arena (one memset launch) carved into views of the given shapes.
     prefix=k: also return the flat sub-arena that holds exactly the first k views (a data-parallel reducer averages the
     parameter gradients of a block in place through it)."""
     sizes = [int(torch.Size(s).numel()) for s in shapes]
     pad = [(n + 3) // 4 * 4 for n in sizes]           # keep every view 16-byte aligned
+    if prefix is not None:                            # the sub-arena of the first `prefix` views: a multiple of ARENA_QUANTUM (zero padding)
+        pad[prefix - 1] += -sum(pad[:prefix]) % ARENA_QUANTUM
     flat = ops.zeros(sum(pad), dev)                   # (a slice of the pass-wide zero pool on a GPU)
     out, off = [], 0
     for s, n, p in zip(shapes, sizes, pad):
@@ -180,7 +186,7 @@ def _wgrad_flush(m, pending):
         dev = pending[0][1]["A"].device
         shapes = [(d["A"].shape[1], d["B"].shape[1]) for _, d in pending]
         sizes = [(a * b + 3) // 4 * 4 for a, b in shapes]          # 16-byte aligned slices
-        arena = torch.empty(sum(sizes), dtype=F32, device=dev)
+        arena = torch.empty((sum(sizes) + ARENA_QUANTUM - 1) // ARENA_QUANTUM * ARENA_QUANTUM, dtype=F32, device=dev)   # (the tail padding is never read)
         off = 0
         for (_, d), (a, b), n in zip(pending, shapes, sizes):
             d["out"] = arena[off:off + a * b].view(a, b)

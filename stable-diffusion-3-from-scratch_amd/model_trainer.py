@@ -84,6 +84,22 @@ class SyntheticData:
         return self._cache
 
 
+class _FlowLoss(torch.autograd.Function):
+    """loss = mean((v - (eps - x0))^2) / accumulation_steps (reference model_trainer.py:429-446) through ops.flow_loss: the forward also
+    forms d loss / d v, the backward scales it by the incoming gradient (the GradScaler's loss scale)."""
+
+    @staticmethod
+    def forward(ctx, v, x0, eps, accumulation_steps):
+        from . import ops
+        loss, ctx.dv = ops.flow_loss(v, x0, eps, accumulation_steps, need_grad=ctx.needs_input_grad[0])
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dv, ctx.dv = ctx.dv, None
+        return dv.mul_(g), None, None, None
+
+
 class model_trainer:
     def __init__(self, diff_model, batchSize, accumulation_steps, totalSteps, lr, ema_update_freq, ema_decay, warmup_steps, use_lr_scheduler,
                  device, saveDir, numSaveSteps, null_prob_pooled=0.1, null_prob_gemma=0.1, null_prob_bert=0.1, text_loss_weight=0.0,
@@ -91,13 +107,19 @@ class model_trainer:
                  wandb_log_gradients=False, reset_wandb=False, reset_optim=False, log_steps=10, loader_to_model_gpu=None,
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
                  data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False,
-                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True, inf_padded_latents=False, loss_scaling=True):
+                 fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True, inf_padded_latents=False, loss_scaling=True,
+                 graph_after=None, hip_loss=True):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
         self.null_prob_pooled, self.null_prob_gemma, self.null_prob_bert = null_prob_pooled, null_prob_gemma, null_prob_bert
         self.use_amp, self.max_res, self.log_file = use_amp, max_res, log_file
         self.device_rng = device_rng
+        # hip_loss: the loss expression as two HIP launches (ops.flow_loss) instead of ~6 torch kernels; False: torch's own ops
+        self.hip_loss = bool(hip_loss)
+        # graph_after=N: train() captures the optimizer step into a hipGraph after N eager steps and replays it from then on
+        # (None: every step is issued from the host, as the reference does)
+        self.graph_after = graph_after
         if text_loss_weight != 0.0:
             raise RuntimeError("text_loss is out of scope on the HIP path (text_loss_weight must be 0)")
         if loader_to_model_gpu not in (None, {}):
@@ -165,7 +187,7 @@ class model_trainer:
         self._gen = torch.Generator(device=self.device).manual_seed(4321 + self.rank) if device_rng else None
         self.inf_padded_latents = bool(inf_padded_latents)
         self.last_loss = None
-        self._graph, self._graph_loss = None, None
+        self._graph, self._slots, self._loss_out, self._graph_loss = None, None, None, None
         self.last_grad_norm = None   # hip_optimizer: device scalar, the unscaled gradient norm of the last step
         if is_main_process():
             total_params = sum(p.numel() for p in self.model.parameters()) / 1e6
@@ -184,13 +206,19 @@ class model_trainer:
         mk = lambda p, thr: torch.where(p < thr, 1, 0).to(torch.bool).to(self.device)
         return t, mk(pp, self.null_prob_pooled), mk(pg, self.null_prob_gemma), mk(pb, self.null_prob_bert)
 
-    def micro_step(self, final: bool):
-        """One forward/backward micro-step; returns the (already /accumulation_steps) loss tensor."""
+    def _draw(self):
+        """One micro-batch and its conditioning draw: (x0, text, pooled, t, null_pooled, null_gemma, null_bert)."""
         with torch.no_grad():
             batch_x_0, batch_txt, batch_txt_pooled = self.data_source()
             if self.inf_padded_latents:      # latents arrive in the reference's +inf-padded wire format (model_trainer.py:362-370)
                 batch_x_0 = unpad_latents(batch_x_0)
-            t_vals, n_pooled, n_gemma, n_bert = self._sample_conditioning(batch_x_0.shape[0])
+            return (batch_x_0, batch_txt, batch_txt_pooled) + tuple(self._sample_conditioning(batch_x_0.shape[0]))
+
+    def micro_step(self, final: bool, inputs=None):
+        """One forward/backward micro-step; returns the (already /accumulation_steps) loss tensor.  inputs: a _draw() result (the graph
+        path passes its static input slots), None: draw here."""
+        batch_x_0, batch_txt, batch_txt_pooled, t_vals, n_pooled, n_gemma, n_bert = inputs if inputs is not None else self._draw()
+        with torch.no_grad():
             batch_x_t, epsilon_t = self.model.noise_batch(batch_x_0, t_vals)
         # Gradient accumulation = DDP.no_sync (reference model_trainer.py:463-480): nothing is reduced on non-final micro-steps.
         #  * hook path (post-accumulate hooks see the ACCUMULATED gradient): the hooks reduce on the final micro-step only;
@@ -203,9 +231,14 @@ class model_trainer:
         late = engine_path and self.accumulation_steps > 1
         self.reducer.skip = (not final) or late
         v_pred = self.model(batch_x_t.detach(), t_vals, batch_txt, batch_txt_pooled, n_pooled, n_gemma, n_bert)
-        labels = epsilon_t - batch_x_0.to(epsilon_t.device)
-        loss = nn.MSELoss(reduction="none")(v_pred, labels.detach().to(v_pred.dtype)).flatten(1, -1).mean()
-        loss = loss / self.accumulation_steps
+        x0 = batch_x_0.to(epsilon_t.device)
+        if self.hip_loss and v_pred.is_cuda and v_pred.dtype == torch.float32 and x0.dtype == epsilon_t.dtype and v_pred.numel() % 8 == 0:
+            # same arithmetic as the torch expression below in two HIP launches with a bit-reproducible reduction (ops.flow_loss)
+            loss = _FlowLoss.apply(v_pred, x0, epsilon_t, self.accumulation_steps)
+        else:
+            labels = epsilon_t - x0
+            loss = nn.MSELoss(reduction="none")(v_pred, labels.detach().to(v_pred.dtype)).flatten(1, -1).mean()
+            loss = loss / self.accumulation_steps
         if self.grad_scaler is not None:
             self.grad_scaler.scale(loss).backward()
         else:
@@ -278,9 +311,12 @@ class model_trainer:
         """One optimizer step = accumulation_steps micro-steps + clip + AdamW."""
         if self._graph is not None:
             return self._replay(step)
+        return self._eager_step(step)
+
+    def _eager_step(self, step, inputs=None):
         loss = None
         for k in range(self.accumulation_steps):
-            l = self.micro_step(final=(k == self.accumulation_steps - 1))
+            l = self.micro_step(final=(k == self.accumulation_steps - 1), inputs=inputs[k] if inputs is not None else None)
             loss = l if loss is None else loss + l
         self.optimizer_step(step)
         self.last_loss = loss
@@ -288,47 +324,97 @@ class model_trainer:
 
     # ------------------------------------------------------------------------------------------
     # hipGraph capture of the whole optimizer step.  The reference has nothing comparable; here a step is ~440 kernel launches
-    # issued through ctypes (~16 ms of host time per 33 ms step), and every launch already takes its stream explicitly, allocates
+    # issued through ctypes (~26 ms of host time per 30 ms step), and every launch already takes its stream explicitly, allocates
     # nothing and never synchronises, so the step can be captured once and replayed with ONE host call.
+    def can_capture(self):
+        """None when capture_graph() can run, else the reason it cannot."""
+        if self.device.type != "cuda" or not self.hip_optimizer:
+            return "needs hip_optimizer=True on a GPU"
+        if self.ema_model_cpu is not None and self._ema_gpu is None:
+            return "the EMA must live on the GPU (ema_on_gpu=True) or be off"
+        if self.reducer.enabled and dist.get_backend(self.subgroup) != "nccl":
+            return "the gradient collectives are captured with the step: backend nccl (RCCL) only"
+        return None
+
     def capture_graph(self, step):
-        """Capture data generation + forward + backward + (unscale, clip, AdamW) + GradScaler.update of one optimizer step into a
-        hipGraph; later train_step() calls replay it.  Call after a few eager steps (the bf16 weight copies, the zero pool,
-        the optimizer state and the scaler must be in their steady state).  Needs the HIP optimizer, the trainer's own device-side
-        data / conditioning generators (SyntheticData, device_rng=True) and a single rank."""
-        if self.device.type != "cuda" or not self.hip_optimizer or not self.device_rng or not isinstance(self.data_source, SyntheticData):
-            raise RuntimeError("capture_graph needs hip_optimizer=True, device_rng=True and the trainer's SyntheticData source on a GPU")
-        if self.reducer.enabled or self.ema_model_cpu is not None and self._ema_gpu is None:
-            raise RuntimeError("capture_graph: single-rank runs only (collectives are not captured), EMA on the GPU or off")
+        """Capture forward + backward + gradient all-reduce + (unscale, clip, AdamW) + GradScaler.update of one optimizer step into a
+        hipGraph; later train_step() calls replay it.  Call after a few eager steps (the bf16 weight copies, the zero pool, the
+        optimizer state and the scaler must be in their steady state).
+        Inputs: with the trainer's own SyntheticData source and device_rng=True the batch and its conditioning draw are generated
+        INSIDE the graph (RNG streams registered with it).  Any other data source / the reference's CPU draw of t and the null masks
+        (device_rng=False) stay outside: every replay first copies the next micro-batches into static input slots the graph reads;
+        a batch whose shapes differ from the captured ones (aspect-ratio buckets) runs as an eager step.
+        Data parallel (reducer enabled, RCCL): the per-block all-reduces and their side stream are part of the captured step -- the
+        fork / join of the side stream becomes graph edges, every rank replays the same sequence of collectives."""
+        why = self.can_capture()
+        if why is not None:
+            raise RuntimeError("capture_graph: " + why)
         from . import engine
         if engine._WG_OVERLAP:
-            engine._WG_OVERLAP = False     # one stream inside the capture (the side stream measured no gain: DESIGN.md 5)
+            engine._WG_OVERLAP = False     # (the weight-gradient side stream measured no gain: DESIGN.md 5)
+        in_graph = isinstance(self.data_source, SyntheticData) and self.device_rng
+        self._slots = None
+        if not in_graph:
+            self._slots = [tuple(x.to(self.device).clone() for x in self._draw()) for _ in range(self.accumulation_steps)]
         torch.cuda.synchronize(self.device)
         self.optim.sync_lr(self.device)
         self.optim.prepare_capture()
+        # the loss leaves the graph through a persistent buffer written by a kernel of the graph (not through a tensor of the graph's
+        # private pool, whose block is shared with earlier temporaries of the step): DESIGN.md 5, "final_loss 0.0"
+        self._loss_out = torch.zeros((), dtype=torch.float32, device=self.device)
         g = torch.cuda.CUDAGraph()
-        for gen in (self._gen, self.data_source.g):
+        for gen in (self._gen, getattr(self.data_source, "g", None)) if in_graph else ():
             if gen is not None:
                 g.register_generator_state(gen)
         self.optim.zero_grad()
-        with torch.cuda.graph(g):
-            loss = None
-            for k in range(self.accumulation_steps):
-                l = self.micro_step(final=(k == self.accumulation_steps - 1))
-                loss = l if loss is None else loss + l
-            self._hip_optimizer_step()
-            if self.grad_scaler is not None:
-                self.grad_scaler.update()
-            self._graph_loss = loss
+        try:
+            # thread_local: the RCCL watchdog thread polls events of earlier collectives while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local" if self.reducer.enabled else "global"):
+                loss = None
+                for k in range(self.accumulation_steps):
+                    l = self.micro_step(final=(k == self.accumulation_steps - 1), inputs=None if in_graph else self._slots[k])
+                    loss = l if loss is None else loss + l
+                self._hip_optimizer_step()
+                if self.grad_scaler is not None:
+                    self.grad_scaler.update()
+                self._write_loss(loss)
+                self._graph_loss = loss      # (the capture-time tensor in the graph's private pool: diagnostics only, see tools/probes/graph_loss_probe*.py)
+        except BaseException:
+            self._abandon_capture()
+            raise
         self.optim.zero_grad()      # (host bookkeeping only: the graph owns the gradient buffers)
+        self.optim.after_replay()   # (the capture itself executed nothing: the eager pointer table / copies bookkeeping is void)
         self._graph = g
         return g
 
+    def _write_loss(self, loss):
+        torch.mul(loss.detach().to(torch.float32).reshape(()), 1.0, out=self._loss_out)
+
+    def _abandon_capture(self):
+        """A capture that raised leaves host state behind that no launch backs: put it back so that eager steps can continue."""
+        self._graph, self._slots = None, None
+        self.reducer.reset()
+        if self.grad_scaler is not None and self.grad_scaler.is_enabled():
+            from torch.amp.grad_scaler import _refresh_per_optimizer_state
+            self.grad_scaler._per_optimizer_states[id(self.optim)] = _refresh_per_optimizer_state()
+        self.optim.after_replay()
+        self.optim.zero_grad()
+        torch.cuda.synchronize(self.device)
+
     def _replay(self, step):
+        if self._slots is not None:
+            inputs = [self._draw() for _ in range(self.accumulation_steps)]
+            if any(tuple(a.shape) != tuple(b.shape) or a.dtype != b.dtype for slot, inp in zip(self._slots, inputs) for a, b in zip(slot, inp)):
+                return self._eager_step(step, inputs)     # another bucket shape: not the captured step
+            for slot, inp in zip(self._slots, inputs):
+                for dst, src in zip(slot, inp):
+                    dst.copy_(src, non_blocking=True)
         self.optim.sync_lr(self.device)     # the scheduler's current rate -> device (a fill only when it changed)
         self._graph.replay()
+        self.optim.after_replay()
         self.scheduler.step(step)
-        self.last_loss = self._graph_loss
-        return self._graph_loss
+        self.last_loss = self._loss_out
+        return self._loss_out
 
     def update_ema(self):
         """ema = ema * decay + param * (1 - decay)  (model_trainer.py:537-541), on the GPU copy when there is one."""
@@ -380,6 +466,8 @@ class model_trainer:
         batch_loss, t0 = 0.0, time.time()
         opt_steps = self.start_step // self.accumulation_steps
         for step in range(opt_steps, self.totalSteps):
+            if self.graph_after is not None and self._graph is None and step - opt_steps == max(3, self.graph_after) and self.can_capture() is None:
+                self.capture_graph(step + 1)
             loss = self.train_step(step + 1)
             n = step + 1
             batch_loss += float(loss) if n % self.log_steps == 0 else 0.0

@@ -142,6 +142,7 @@ class diff_model(nn.Module):
         only -- e4m3 operands with per-tensor scales for the QKV / out / MLP GEMMs of every block (BASELINE config 5)."""
         assert precision in ("fast", "parity", "fp8", "mxfp8")
         engine.FP8._q.clear()
+        engine.MXFP8._q.clear()
         for mod in self.modules():
             if hasattr(mod, "precision"):
                 mod.precision = "fast" if precision in ("fp8", "mxfp8") else precision     # stand-alone sub-modules have no fp8 path
@@ -300,7 +301,7 @@ class diff_model(nn.Module):
                 x_keep = x.clone()
                 x.sub_(v1, alpha=dt)
                 xx[B:].copy_(x)
-                v2 = velocity(t_now - dt)
+                v2 = velocity(float(torch.tensor(t_now, dtype=torch.float32) - dt))     # (fp32 `t - dt` as the reference's tensor arithmetic rounds it)
                 torch.sub(x_keep, v1 + v2, alpha=dt / 2, out=x)
             xx[B:].copy_(x)
             if save_intermediate:

@@ -44,6 +44,7 @@ class _ZeroPool:
 
 
 _pools = {}
+NO_POOL = False     # debug_guard.install() sets it: every zeros() request becomes an allocation of its own (with its own guards)
 
 
 def zero_pool_begin(device):
@@ -54,7 +55,7 @@ def zero_pool_begin(device):
 def zeros(shape, device):
     """fp32 zeros of `shape`: a slice of the pass's pool on a GPU, plain torch.zeros elsewhere."""
     shape = tuple(shape) if not isinstance(shape, int) else (shape,)
-    pool = _pools.get(device)
+    pool = None if NO_POOL else _pools.get(device)
     if pool is None:
         return torch.zeros(shape, dtype=torch.float32, device=device)
     return pool.take(int(torch.Size(shape).numel()), device).view(shape)
@@ -584,6 +585,19 @@ def gate_residual_bwd(dy, acc, gate, rows_per_batch, dgate, dbias, out_dtype):
     check(_lib.lib().mmdit_gate_residual_bwd(_p(_c(dy)), _p(acc), _dt(acc), _p(gate), gate.stride(0), rows, d, rows_per_batch,
                                              _p(dacc), _dt(dacc), _p(dgate), dgate.stride(0), _p(dbias), ld_dbias, _s()), "mmdit_gate_residual_bwd")
     return dacc
+
+
+def flow_loss(v, x0, eps, accumulation_steps=1, need_grad=True):
+    """Rectified-flow loss mean((v - (eps - x0))^2) / accumulation_steps (mmdit_flow_loss): returns (loss 0-dim fp32, dv = d loss / d v
+    fp32 like v, or None).  v fp32, x0 / eps of one dtype (bf16: the label is rounded to bf16 as torch's bf16 subtraction does)."""
+    n = v.numel()
+    if v.dtype != torch.float32 or x0.dtype != eps.dtype or x0.numel() != n or eps.numel() != n or n % 8:
+        raise RuntimeError("flow_loss: v fp32, x0 and eps of one dtype and v's size, numel % 8 == 0")
+    loss = torch.empty((), dtype=torch.float32, device=v.device)
+    part = torch.empty(256, dtype=torch.float32, device=v.device)
+    dv = torch.empty(v.shape, dtype=torch.float32, device=v.device) if need_grad else None
+    check(_lib.lib().mmdit_flow_loss(_p(_c(v)), _p(_c(x0)), _p(_c(eps)), _dt(x0), n, 1.0 / (n * accumulation_steps), _p(dv), _p(part), _p(loss), _s()), "mmdit_flow_loss")
+    return loss, dv
 
 
 def colsum(x, out):

@@ -32,6 +32,7 @@ class ClipAdamW(torch.optim.AdamW):
         # must not bake the scheduler's current value in); refreshed by one tiny fill only when a group's lr changed
         self._lr_dev, self._lr_host = None, None
         self._capture_staging = None
+        self._last_shadows = ([], set())   # (packs, parameter ids) whose bf16 copies the last step_clipped() rewrote (replay bookkeeping)
 
     # ------------------------------------------------------------------------------------------
     def _state_of(self, p):
@@ -107,6 +108,17 @@ class ClipAdamW(torch.optim.AdamW):
             t["ptrs"] = ptrs
         return t
 
+    def after_replay(self):
+        """Host bookkeeping of a step that ran as a graph replay (the launches of step_clipped() were captured, its host side was not):
+        the parameters moved behind Tensor._version -> every derived copy is stale (packing epoch) except the bf16 copies the captured
+        update kernel rewrote, whose generation advances (the fp8 / mxfp8 weight caches key on it); and the replay re-uploaded the
+        CAPTURE's gradient pointers into the device table, so the host-side cache of an eager step's pointers is void."""
+        packing.bump_epoch()
+        if self._last_shadows[0]:
+            packing.mark_rewritten(*self._last_shadows)
+        if self._table is not None:
+            self._table["ptrs"] = None
+
     def prepare_capture(self):
         """Call right before capturing step_clipped() into a graph: a pinned pointer-table source that belongs to the capture."""
         n = sum(1 for g in self.param_groups for p in g["params"] if p.requires_grad)
@@ -171,8 +183,9 @@ class ClipAdamW(torch.optim.AdamW):
                                               float(group["weight_decay"]), s), "mmdit_adamw_step_dlr")
         steps_flat.add_(1.0 - t["out3"][1])
         packing.bump_epoch()     # the kernels wrote the parameters through raw pointers: the bf16 operand copies are stale now ...
+        self._last_shadows = (shadow_packs, {id(r[0]) for rows in groups for r in rows if r[4] is not None})
         if shadow_packs:         # ... except the ones the update kernel has just rewritten
-            packing.mark_rewritten(shadow_packs, {id(r[0]) for rows in groups for r in rows if r[4] is not None})
+            packing.mark_rewritten(*self._last_shadows)
         # out3 is overwritten by the next call: hand out copies
         res = t["out3"].clone()
         return res[1], res[2]

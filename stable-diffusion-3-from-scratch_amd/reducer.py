@@ -6,34 +6,92 @@ HIP stream so the collective of block i overlaps the backward kernels of block i
 over each block's gradients as soon as they are final (engine.model_bwd(on_grads=...)); xGMI is
 point-to-point (7 links x ~153 GB/s), so buckets are large (one per transformer block, ~105 MB fp32
 for MMDiT-B) to stay bandwidth- rather than latency-bound.  No data-path collective other than this one.
+
+Three selectable algorithms per bucket (constructor `algorithm`, env MMDIT_REDUCE_ALGO; DESIGN.md 5 for the expected times):
+  allreduce  dist.all_reduce(AVG): RCCL's own choice of ring / tree over its channels (default: the path every RCCL release tunes).
+  rs_ag      dist.reduce_scatter_tensor + dist.all_gather_into_tensor: the same traffic split in its two phases (the seam a sharded
+             optimizer step goes into).
+  direct     reduce-scatter as ONE all-to-all (rank r sends shard j to rank j over the direct xGMI link r-j: all 7 links of a GPU carry
+             1/8 of the bucket at the same time) + local fp32 sum of the 8 received shards + all-gather as one all-to-all of the
+             averaged shard.  Optional bf16 wire format (`wire_dtype=torch.bfloat16`: half the bytes per link, fp32 accumulation of
+             the received shards; the gathered average is bf16-rounded).
+Every algorithm needs the bucket length to be a multiple of the world size only for rs_ag / direct; the engine's arenas are padded to
+multiples of 1024 elements (engine.ARENA_QUANTUM), other buckets fall back to allreduce.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
+ALGORITHMS = ("allreduce", "rs_ag", "direct")
+
 
 class GradReducer:
-    def __init__(self, group=None, bucket_bytes=32 << 20, force=False):
+    def __init__(self, group=None, bucket_bytes=32 << 20, force=False, algorithm=None, wire_dtype=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
         self.enabled = self.world > 1 or (force and dist.is_initialized())   # force: exercise the path with one rank (tests)
+        self.algorithm = algorithm or os.environ.get("MMDIT_REDUCE_ALGO", "allreduce")
+        if self.algorithm not in ALGORITHMS:
+            raise ValueError(f"GradReducer: algorithm must be one of {ALGORITHMS}, not {self.algorithm!r}")
+        if wire_dtype is None and os.environ.get("MMDIT_REDUCE_WIRE", "") == "bf16":
+            wire_dtype = torch.bfloat16
+        if wire_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("GradReducer: wire_dtype is torch.float32 (default) or torch.bfloat16")
+        self.wire_dtype = None if wire_dtype == torch.float32 else wire_dtype
         self._cuda = torch.cuda.is_available()
         self._stream = None
         self._pending = []       # tensors waiting for a bucket
         self._pending_bytes = 0
-        self._inflight = []      # (flat, tensors, work)
+        self._inflight = []      # (flat, tensors to copy back into | None)
         self._after = None
         self.skip = False        # True on non-final gradient-accumulation micro-steps (no_sync semantics)
         self._views_wanted = False
+        self.buckets = 0         # buckets averaged so far (tests / logs)
 
     def _side(self, device):
         if self._stream is None:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
 
+    # ---- the collective -------------------------------------------------------------------------
+    def _average(self, flat):
+        """Average the flat fp32 buffer over the ranks, in place.  Called inside the side-stream context on a GPU: the (synchronous)
+        torch.distributed calls enqueue behind the stream's work and make the stream -- not the host -- wait for their results."""
+        self.buckets += 1
+        W, n = self.world, flat.numel()
+        nccl = dist.get_backend(self.group) == "nccl"
+        algo = self.algorithm if (n % W == 0 and n > 0) else "allreduce"
+        if algo == "allreduce":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
+            if not nccl:
+                flat.div_(W)
+            return
+        s = n // W
+        if algo == "rs_ag":
+            shard = torch.empty(s, dtype=flat.dtype, device=flat.device)
+            dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
+            if not nccl:
+                shard.div_(W)
+            dist.all_gather_into_tensor(flat, shard, group=self.group)
+            return
+        # direct: shard j of every rank -> rank j (one all-to-all), fp32 sum there, averaged shard -> everyone (one all-to-all)
+        wire = self.wire_dtype or flat.dtype
+        send = flat if wire == flat.dtype else flat.to(wire)
+        recv = torch.empty(n, dtype=wire, device=flat.device)
+        dist.all_to_all_single(recv, send, group=self.group)
+        shard = torch.sum(recv.view(W, s), dim=0, dtype=torch.float32).div_(W)       # (rank order: the same summation on every rank)
+        send2 = shard.to(wire).unsqueeze(0).expand(W, s).contiguous().view(-1)
+        if wire == flat.dtype:
+            dist.all_to_all_single(flat, send2, group=self.group)
+        else:
+            dist.all_to_all_single(recv, send2, group=self.group)
+            flat.copy_(recv)
+
     # ---- called by the engine (or the hook fallback) as gradients become final -----------------
     def _reduce_in_place(self, arenas):
-        """All-reduce flat buffers where they are (no gather, no copy-back)."""
+        """Average flat buffers where they are (no gather, no copy-back)."""
         if arenas[0].is_cuda:
             side = self._side(arenas[0].device)
             side.wait_stream(torch.cuda.current_stream())
@@ -42,11 +100,9 @@ class GradReducer:
             ctx = torch.cuda.stream(side)
         else:
             ctx = _null()
-        nccl = dist.get_backend(self.group) == "nccl"
         with ctx:
             for a in arenas:
-                work = dist.all_reduce(a, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group, async_op=True)
-                self._inflight.append((a, None, work, not nccl))
+                self._average(a)
         # no record_stream: the buffers are released on the main stream, which has waited for this stream in finish()
 
     def add_bucket(self, tensors, after=None, arenas=None):
@@ -109,16 +165,15 @@ class GradReducer:
             self._launch(tensors)
 
     def _launch(self, tensors):
-        flat = torch.cat([t.reshape(-1) for t in tensors])
-        backend = dist.get_backend(self.group)
-        if backend == "nccl":
-            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            div = False
-        else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            div = True
-        # (flat, tensors to copy back into | None when the caller took views of flat, work, divide-after)
-        self._inflight.append((flat, None if self._views_wanted else tensors, work, div))
+        parts = [t.reshape(-1) for t in tensors]
+        n = sum(p.numel() for p in parts)
+        pad = -n % self.world if self.algorithm != "allreduce" else 0      # (rs_ag / direct: equal shards)
+        if pad:
+            parts.append(torch.zeros(pad, dtype=parts[0].dtype, device=parts[0].device))
+        flat = torch.cat(parts)
+        self._average(flat)
+        # (flat, tensors to copy back into | None when the caller took views of flat)
+        self._inflight.append((flat, None if self._views_wanted else tensors))
         self._views_wanted = False
 
     # ---- called by the trainer after backward(), before clip / optimizer step --------------------
@@ -126,23 +181,24 @@ class GradReducer:
         if not self.enabled or self.skip:
             return
         self.flush()
-        for flat, tensors, work, div in self._inflight:
-            cuda = flat.is_cuda
-            ctx = torch.cuda.stream(self._stream) if cuda else _null()
+        for flat, tensors in self._inflight:
+            if tensors is None:
+                continue
+            ctx = torch.cuda.stream(self._stream) if flat.is_cuda else _null()
             with ctx:
-                work.wait()
-                if div:
-                    flat.div_(self.world)
-                if tensors is not None:
-                    outs, off = [], 0
-                    for t in tensors:
-                        n = t.numel()
-                        outs.append(flat[off:off + n].view_as(t))
-                        off += n
-                    torch._foreach_copy_(tensors, outs)
+                outs, off = [], 0
+                for t in tensors:
+                    n = t.numel()
+                    outs.append(flat[off:off + n].view_as(t))
+                    off += n
+                torch._foreach_copy_(tensors, outs)
         self._inflight = []
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+
+    def reset(self):
+        """Forget everything queued or in flight (a graph capture that raised: its collectives were never launched)."""
+        self._pending, self._pending_bytes, self._inflight, self._views_wanted = [], 0, [], False
 
     def attach_hooks(self, params):
         """Fallback for modules without an engine callback: reduce each parameter's gradient as soon as

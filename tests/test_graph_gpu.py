@@ -1,0 +1,227 @@
+"""hipGraph replay of the optimizer step (model_trainer.capture_graph) IS the eager step -- at MMDiT-B size with the replay pattern that
+lost the loss in round 2, with the gradient collectives inside the graph (1-rank RCCL group), with static input slots (any data
+source), and across the eager -> replay -> sample (fp8 weight caches) -> replay boundary.
+
+Root cause pinned by test_b_size_replay_with_synchronize_between_replays ("final_loss 0.0"): a hipMemsetAsync captured
+into a hipGraph is not kept in stream order by the ROCm 7 runtime when the graph is launched on an idle stream
+(tools/probes/graph_memset_order.py); torch's multi-block mean() zeroes a 4-byte semaphore that way, in a block of the graph's private
+pool that earlier temporaries of the same step reuse, so the last-block election failed and the mean was never written.  The loss is
+now produced by ops.flow_loss (no workspace to clear) and leaves the graph through a persistent buffer."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.weights import make_inputs, make_state_dict  # noqa: E402
+
+CONFIGS = {"micro": dict(dim=128, num_heads=2, num_blocks=3), "b": dict(dim=768, num_heads=12, num_blocks=12)}
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+class _CpuSource:
+    """A data source that is NOT the trainer's SyntheticData: batches drawn on the CPU and moved (what a loader would hand over)."""
+
+    def __init__(self, batch, hw, seed):
+        self.g, self.batch, self.hw = torch.Generator().manual_seed(seed), batch, hw
+
+    def __call__(self):
+        x0 = torch.randn((self.batch, 16, self.hw, self.hw), generator=self.g).to(torch.bfloat16)
+        c = torch.randn((self.batch, 154, 2304), generator=self.g)
+        c[:, :77] *= 30.0
+        c[:, 77:, 1024:] = 0
+        cp = torch.randn((self.batch, 768), generator=self.g).to(torch.bfloat16)
+        return x0.cuda(), c.to(torch.bfloat16).cuda(), cp.cuda()
+
+
+def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reducer=False, slots=False, lr=1e-3, accum=1):
+    """One trainer: three eager warm-up steps, snapshot of everything (parameters, AdamW state, loss scale, every RNG stream),
+    n_steps eager; restore; capture; n_steps replayed with the given host pattern between replays.  Returns (eager losses,
+    replayed losses, eager final parameters, replayed final parameters, trainer)."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd import engine, packing
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+
+    overlap = engine._WG_OVERLAP
+    try:
+        engine._WG_OVERLAP = False
+        torch.manual_seed(0)
+        dev = torch.device("cuda:0")
+        net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                         device=dev, positional_encoding="RoPE2d", checkpoint_MLP=False, checkpoint_attn=False, **CONFIGS[cname])
+        net.load_state_dict(make_state_dict(0, **CONFIGS[cname]))
+        src = _CpuSource(batch, max_res // 8, 77) if slots else None
+        tr = model_trainer(net, batchSize=batch, accumulation_steps=accum, totalSteps=100, lr=lr, ema_update_freq=1, ema_decay=0.9, warmup_steps=8,
+                           use_lr_scheduler=False, device=dev, saveDir="/tmp/_t", numSaveSteps=100, null_prob_pooled=0.1,
+                           null_prob_gemma=0.316, null_prob_bert=0.316, max_res=max_res, device_rng=not slots, use_ema=False,
+                           force_reducer=force_reducer, data_source=src)
+        assert tr.reducer.enabled == force_reducer
+        for s in (1, 2, 3):
+            tr.train_step(s)
+        torch.cuda.synchronize()
+        params = [p for p in net.parameters()]
+        snap_p = [p.detach().clone() for p in params]
+        snap_o = {id(p): {k: v.clone() for k, v in tr.optim.state[p].items()} for p in params if p in tr.optim.state}
+        snap_s = (tr.grad_scaler._scale.clone(), tr.grad_scaler._growth_tracker.clone())
+
+        def rng_get():
+            return (torch.get_rng_state(), torch.cuda.get_rng_state(), tr._gen.get_state() if tr._gen is not None else None,
+                    (src.g if slots else tr.data_source.g).get_state())
+
+        def rng_set(st):
+            torch.set_rng_state(st[0])
+            torch.cuda.set_rng_state(st[1])
+            if tr._gen is not None:
+                tr._gen.set_state(st[2])
+            (src.g if slots else tr.data_source.g).set_state(st[3])
+
+        snap_r = rng_get()
+
+        def steps():
+            out = []
+            for s in range(4, 4 + n_steps):
+                l = tr.train_step(s)
+                if pattern == "each":
+                    out.append(float(l))
+                elif pattern == "sync":      # the host waits for the GPU between replays and reads nothing: the graph is launched on an idle stream
+                    torch.cuda.synchronize()
+                    out.append(l.clone())
+                else:                        # burst: replays back to back
+                    out.append(l.clone())
+            torch.cuda.synchronize()
+            return [float(x) for x in out], [p.detach().clone() for p in params]
+
+        l0, p0 = steps()
+        with torch.no_grad():
+            for p, q in zip(params, snap_p):
+                p.copy_(q)
+                for k, v in snap_o.get(id(p), {}).items():
+                    tr.optim.state[p][k].copy_(v)
+            tr.grad_scaler._scale.copy_(snap_s[0])
+            tr.grad_scaler._growth_tracker.copy_(snap_s[1])
+        packing.bump_epoch()                       # the parameters were rewritten: their bf16 operand copies are stale
+        tr.scheduler.step(3)
+        hw = max_res // 8
+        x, c, cp = [a.cuda() for a in make_inputs(3, 2, hw, hw)]
+        net(x, torch.tensor([0.3, 0.7]), c, cp).sum().backward()      # (one eager pass refreshes the bf16 copies outside the capture)
+        tr.optim.zero_grad()
+        rng_set(snap_r)
+        if slots:                                   # the capture draws one batch per micro-step to size its input slots: give it back
+            tr.capture_graph(4)
+            rng_set(snap_r)
+        else:
+            tr.capture_graph(4)
+        assert tr._graph is not None
+        l1, p1 = steps()
+    finally:
+        engine._WG_OVERLAP = overlap
+    return l0, l1, p0, p1, tr
+
+
+def check(l0, l1, p0, p1, tag):
+    print(f"[graph {tag}] eager losses {l0}  replayed {l1}")
+    # step 4: same parameters, same batch, deterministic forward and loss reduction -> bit-identical; later steps to the run-to-run
+    # noise of the backward (fp32 atomic column sums, tools/probes/determinism.py)
+    assert l0[0] == l1[0] and np.allclose(l0, l1, rtol=1e-3), (l0, l1)
+    assert all(1e-3 < x < 10 for x in l1)
+    for a, b in zip(p0, p1):
+        assert rel(a, b) < 1e-3 and float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6
+
+
+def test_b_size_replay_with_synchronize_between_replays():
+    """MMDiT-B, batch 64 (the bench's step), the host pattern that printed `final_loss: 0.0` in round 2: a device synchronisation
+    after every replay and one read at the end."""
+    l0, l1, p0, p1, tr = graph_vs_eager("b", 64, 256, n_steps=4, pattern="sync", lr=1e-4)
+    check(l0, l1, p0, p1, "B sync")
+    assert float(tr.last_loss) == l1[-1]
+
+
+def test_b_size_replay_burst():
+    l0, l1, p0, p1, _ = graph_vs_eager("b", 64, 256, n_steps=4, pattern="burst", lr=1e-4)
+    check(l0, l1, p0, p1, "B burst")
+
+
+def test_replay_with_static_input_slots_and_cpu_conditioning():
+    """Any data source + the reference's CPU draw of t / null masks (device_rng=False): inputs are copied into static slots before
+    every replay; two accumulation micro-steps per optimizer step."""
+    l0, l1, p0, p1, tr = graph_vs_eager("micro", 4, 128, n_steps=3, pattern="each", slots=True, accum=2)
+    assert tr._slots is not None and len(tr._slots) == 2
+    check(l0, l1, p0, p1, "micro slots accum2")
+
+
+def test_replay_with_other_bucket_shape_runs_eager():
+    """A batch whose shapes differ from the captured ones (aspect-ratio buckets) is an eager step; the graph stays for its shape."""
+    _, _, _, _, tr = graph_vs_eager("micro", 4, 128, n_steps=1, pattern="each", slots=True)
+    src = tr.data_source
+    tr.data_source = _CpuSource(4, 12, 5)           # 96^2 images: 12x12 latents instead of 16x16
+    before = [p.detach().clone() for p in tr.model.parameters()]
+    l = float(tr.train_step(9))
+    assert 1e-3 < l < 10 and tr._graph is not None
+    assert any(not torch.equal(a, b) for a, b in zip(before, tr.model.parameters()))
+    tr.data_source = src
+    assert 1e-3 < float(tr.train_step(10)) < 10
+
+
+def test_replay_with_gradient_collectives_one_rank_rccl():
+    """Data-parallel step captured WITH its collectives: per-block all-reduce on the side stream inside the graph (fork / join edges).
+    One-rank RCCL group (the boxes of this pool have one GPU): the same code path as N ranks, and AVG over one rank is the identity,
+    so the replayed steps must equal the eager steps of the same trainer."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    tr = None
+    try:
+        l0, l1, p0, p1, tr = graph_vs_eager("micro", 4, 128, n_steps=3, pattern="burst", force_reducer=True)
+        assert tr.reducer.enabled and tr.model.grad_reducer is tr.reducer and tr.reducer.buckets > 0
+    finally:
+        if tr is not None:          # the graph holds the captured collectives: release it before the communicator goes away
+            tr._graph = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+    check(l0, l1, p0, p1, "micro 1-rank RCCL")
+
+
+def test_fp8_weight_caches_follow_replays():
+    """the captured AdamW rewrites the bf16 weight copies at every replay; the fp8 / mxfp8 weight caches (keyed on the
+    copies' generation) must notice.  capture -> replay -> sample mxfp8 -> replay -> sample again == fresh model with the same
+    parameters."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.models.diff_model import diff_model
+    _, _, _, _, tr = graph_vs_eager("micro", 4, 128, n_steps=1, pattern="each")
+    net = tr.model
+    x, c, cp = [a.cuda() for a in make_inputs(11, 2, 16, 16, text_scale=30.0)]
+    t = torch.tensor([0.4, 0.6])
+    outs = []
+    for k in range(2):
+        tr.train_step(20 + k)                       # replay
+        net.eval()
+        if k == 0:
+            net.set_precision("mxfp8")      # (clears the quantised-weight caches)
+        else:
+            net.precision = "mxfp8"          # (does not: the caches must notice the replay by themselves)
+        with torch.no_grad():
+            v = net(x, t, c.clone(), cp.clone())
+        fresh = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                           device=torch.device("cuda:0"), positional_encoding="RoPE2d", **CONFIGS["micro"])
+        fresh.load_state_dict(net.state_dict())
+        fresh.set_precision("mxfp8")
+        fresh.eval()
+        with torch.no_grad():
+            vf = fresh(x, t, c.clone(), cp.clone())
+        outs.append((v.clone(), vf.clone()))
+        net.precision = "fast"
+        net.train()
+    for k, (v, vf) in enumerate(outs):
+        assert torch.equal(v, vf), f"mxfp8 forward after replay {k} used stale quantised weights (rel {rel(v, vf):.3e})"
+    assert not torch.equal(outs[0][0], outs[1][0])      # (the replay in between did change the weights)
+    net.set_precision("fast")

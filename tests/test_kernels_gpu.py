@@ -3,11 +3,15 @@ same op, on seeded inputs.  Tolerances: fp32 / split-bf16 paths 1e-5..1e-4 relat
 bounded by bf16 rounding of inputs/outputs (stated per test)."""
 import math
 
+import numpy as np
+
 import os
 
 import pytest
 import torch
 import torch.nn.functional as F
+
+from oracle.weights import make_state_dict  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -834,3 +838,49 @@ def test_clip_adamw_rewrites_bf16_operand_copies(ops):
     snap = pk1._buf.clone()
     found_inf, _ = opt.step_clipped(None, 1.0)
     assert float(found_inf) == 1.0 and torch.equal(pk1.get(engine.FAST), snap)
+
+
+def test_flow_loss_matches_torch_expression():
+    """ops.flow_loss (mmdit_flow_loss) == the trainer's torch expression (reference model_trainer.py:429-446):
+    mean((v - (eps - x0))^2) / accumulation_steps with the bf16 label rounding of torch's bf16 subtraction, and its gradient;
+    bit-reproducible from call to call (fixed-order reduction, no atomics)."""
+    from sd3_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for shape, dt, accum in (((64, 16, 32, 32), torch.bfloat16, 1), ((4, 16, 16, 16), torch.bfloat16, 2), ((3, 16, 12, 20), torch.float32, 1)):
+        v = torch.randn(shape, generator=g, device="cuda")
+        x0 = torch.randn(shape, generator=g, device="cuda").to(dt)
+        eps = torch.randn(shape, generator=g, device="cuda").to(dt)
+        vr = v.clone().requires_grad_(True)
+        ref = torch.nn.MSELoss(reduction="none")(vr, (eps - x0).to(torch.float32)).flatten(1, -1).mean() / accum
+        ref.backward()
+        loss, dv = ops.flow_loss(v, x0, eps, accum)
+        loss2, dv2 = ops.flow_loss(v, x0, eps, accum)
+        assert torch.equal(loss, loss2) and torch.equal(dv, dv2)
+        assert abs(float(loss) - float(ref)) <= 2e-6 * abs(float(ref)), (float(loss), float(ref))
+        assert float((dv - vr.grad).abs().max()) <= 1e-6 * float(vr.grad.abs().max())
+        assert ops.flow_loss(v, x0, eps, accum, need_grad=False)[1] is None
+    with pytest.raises(RuntimeError):
+        ops.flow_loss(v, x0.to(torch.bfloat16), eps, 1)
+
+
+def test_trainer_hip_loss_equals_torch_loss_step():
+    """model_trainer(hip_loss=True) and (hip_loss=False) take the same two optimizer steps (same seeds): equal losses to fp32
+    summation order, parameters to the backward's own run-to-run noise."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.models.diff_model import diff_model
+    res = []
+    for hip_loss in (True, False):
+        torch.manual_seed(0)
+        net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu",
+                         device=torch.device("cuda:0"), positional_encoding="RoPE2d", dim=128, num_heads=2, num_blocks=3)
+        net.load_state_dict(make_state_dict(0, dim=128, num_heads=2, num_blocks=3))
+        tr = model_trainer(net, batchSize=4, accumulation_steps=2, totalSteps=10, lr=1e-3, ema_update_freq=1, ema_decay=0.9, warmup_steps=2,
+                           use_lr_scheduler=False, device=torch.device("cuda:0"), saveDir="/tmp/_t", numSaveSteps=100, max_res=128,
+                           device_rng=True, use_ema=False, hip_loss=hip_loss)
+        losses = [float(tr.train_step(s)) for s in (1, 2)]
+        torch.cuda.synchronize()
+        res.append((losses, [p.detach().clone() for p in net.parameters()]))
+    assert np.allclose(res[0][0], res[1][0], rtol=1e-5), (res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6

@@ -133,6 +133,21 @@ def test_oracle_sampler_and_gelu(golden_dir):
     assert rel(v, torch.from_numpy(gg["v"])) < 1e-6
 
 
+def test_oracle_heun_and_stochastic_samplers(golden_dir):
+    """The reference's "heun" and "euler_stochastic" sample_imgs loops (src/models/diff_model.py:434-462; goldens from the real
+    reference: tools/make_goldens_samplers.py, identity decode with shift 0 / scale 8) against the oracle restatement."""
+    gold = np.load(os.path.join(golden_dir, "sampler_micro_variants.npz"))
+    sd = make_state_dict(0, **CONFIGS["micro"])
+    _, th, tp = make_inputs(40, 1, 16, 16, text_scale=30.0)
+    for sampler in ("heun", "euler_stochastic"):
+        gen = torch.Generator().manual_seed(99)
+        noise = torch.randn((2, 16, 16, 16), generator=gen)
+        assert torch.equal(noise, torch.from_numpy(gold["noise"]))
+        lat = O.cfg_sample(sd, O.OracleConfig(**CONFIGS["micro"]), noise, th, tp, 4, 3.0, sampler, gen)
+        assert rel((lat / 8.0).clamp(-1, 1), torch.from_numpy(gold["out_" + sampler])) < 1e-5, sampler
+    assert rel(torch.from_numpy(gold["out_heun"]), torch.from_numpy(gold["out_euler_stochastic"])) > 0.1     # (the two goldens are not interchangeable)
+
+
 def test_oracle_rounding_modes_distance():
     """The fast-mode rounding model sits a few 1e-3 from the fp32 reference arithmetic; exact attention ~1e-3 or below."""
     sd = make_state_dict(0, **CONFIGS["micro"])
@@ -154,7 +169,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert _lib.lib().mmdit_abi_version() == 1 and _lib.lib().mmdit_build_arch() == b"gfx950"
+    assert _lib.lib().mmdit_abi_version() == _lib.ABI_VERSION == 3 and _lib.lib().mmdit_struct_size(0) == ctypes.sizeof(_lib.GemmArgs) and _lib.lib().mmdit_build_arch() == b"gfx950"
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -286,3 +286,66 @@ def test_trainer_accumulation_reduces_once_per_optimizer_step(accum):
     for a, p in zip(res[0][0], net.parameters()):
         assert torch.allclose(torch.from_numpy(a), p.detach(), atol=1e-6)
     assert abs(0.5 * (res[0][1][0] + res[1][1][0]) - losses[0]) < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The selectable bucket algorithms (reducer.ALGORITHMS): RCCL's all-reduce, reduce-scatter + all-gather, and the "direct" one
+# (reduce-scatter and all-gather as one all-to-all each, local fp32 sum of the received shards, optional bf16 wire format).
+def _algo_worker(rank, world, port, algo, wire, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sd3_amd  # noqa: F401
+    from sd3_amd.reducer import GradReducer
+    red = GradReducer(algorithm=algo, wire_dtype=torch.bfloat16 if wire == "bf16" else None)
+    g = torch.Generator().manual_seed(40 + rank)
+    arena = torch.randn(2048, generator=g)                     # an engine arena (a multiple of engine.ARENA_QUANTUM): averaged in place
+    views = [arena[:1000].view(10, 100), arena[1000:2040]]
+    assert red.add_bucket(views, arenas=[arena]) is None
+    odd = [torch.randn(5, 7, generator=g), torch.randn(11, generator=g)]     # 46 elements + padding to the world size inside the reducer
+    repl = red.add_bucket(odd)
+    tiny = torch.randn(3, generator=g)                          # 3 elements, world 2: not divisible -> that bucket falls back to all-reduce
+    assert red.add_bucket([tiny[:2], tiny[2:]], arenas=[tiny]) is None
+    red.finish()
+    assert red.buckets == 3
+    q.put((rank, [arena.numpy().copy(), repl[0].numpy().copy(), repl[1].numpy().copy(), tiny.numpy().copy()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo,wire", [("allreduce", "f32"), ("rs_ag", "f32"), ("direct", "f32"), ("direct", "bf16")])
+def test_two_rank_gloo_bucket_algorithms(algo, wire):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_algo_worker, args=(r, world, port, algo, wire, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    per_rank = []
+    for rank in range(world):
+        g = torch.Generator().manual_seed(40 + rank)
+        per_rank.append([torch.randn(2048, generator=g), torch.randn(5, 7, generator=g), torch.randn(11, generator=g), torch.randn(3, generator=g)])
+    want = [(a + b) / 2 for a, b in zip(*per_rank)]
+    for i, (a, b, w) in enumerate(zip(res[0], res[1], want)):
+        assert (a == b).all(), "ranks diverged"
+        got = torch.from_numpy(a)
+        if wire == "f32" or i == 3:      # fp32 wire: the two-rank mean is exact in every algorithm (one addition, one halving)
+            assert torch.equal(got, w), (algo, i)
+        else:                             # bf16 wire: operands and the gathered mean are bf16-rounded (2^-9 relative each)
+            assert torch.allclose(got, w, rtol=2 ** -7, atol=2e-2) and not torch.equal(got, w)
+
+
+def test_engine_arenas_are_shardable():
+    """The flat gradient arenas the engine hands to the reducer are multiples of ARENA_QUANTUM elements (equal shards for every world
+    size that divides it), also the prefix of the small-gradient arena."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd import engine
+    views, prefix = engine._zeros_views([(7,), (130,), (64,), (3, 5)], torch.device("cpu"), prefix=3)
+    assert prefix.numel() % engine.ARENA_QUANTUM == 0 and prefix.numel() >= 7 + 130 + 64
+    assert views[3].data_ptr() == prefix.data_ptr() + 4 * prefix.numel()       # scratch views start right behind the padded prefix
+    assert all(float(v.abs().sum()) == 0 for v in views)
+    assert engine.ARENA_QUANTUM % 8 == 0
