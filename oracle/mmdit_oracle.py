@@ -74,6 +74,11 @@ class OracleConfig:
     text_hidden: int = 2304
     attn_core: str = "oracle_bf16"
     gemm: str = "fp32"
+    # arithmetic dtype: float32 = the reference; float64 (with a float64 state dict and inputs) = the same algorithm and the same
+    # bf16 rounding points of the attention core in exact arithmetic -- the yardstick that separates the reference's own fp32
+    # rounding noise from an implementation's (tools/probes/parity_budget.py).  Tables the reference computes in fp32 (time-embedding
+    # denominators, RoPE angles and their cos / sin) keep their fp32 values.
+    dtype: torch.dtype = torch.float32
 
     @property
     def head_dim(self):
@@ -157,7 +162,7 @@ def positional_encoding(time: torch.Tensor, dim: int) -> torch.Tensor:
     denom_i = 10000^(2i/dim) for i = 0..dim-1 (not dim/2); output is
     cat(sin(e[:, 0::2]), cos(e[:, 1::2]))."""
     denom = (torch.tensor(10000.0) ** ((2 * torch.arange(dim)) / dim)).to(torch.float32)
-    e = time[:, None] / denom[None, :]
+    e = time[:, None] / denom[None, :].to(time.dtype)
     return torch.cat((e[:, ::2].sin(), e[:, 1::2].cos()), dim=1)
 
 
@@ -199,7 +204,7 @@ def rotate_half(x):
 
 def apply_rope(freqs, t):
     """apply_rotary_emb (blocks/rotary_embedding.py:43-76), full-width rotation."""
-    return t * freqs.cos() + rotate_half(t) * freqs.sin()
+    return t * freqs.cos().to(t.dtype) + rotate_half(t) * freqs.sin().to(t.dtype)
 
 
 def attention_core(q, k, v, scale: float, mode: str):
@@ -339,16 +344,16 @@ def forward(sd: Dict[str, torch.Tensor], cfg: OracleConfig, x_t, t, c, c_pooled,
         if nullCls_bert is not None:
             c[nullCls_bert, 77:] *= 0
     d = cfg.dim
-    pe = positional_encoding(t.float() * sd["time_scale"], d)
+    pe = positional_encoding(t.to(cfg.dtype) * sd["time_scale"], d)
     t_emb = _lin(cfg, pe, sd["t_emb2.weight"])
-    y = t_emb + _lin(cfg, c_pooled.to(torch.float32), sd["cond_MLP.weight"])
+    y = t_emb + _lin(cfg, c_pooled.to(cfg.dtype), sd["cond_MLP.weight"])
     hw = x_t.shape[-2:]
-    cf = c.to(torch.float32)
+    cf = c.to(cfg.dtype)
     ctx = torch.cat([
         _lin(cfg, sd["learnable_scalar"] * rms_norm(cf[:, :77], sd["pre_c_norm.weight"]), sd["c_proj.weight"]),
         _lin(cfg, sd["learnable_scalar2"] * rms_norm(cf[:, 77:], sd["pre_c_norm2.weight"]), sd["c_proj2.weight"]),
     ], dim=1)
-    X = patch_embed(x_t.to(torch.float32), sd["pos_enc.proj.weight"], cfg)
+    X = patch_embed(x_t.to(cfg.dtype), sd["pos_enc.proj.weight"], cfg)
     X = _lin(cfg, X, sd["patch_emb.weight"], sd["patch_emb.bias"])
     if taps is not None:
         taps.update(y=y.detach(), c0=ctx.detach(), x0=X.detach(), blocks=[])

@@ -120,6 +120,7 @@ class model_trainer:
         # graph_after=N: train() captures the optimizer step into a hipGraph after N eager steps and replays it from then on
         # (None: every step is issued from the host, as the reference does)
         self.graph_after = graph_after
+        self.keep_graph = False      # True: capture_graph() keeps the hipGraph_t next to the executable graph (graph_node_types())
         if text_loss_weight != 0.0:
             raise RuntimeError("text_loss is out of scope on the HIP path (text_loss_weight must be 0)")
         if loader_to_model_gpu not in (None, {}):
@@ -234,7 +235,7 @@ class model_trainer:
         x0 = batch_x_0.to(epsilon_t.device)
         if self.hip_loss and v_pred.is_cuda and v_pred.dtype == torch.float32 and x0.dtype == epsilon_t.dtype and v_pred.numel() % 8 == 0:
             # same arithmetic as the torch expression below in two HIP launches with a bit-reproducible reduction (ops.flow_loss)
-            loss = _FlowLoss.apply(v_pred, x0, epsilon_t, self.accumulation_steps)
+            loss = _FlowLoss.apply(v_pred, x0.contiguous(), epsilon_t.contiguous(), self.accumulation_steps)     # (unpadded bucket latents are strided views)
         else:
             labels = epsilon_t - x0
             loss = nn.MSELoss(reduction="none")(v_pred, labels.detach().to(v_pred.dtype)).flatten(1, -1).mean()
@@ -362,7 +363,7 @@ class model_trainer:
         # the loss leaves the graph through a persistent buffer written by a kernel of the graph (not through a tensor of the graph's
         # private pool, whose block is shared with earlier temporaries of the step): DESIGN.md 5, "final_loss 0.0"
         self._loss_out = torch.zeros((), dtype=torch.float32, device=self.device)
-        g = torch.cuda.CUDAGraph()
+        g = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
         for gen in (self._gen, getattr(self.data_source, "g", None)) if in_graph else ():
             if gen is not None:
                 g.register_generator_state(gen)
@@ -386,6 +387,31 @@ class model_trainer:
         self.optim.after_replay()   # (the capture itself executed nothing: the eager pointer table / copies bookkeeping is void)
         self._graph = g
         return g
+
+    def graph_node_types(self):
+        """Histogram of the captured step's node kinds {"kernel": n, "memcpy": n, "memset": n, ...} (needs keep_graph=True before
+        capture_graph()).  The step must not contain memset nodes: a hipMemsetAsync captured into a hipGraph does not reliably keep
+        its place in the stream order when the graph is replayed on ROCm 7 (tools/probes/graph_memset_order.py)."""
+        import ctypes
+        if self._graph is None or not self.keep_graph:
+            raise RuntimeError("graph_node_types: set keep_graph = True before capture_graph()")
+        hip = ctypes.CDLL("libamdhip64.so")
+        graph = ctypes.c_void_p(self._graph.raw_cuda_graph())
+        n = ctypes.c_size_t(0)
+        if hip.hipGraphGetNodes(graph, None, ctypes.byref(n)) != 0:
+            raise RuntimeError("hipGraphGetNodes failed")
+        nodes = (ctypes.c_void_p * n.value)()
+        if hip.hipGraphGetNodes(graph, nodes, ctypes.byref(n)) != 0:
+            raise RuntimeError("hipGraphGetNodes failed")
+        names = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event", 7: "event_record"}
+        hist = {}
+        for node in nodes:
+            t = ctypes.c_int(-1)
+            if hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(t)) != 0:
+                raise RuntimeError("hipGraphNodeGetType failed")
+            k = names.get(t.value, f"type{t.value}")
+            hist[k] = hist.get(k, 0) + 1
+        return hist
 
     def _write_loss(self, loss):
         torch.mul(loss.detach().to(torch.float32).reshape(()), 1.0, out=self._loss_out)

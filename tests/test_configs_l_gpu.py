@@ -71,8 +71,9 @@ class _Enc:
 
 def test_l_forward_vs_reference_golden(golden_dir):
     """One MMDiT-L forward (batch 1, 64x64 latents, Gemma-like text x30) against the reference's output:
-    parity mode < 2e-3 (24 blocks: the reference's own bf16 attention core sits ~1e-3 from exact-softmax arithmetic at this
-    depth, tests/golden/generation_report_l.json), fast (bf16) mode < 2e-2 and < 8e-3 from the oracle with the same rounding points."""
+    parity mode < 1e-3 (north_star's bar; measured 8.0e-4, and the reference itself is 7.8e-4 from its own 1-thread run and 7.9e-4 from
+    exact arithmetic with the same rounding points on this input: tests/golden/noise_floor_b.json "l_plain"), fast (bf16) mode < 2e-2
+    and < 8e-3 from the oracle with the same rounding points."""
     gold = np.load(os.path.join(golden_dir, "forward_l_plain.npz"))
     x, c, cp = make_inputs(50, 1, 64, 64, text_scale=30.0)
     t = torch.tensor([0.35])
@@ -86,7 +87,7 @@ def test_l_forward_vs_reference_golden(golden_dir):
         vo = O.forward(sd, O.OracleConfig(**L_CFG, attn_core="flash_bf16", gemm="bf16"), x.clone(), t, c.clone(), cp.clone())
     r_par, r_fast, r_fo = rel(v_par, ref), rel(v_fast, ref), rel(v_fast, vo)
     print(f"[L] parity vs reference {r_par:.3e}; fast vs reference {r_fast:.3e}; fast vs rounding-matched oracle {r_fo:.3e}")
-    assert r_par < 2e-3 and r_fast < 2e-2 and r_fo < 8e-3
+    assert r_par < 1e-3 and r_fast < 2e-2 and r_fo < 8e-3
 
 
 def test_l_full_size_properties_batch16():

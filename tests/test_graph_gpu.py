@@ -40,7 +40,7 @@ class _CpuSource:
         return x0.cuda(), c.to(torch.bfloat16).cuda(), cp.cuda()
 
 
-def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reducer=False, slots=False, lr=1e-3, accum=1):
+def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reducer=False, slots=False, lr=1e-3, accum=1, keep_graph=False, hip_loss=True):
     """One trainer: three eager warm-up steps, snapshot of everything (parameters, AdamW state, loss scale, every RNG stream),
     n_steps eager; restore; capture; n_steps replayed with the given host pattern between replays.  Returns (eager losses,
     replayed losses, eager final parameters, replayed final parameters, trainer)."""
@@ -61,7 +61,8 @@ def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reduc
         tr = model_trainer(net, batchSize=batch, accumulation_steps=accum, totalSteps=100, lr=lr, ema_update_freq=1, ema_decay=0.9, warmup_steps=8,
                            use_lr_scheduler=False, device=dev, saveDir="/tmp/_t", numSaveSteps=100, null_prob_pooled=0.1,
                            null_prob_gemma=0.316, null_prob_bert=0.316, max_res=max_res, device_rng=not slots, use_ema=False,
-                           force_reducer=force_reducer, data_source=src)
+                           force_reducer=force_reducer, data_source=src, hip_loss=hip_loss)
+        tr.keep_graph = keep_graph
         assert tr.reducer.enabled == force_reducer
         for s in (1, 2, 3):
             tr.train_step(s)
@@ -141,6 +142,20 @@ def test_b_size_replay_with_synchronize_between_replays():
     l0, l1, p0, p1, tr = graph_vs_eager("b", 64, 256, n_steps=4, pattern="sync", lr=1e-4)
     check(l0, l1, p0, p1, "B sync")
     assert float(tr.last_loss) == l1[-1]
+
+
+def test_captured_step_has_no_memset_nodes():
+    """The hazard behind round 2's lost loss is structural: any hipMemsetAsync inside the captured step is a memset NODE, and those do
+    not reliably keep their stream order on replay.  The captured step (HIP loss) must contain kernel and memcpy nodes only; with the
+    torch loss expression (hip_loss=False) torch's multi-block mean() brings one in -- which is how this test knows it can see them."""
+    _, _, _, _, tr = graph_vs_eager("b", 64, 256, n_steps=1, pattern="each", lr=1e-4, keep_graph=True)
+    hist = tr.graph_node_types()
+    print(f"[graph nodes] MMDiT-B step, HIP loss: {hist}")
+    assert hist.get("kernel", 0) > 300 and hist.get("memset", 0) == 0, hist
+    _, _, _, _, tr = graph_vs_eager("b", 64, 256, n_steps=1, pattern="each", lr=1e-4, keep_graph=True, hip_loss=False)
+    hist2 = tr.graph_node_types()
+    print(f"[graph nodes] MMDiT-B step, torch loss expression: {hist2}")
+    assert hist2.get("memset", 0) >= 1, hist2
 
 
 def test_b_size_replay_burst():
