@@ -125,6 +125,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
   auto vt = [&](int i) { return smem + 2 * KT * P144 + i * KT * P192; };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  MMDIT_YOUNG_HALF_PRIO();
   int qtile, bh;
   map_block((S + 32 * NW - 1) / (32 * NW), BH, qtile, bh);
   const int h = bh % H;
@@ -321,6 +322,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
   constexpr int NW = 8;
   __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  MMDIT_YOUNG_HALF_PRIO();
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   int qtile, bh;
   map_block((S + 32 * NW - 1) / (32 * NW), BH, qtile, bh);
@@ -520,6 +522,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_pers_kernel(const bf16_t* __r
   constexpr int NW = 8;
   __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  MMDIT_YOUNG_HALF_PRIO();
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   const int ntile = (S + 32 * NW - 1) / (32 * NW), items = ntile * BH, G = (int)gridDim.x;
   const int nkv = (S + KT - 1) / KT;
@@ -759,6 +762,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
   constexpr int NW = 4, QW = 64;     // waves, queries per wave
   __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  MMDIT_YOUNG_HALF_PRIO();
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   int qtile, bh;
   map_block((S + QW * NW - 1) / (QW * NW), BH, qtile, bh);
@@ -949,6 +953,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
   char* ktile = smem;
   char* vtile = smem + KT * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  MMDIT_YOUNG_HALF_PRIO();
   int qtile, bh;
   map_block((S + 32 * NW - 1) / (32 * NW), BH, qtile, bh);
   const int h = bh % H;
@@ -1056,6 +1061,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
   float* lse_s = (float*)(smem + 2 * KT * 128);
   float* del_s = lse_s + KT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  MMDIT_YOUNG_HALF_PRIO();
   int ktile, bh;
   map_block((S + 32 * NW - 1) / (32 * NW), BH, ktile, bh);
   const int h = bh % H;
@@ -1195,6 +1201,7 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   return mmdit_launch_status();
 }
 
+#ifdef MMDIT_PROBES   // probe entry points are not part of the product library: bash tools/build_variant.sh probes -DMMDIT_PROBES, then MMDIT_LIB=tools/scratch/probes/libmmdit_hip.so
 // measurement aid (tools/probes/attn_trace.py; not declared in include/mmdit_hip.h): the 64-queries-per-wave forward with per-phase
 // s_memtime stamps, trace = 2048 workgroups x 4 waves x 40 slots of 8 bytes
 extern "C" int mmdit_probe_attn_fwd_trace(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
@@ -1203,6 +1210,8 @@ extern "C" int mmdit_probe_attn_fwd_trace(const void* Q, const void* K, const vo
                      (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, (unsigned long long*)trace);
   return mmdit_launch_status();
 }
+
+#endif
 
 extern "C" int mmdit_attn_fwd_mx(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
                                  void* Ox_fp8, void* Oc_fp8, void* scales_x, void* scales_c, mmdit_stream_t stream) {
@@ -1213,6 +1222,7 @@ extern "C" int mmdit_attn_fwd_mx(const void* Q, const void* K, const void* V, in
   return mmdit_launch_status();
 }
 
+#ifdef MMDIT_PROBES
 // measurement aid (tools/probes/attn_ablate.py; not part of include/mmdit_hip.h): the forward kernel with parts of its loop removed
 extern "C" int mmdit_probe_attn_fwd_dbg(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
                                         void* Ox, void* Oc, float* lse, int dbg, mmdit_stream_t stream) {
@@ -1225,6 +1235,8 @@ extern "C" int mmdit_probe_attn_fwd_dbg(const void* Q, const void* K, const void
 #undef MMDIT_DBG
   return mmdit_launch_status();
 }
+
+#endif
 
 extern "C" int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc, const void* dOx, const void* dOc,
                               const float* lse, float* delta, int batch, int heads, int S, int n_img, float scale,

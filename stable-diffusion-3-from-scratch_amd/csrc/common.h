@@ -129,6 +129,23 @@ __device__ __forceinline__ int64_t mx_scale_index(int row, int blk, int rows) {
 // transpose read: lane gets 4 bf16 = column (lane&15) of the 4x16 block whose rows are addressed by the 16-lane group
 __device__ __forceinline__ s16x4 lds_tr16(const void* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p)); }
 
+// Static priority for the second-dispatched half of an 8-wave workgroup (MI355X_MICROARCH.md "Two waves per SIMD", item 4): the two waves
+// of a SIMD arbitrate VALU issue by priority, then age, so waves 4-7 lose every contended slot; ONE s_setprio 1 for that half, no
+// per-segment flips.  The condition must be provably wave-uniform (s_setprio ignores EXEC).  Experiment switch: -DMMDIT_STATIC_PRIO.
+#ifdef MMDIT_STATIC_PRIO
+#define MMDIT_YOUNG_HALF_PRIO() do { if (__builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1); } while (0)
+#else
+#define MMDIT_YOUNG_HALF_PRIO() do { } while (0)
+#endif
+
+// Experiment switch -DMMDIT_MFMA_PRIO: raise the wave's priority around each MFMA row of the GEMM main loops (cdna_hip_programming.md T5:
+// +21-25 % on a phase-split schedule, ~0 on a lockstep one).
+#ifdef MMDIT_MFMA_PRIO
+#define MMDIT_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define MMDIT_PRIO(x) do { } while (0)
+#endif
+
 static inline int mmdit_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? 0 : (int)e;

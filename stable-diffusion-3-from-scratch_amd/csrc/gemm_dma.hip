@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
   static_assert(PA >= 1 && PB >= 1 && PP <= 2 * MI && PP <= 4, "piece schedule");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  MMDIT_YOUNG_HALF_PRIO();
   const int wm = wave / WN, wn = wave % WN;
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   // epilogue staging: the ring slot that is free between the barrier of half_sync and the next DMA issue (when a slot
@@ -291,9 +292,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_dma_kernel(GroupParams gp) 
 #pragma unroll
         for (int i = 0; i < MI; i++) {
           __builtin_amdgcn_sched_barrier(0);
+          MMDIT_PRIO(1);
 #pragma unroll
           for (int j = 0; j < NJ; j++)
             if constexpr (!FP8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
+          MMDIT_PRIO(0);
           a[i] = ldA(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1);
           const int q = ks * MI + i;   // compile-time after unrolling
           if (q % DSTRIDE == 0 && q / DSTRIDE < PP) {

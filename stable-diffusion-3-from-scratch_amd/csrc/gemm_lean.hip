@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_lean_kernel(GroupParams gp)
   static_assert(NW * EP32_WAVE_BYTES <= H && NJ == 2, "epilogue staging lives in a ring slot; wave sub-tile is 64 columns wide");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  MMDIT_YOUNG_HALF_PRIO();
   const int wm = wave / WN, wn = wave % WN;
   const bool hi = PA_REM && wave < PA_REM;                           // this wave carries PA_HI A pieces per half
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GroupParams gp)
   static_assert(NW * EP32_WAVE_BYTES <= H && NJ == 2, "epilogue staging lives in the idle slot; wave sub-tile is 64 columns wide");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  MMDIT_YOUNG_HALF_PRIO();
   const int wm = wave / WN, wn = wave % WN;
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   const int G = (int)gridDim.x;
@@ -339,8 +341,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GroupParams gp)
 #pragma unroll
       for (int i = 0; i < MI; i++) {
         __builtin_amdgcn_sched_barrier(0);
+        MMDIT_PRIO(1);
 #pragma unroll
         for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
+        MMDIT_PRIO(0);
         if (!last) a[i] = load_frag_w(ta, wm * (MI * 32) + i * 32, ks + 1, lane);
         const int q = ks * MI + i;   // compile-time after unrolling
         if (q % DSTRIDE == 0 && q / DSTRIDE < PPS) {

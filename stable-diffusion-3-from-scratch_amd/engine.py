@@ -413,6 +413,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
 
 _LN_PAIR = _os.environ.get("MMDIT_LN_PAIR", "1") != "0"      # image + text rows of the adaLN / QK-norm+RoPE / MLP-activation-backward kernels in one launch (A/B switch)
 _MX_FUSE = _os.environ.get("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
+_BATCH_WMOD = _os.environ.get("MMDIT_BATCH_WMOD", "1") != "0"   # single-rank backward: the modulation-matrix weight gradients of all blocks in one grouped launch (A/B switch)
 _FUSE_GATE = _os.environ.get("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
 
 
@@ -447,7 +448,7 @@ def block_bwd_begin(m, w, sv, dims, dev, defer_cond=False):
     return st
 
 
-def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None, dacc=None, nxt=None):
+def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None, dacc=None, nxt=None, defer_wmod=False):
     """dX2 (B*N,d) fp32, dC2 (B*M,d) fp32 or None, dy_acc (B,d) fp32 or None.
     Returns dX, dC, dy_acc', grads (NS keyed like the packed weights).
     defer_cond: leave the backward of y' = SiLU(W_y y + b) to cond_bwd_all (one launch set for all blocks): the third
@@ -544,10 +545,16 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None,
 
     # ---- modulation vectors and y_proj
     dmod_a = m.act(dmod)
-    defer(g, "Wmod", dmod_a, sv.yp)
     if defer_cond:
+        # defer_wmod: the M = batch weight gradient of the modulation matrix is left to the caller as well -- model_bwd issues those of
+        # all blocks in ONE grouped launch at the end (twelve 21-us launches of a few tiles each are pure ramp-up and tail).  Not with a
+        # data-parallel reducer: there every block's gradients must be complete when the block is handed over, so that their all-reduce
+        # overlaps the rest of the backward instead of landing in the last, exposed bucket.
+        if not defer_wmod:
+            defer(g, "Wmod", dmod_a, sv.yp)
         dy_acc = dmod_a
     else:
+        defer(g, "Wmod", dmod_a, sv.yp)
         dyp = _dgrad(m, dmod_a, w.Wmod, F32, **({"split_k": 16} if m.fast else {}))   # M = batch: 6 tiles, K = 12 d
         dpre = ops.silu_bwd(dyp, sv.pre, m.T, g.by)
         dy_acc = _dgrad(m, dpre, w.Wy, F32, residual=dy_acc)
@@ -669,14 +676,18 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
     dC = None
     g.blocks = [None] * nblk
     dmods = [None] * nblk
+    yps = [None] * nblk
+    batch_wmod = on_grads is None and _BATCH_WMOD
     for i in range(nblk - 1, -1, -1):
         if i > 0:
             sts[i - 1] = block_bwd_begin(m, W.blocks[i - 1], sv.blocks[i - 1], sv.dims, dev, defer_cond=True)
             dX, dC, dmods[i], g.blocks[i], dacc = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, None, sv.dims, rope, defer_cond=True,
-                                                            st=sts[i], dacc=dacc, nxt=sts[i - 1])
+                                                            st=sts[i], dacc=dacc, nxt=sts[i - 1], defer_wmod=batch_wmod)
         else:
-            dX, dC, dmods[i], g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, None, sv.dims, rope, defer_cond=True, st=sts[i], dacc=dacc)
+            dX, dC, dmods[i], g.blocks[i] = block_bwd(m, W.blocks[i], sv.blocks[i], dX, dC, None, sv.dims, rope, defer_cond=True, st=sts[i], dacc=dacc,
+                                                      defer_wmod=batch_wmod)
         sts[i] = None
+        yps[i] = sv.blocks[i].yp
         sv.blocks[i] = None  # free saved activations as we go
         if on_grads is not None:
             # the reducer may hand back views of its flat bucket (zero copy-back): use them as this block's gradients
@@ -701,6 +712,8 @@ def model_bwd(m, W, sv, dv, rope, on_grads=None):
         g.blocks[i].by = by_all[i]
         pending.append((lambda o, i=i: setattr(g.blocks[i], "Wy", o), _wg(dpre_all[i * B:(i + 1) * B], sv.y)))
         late += [(i, "by"), (i, "Wy")]
+        if batch_wmod:
+            pending.append((lambda o, i=i: setattr(g.blocks[i], "Wmod", o), _wg(dmods[i], yps[i])))
 
     # patch embedding
     g.bpe = ops.zeros(d, dev)

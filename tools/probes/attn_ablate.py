@@ -1,4 +1,5 @@
-"""Ablations of the attention forward kernel (mmdit_probe_attn_fwd_dbg): which part of the loop carries the time?"""
+"""(needs a probes build of the library: `bash tools/build_variant.sh probes -DMMDIT_PROBES` and MMDIT_LIB=tools/scratch/probes/libmmdit_hip.so)
+Ablations of the attention forward kernel (mmdit_probe_attn_fwd_dbg): which part of the loop carries the time?"""
 import ctypes, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,4 +1,5 @@
-"""Per-phase cycle trace of the 64-queries-per-wave attention forward (mmdit_probe_attn_fwd_trace): where does a wave's lifetime go?
+"""(needs a probes build of the library: `bash tools/build_variant.sh probes -DMMDIT_PROBES` and MMDIT_LIB=tools/scratch/probes/libmmdit_hip.so)
+Per-phase cycle trace of the 64-queries-per-wave attention forward (mmdit_probe_attn_fwd_trace): where does a wave's lifetime go?
 Stamps per wave: 0 start, 1 Q loaded, then per KV tile [wait done, barrier done, QK done, softmax done], last-1 loop end, last stores done."""
 import ctypes, os, sys
 import torch

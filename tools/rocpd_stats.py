@@ -24,7 +24,7 @@ def main():
     t0, t1 = db.execute("select min(start), max(end) from rocpd_kernel_dispatch").fetchone()
     print(f"total kernel time {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches; trace span {(t1 - t0) / 1e6:.1f} ms")
     print(f"{'kernel':<112} {'calls':>7} {'total_ms':>10} {'avg_us':>9} {'min_us':>8} {'max_us':>8} {'pct':>6}" + ("  ms/step" if steps else ""))
-    for name, n, t, mn, mx in rows[:45]:
+    for name, n, t, mn, mx in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
         line = f"{short(name):<112} {n:>7} {t / 1e6:>10.3f} {t / n / 1e3:>9.2f} {mn / 1e3:>8.2f} {mx / 1e3:>8.2f} {100 * t / tot:>6.2f}"
         if steps:
             line += f" {t / 1e6 / steps:>8.3f}"
