@@ -410,6 +410,44 @@ def test_attention_bwd(ops, Bt, H, N, Mt, last):
     assert rel(dQ, qr.grad) < 1.5e-2 and rel(dK, kr.grad) < 1.5e-2 and rel(dV, vr.grad) < 1.5e-2
 
 
+def test_attention_fwd_bwd_at_mmdit_l_sequence_length(ops):
+    """S = 1178 (MMDiT-L: 1024 image + 154 text tokens; 18 full 64-key tiles + a 26-key tail, five 256-query workgroups with a 154-query
+    tail): forward in both modes and backward against the CPU oracle's attention core (oracle/mmdit_oracle.py attention_core:
+    "oracle_bf16" = the reference's CPU branch, Attention.py:277-284; "fp32" = exact softmax attention under torch autograd) for
+    every (batch, head) of a (1, 2) problem; also the last block's shape (no text output gradient)."""
+    from oracle.mmdit_oracle import attention_core
+    Bt, H, N, Mt = 1, 2, 1024, 154
+    S = N + Mt
+    Q, K, V = [rnd(Bt, H, S, 64, seed=s) for s in (11, 12, 13)]
+    Qb, Kb, Vb = Q.to(torch.bfloat16), K.to(torch.bfloat16), V.to(torch.bfloat16)
+    merge = lambda o: o.permute(0, 2, 1, 3).reshape(Bt, S, H * 64)
+    # forward, reference-rounding mode vs the oracle's restatement of the reference's CPU branch
+    Ox, Oc, _ = ops.attn_fwd(Qb, Kb, Vb, N, 0.125, 1)
+    ref1 = merge(attention_core(Q.cpu(), K.cpu(), V.cpu(), 0.125, "oracle_bf16"))
+    r1 = rel(torch.cat([Ox, Oc], 1).cpu(), ref1)
+    # forward (flash) + backward vs exact attention on the bf16-rounded operands (fp32 autograd on the CPU oracle function)
+    Ox, Oc, lse = ops.attn_fwd(Qb, Kb, Vb, N, 0.125, 0)
+    qr, kr, vr = [t.float().cpu().requires_grad_(True) for t in (Qb, Kb, Vb)]
+    ref0 = merge(attention_core(qr, kr, vr, 0.125, "fp32"))
+    r0 = rel(torch.cat([Ox, Oc], 1).cpu(), ref0.detach())
+    assert r1 < 3e-3 and r0 < 5e-3, (r1, r0)
+    assert (lse.cpu() - torch.logsumexp((qr.detach() @ kr.detach().mT) * 0.125, -1)).abs().max() < 2e-2
+    res = []
+    for last in (False, True):
+        dOx = rnd(Bt, N, H * 64, seed=14).to(torch.bfloat16)
+        dOc = None if last else rnd(Bt, Mt, H * 64, seed=15).to(torch.bfloat16)
+        dQ, dK, dV = ops.attn_bwd(Qb, Kb, Vb, Ox, Oc, dOx, dOc, lse, N, 0.125, torch.float32)
+        for t in (qr, kr, vr):
+            t.grad = None
+        dO = torch.cat([dOx.float().cpu(), torch.zeros(Bt, Mt, H * 64) if last else dOc.float().cpu()], 1)
+        ref0.backward(dO, retain_graph=True)
+        errs = (rel(dQ.cpu(), qr.grad), rel(dK.cpu(), kr.grad), rel(dV.cpu(), vr.grad))
+        res.append(errs)
+        # bf16 P / dS operands: ~1e-2 relative (the same bar as at S <= 410)
+        assert max(errs) < 1.5e-2, (last, errs)
+    print(f"[attention S=1178] fwd oracle-rounding mode {r1:.2e}, flash {r0:.2e}; bwd (dQ, dK, dV) {res[0]} / last block {res[1]}")
+
+
 def test_attention_oracle_mode_matches_cpu_oracle(ops):
     """mode 1 must reproduce the reference's CPU attention branch far below the 1e-3 parity bar."""
     from oracle.mmdit_oracle import attention_core

@@ -68,18 +68,17 @@ def _train(rank, world, data_world, accum, force):
     tr._sample_conditioning = lambda k: (state["t"], None, None, None)
     net.noise_batch = lambda X, t: ((1 - t)[:, None, None, None] * X + t[:, None, None, None] * state["eps"], state["eps"])
     net.train()
-    losses = [float(tr.train_step(s + 1)) for s in range(STEPS)]
-    torch.cuda.synchronize(dev)
-    params = [p.detach().cpu().numpy().copy() for p in net.parameters()]
-    # one more backward WITHOUT an optimizer step: the gradients as the reducer leaves them (averaged over the ranks), compared
-    # directly -- a reducer bug cannot hide behind Adam's sign sensitivity
+    # first a backward WITHOUT an optimizer step, at the (broadcast) initial parameters: the gradients as the reducer leaves them
+    # (averaged over the ranks), compared directly -- a reducer bug cannot hide behind Adam's sign sensitivity
     tr.optim.zero_grad()
     for k in range(accum):
         tr.micro_step(final=(k == accum - 1))
     torch.cuda.synchronize(dev)
     tr.grads = [None if p.grad is None else p.grad.detach().cpu().numpy().copy() for p in net.parameters()]
     tr.optim.zero_grad()
-    return losses, params, tr
+    losses = [float(tr.train_step(s + 1)) for s in range(STEPS)]
+    torch.cuda.synchronize(dev)
+    return losses, [p.detach().cpu().numpy().copy() for p in net.parameters()], tr
 
 
 def _worker(rank, world, port, accum, q):
