@@ -1,10 +1,10 @@
 cd $GRAFT_REPO_ROOT; R=$1
 python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench.err
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace -d gpurun_out/prof_$R -o run -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-roofline > gpurun_out/${R}_prof.log 2>&1
+rocprofv3 --kernel-trace -d gpurun_out/prof_$R -o run -- python3 bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-roofline --no-eager-leg > gpurun_out/${R}_prof.log 2>&1
 DB=$(find gpurun_out/prof_$R -name "*.db" | head -1)
 # steps in the trace: 3 eager warm-up steps (capture needs >= 3) + 2 warm replays + 10 timed replays
-python tools/rocpd_stats.py $DB 15 > gpurun_out/${R}_bench_kernel_stats.txt
+python tools/rocpd_stats.py $DB 15 60 > gpurun_out/${R}_bench_kernel_stats.txt
 python tools/rocpd_gaps.py $DB > gpurun_out/${R}_step_gaps.txt 2>&1
 rm -rf gpurun_out/prof_$R
 bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
@@ -22,4 +22,14 @@ bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
   echo "== tools/vae_bench.py"; python tools/vae_bench.py 2>&1 | grep -v amdgpu | tail -4
   echo "== bench.py --eager"; python bench.py --no-cpu-baseline --no-roofline --eager 2>/dev/null | cut -c1-200
   echo "== bench.py (hipGraph replay, default)"; python bench.py --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-200
+  echo "== tools/probes/gemm_mainloop.sh"; bash tools/probes/gemm_mainloop.sh 2>&1
+  echo "== tools/probes/guard_step.py b"; python tools/probes/guard_step.py b 2>&1 | grep guard
+  echo "== tools/probes/parity_budget.py"; python tools/probes/parity_budget.py 2>&1 | grep "HIP\|reference"
 ) > gpurun_out/${R}_probe_outputs.txt 2>&1
+# MMDiT-L training step (config 4's model, batch 16) and the 28-step mxfp8 sampler (config 5): kernel tables
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_l -o run -- python3 tools/probes/l_config.py 16 > gpurun_out/${R}_l_prof.log 2>&1
+python tools/rocpd_stats.py $(find gpurun_out/prof_${R}_l -name "*.db" | head -1) 8 40 > gpurun_out/${R}_l_kernel_stats.txt; rm -rf gpurun_out/prof_${R}_l
+rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_s -o run -- python3 tools/sampler_bench.py --batch 16 > gpurun_out/${R}_sampler_prof.log 2>&1
+python tools/rocpd_stats.py $(find gpurun_out/prof_${R}_s -name "*.db" | head -1) > gpurun_out/${R}_sampler_kernel_stats.txt; rm -rf gpurun_out/prof_${R}_s
+python -m pytest tests -m gpu -q -s 2>&1 | grep "^\[\|passed\|failed" > gpurun_out/${R}_parity_numbers.txt
