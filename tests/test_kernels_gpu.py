@@ -922,3 +922,25 @@ def test_trainer_hip_loss_equals_torch_loss_step():
     assert np.allclose(res[0][0], res[1][0], rtol=1e-5), (res[0][0], res[1][0])
     for a, b in zip(res[0][1], res[1][1]):
         assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-6
+
+
+def test_weight_gradient_flush_groups_by_k_alignment():
+    """engine._wgrad_flush: a block's weight gradients dW = dY^T X in grouped launches.  The text stream's 154 * batch rows are not a
+    multiple of the 64-deep K tile of the LDS-DMA kernels for most batch sizes; a grouped launch runs ONE kernel, so such problems
+    get a launch of their own (register-staged kernel) instead of dragging the aligned image problems there with them.  All outputs
+    must equal the fp32 products of the bf16 operands."""
+    from sd3_amd import engine
+    got = {}
+    shapes = [(16384, 256, 128), (2464, 256, 128), (2464, 384, 256), (4096, 128, 384), (2100, 128, 128), (64, 256, 128)]
+    ops_ = []
+    for i, (rows, n, k) in enumerate(shapes):
+        dY, X = rnd(rows, n, seed=20 + i).to(torch.bfloat16), rnd(rows, k, seed=40 + i).to(torch.bfloat16)
+        ops_.append((dY, X))
+    pending = [((lambda o, i=i: got.__setitem__(i, o)), engine._wg(dY, X)) for i, (dY, X) in enumerate(ops_)]
+    arena = engine._wgrad_flush(engine.FAST, pending)
+    torch.cuda.synchronize()
+    assert arena is not None and arena.numel() % engine.ARENA_QUANTUM == 0
+    for i, (dY, X) in enumerate(ops_):
+        ref = dY.float().t() @ X.float()
+        assert got[i].shape == ref.shape and got[i].data_ptr() >= arena.data_ptr()
+        assert rel(got[i], ref) < 2e-5, (shapes[i], rel(got[i], ref))
