@@ -5,9 +5,12 @@ models/diff_model.py:467-477 (decode((z - shift_factor) / scaling_factor).sample
 
 TEST INFRASTRUCTURE ONLY (tests/, __graft_entry__.smoke(), bench.py's cpu_baseline leg may import it).
 
-**PARITY UNPINNED.**  diffusers is not installed in the build container, there is no network and the reference holds no
-test or golden vector for the VAE, so this restatement cannot be checked against the real implementation here.  It
-restates the published algorithm of `AutoencoderKL` / `Encoder` / `Decoder` / `ResnetBlock2D` / `Downsample2D` /
+**Parity against diffusers itself: UNPINNED** -- diffusers is not installed in the build container, there is no network and the
+reference holds no test or golden vector for the VAE.  **Architecture pinned against an independent implementation**: HF transformers
+(installed) carries its own implementation of the latent-diffusion encoder / decoder that `AutoencoderKL` was converted from
+(modeling_janus.py); with the FLUX geometry and this file's diffusers-keyed seeded weights loaded through a pure key renaming it agrees
+with this restatement to 1e-6 (oracle/vae_crosscheck.py, tests/test_vae.py).  The file restates the published algorithm of
+`AutoencoderKL` / `Encoder` / `Decoder` / `ResnetBlock2D` / `Downsample2D` /
 `Upsample2D` / `Attention` (diffusers 0.30.3, models/autoencoders/vae.py, models/resnet.py, models/downsampling.py,
 models/upsampling.py, models/attention_processor.py) for the FLUX VAE config:
   in/out_channels 3, latent_channels 16, block_out_channels (128, 256, 512, 512), layers_per_block 2, norm_num_groups 32,
