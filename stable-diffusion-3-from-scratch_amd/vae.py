@@ -23,6 +23,8 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
+import os as _os
+_H_BF16 = _os.environ.get("MMDIT_VAE_H_BF16", "1") != "0"     # A/B switch: conv1 outputs of the ResNet blocks in bf16
 _CIN_PAD = 64     # conv_in operand channels (the implicit-GEMM K = 9 * C must be a multiple of the 64-wide K tile)
 
 
@@ -188,7 +190,7 @@ class AutoencoderKL(nn.Module):
         out = self._padded(a.B, a.H, a.W, a.x.shape[1], a.x.device) if padded else None
         return ops.vae_groupnorm(a.x, norm.weight, norm.bias, a.B, a.H, a.W, self.config.norm_num_groups, self.eps, silu, out)
 
-    def _conv3(self, xin, a, conv, mode=0, residual=None):
+    def _conv3(self, xin, a, conv, mode=0, residual=None, out_dtype=F32):
         """3x3 convolution of the activation `a` whose conv operand is `xin`:
         a zero-bordered bf16 (B, H+2, W+2, Cin) tensor -> implicit GEMM (Cin % 64 == 0: every layer, conv_in through _conv_in);
         bf16 rows (B*H*W, Cin_p) -> materialised im2col + GEMM (kept for operands that are not channel-padded).
@@ -196,7 +198,7 @@ class AutoencoderKL(nn.Module):
         w, b = conv.packed()
         if xin.dim() == 4:
             Hin, Win = xin.shape[1] - 2, xin.shape[2] - 2           # (already upsampled for mode 2)
-            y = ops.gemm(xin, w, bias=b, residual=residual, out_dtype=F32, conv=(2 if mode == 1 else 1, Hin, Win, xin.shape[3]))
+            y = ops.gemm(xin, w, bias=b, residual=residual, out_dtype=out_dtype, conv=(2 if mode == 1 else 1, Hin, Win, xin.shape[3]))
             return _Act(y, a.B, Hin // 2 if mode == 1 else Hin, Win // 2 if mode == 1 else Win)
         cols, Ho, Wo = ops.vae_im2col3x3(xin.view(a.B, a.H, a.W, xin.shape[1]), mode)
         y = ops.gemm(cols, w, bias=b, residual=residual, out_dtype=F32)
@@ -216,7 +218,9 @@ class AutoencoderKL(nn.Module):
         return ops.vae_pad_cast(a.x, a.B, a.H, a.W, self._padded(a.B, a.H * s, a.W * s, a.x.shape[1], a.x.device), upsample)
 
     def _resnet(self, a, r):
-        h = self._conv3(self._gn(a, r.norm1, True, padded=True), a, r.conv1)
+        # conv1's output only feeds norm2: bf16 (the reference runs the whole VAE in bf16, VAE_T5_CLIP.py:155-171) -- the bf16 epilogue of
+        # the GEMM stores half the bytes and both GroupNorm passes read half; the residual stream between the blocks stays fp32
+        h = self._conv3(self._gn(a, r.norm1, True, padded=True), a, r.conv1, out_dtype=BF16 if _H_BF16 else F32)
         sc = a.x
         if hasattr(r, "conv_shortcut"):
             w, b = r.conv_shortcut.packed()
