@@ -94,6 +94,7 @@ _SIGNATURES = {
     "mmdit_qk_norm_rope_fwd": ([_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "mmdit_qk_norm_rope_bwd": ([_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp], _i),
     "mmdit_attn_fwd": ([_vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp], _i),
+    "mmdit_attn_bwd_qk": ([_vp] * 9 + [_i, _i, _i, _i, _f] + [_vp] * 11 + [_vp], _i),
     "mmdit_attn_bwd": ([_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp], _i),
     "mmdit_swiglu_fwd": ([_vp, _vp, _i, _i, _i, _vp], _i),
     "mmdit_swiglu_bwd": ([_vp, _vp, _vp, _i, _i, _i, _vp, _vp], _i),

@@ -113,6 +113,135 @@ __device__ __forceinline__ void map_block(int ntile, int BH, int& tile, int& bh)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of the per-head QK RMSNorm (+ axial RoPE on image tokens) fused into the epilogues of the attention backward kernels
+// (mmdit_attn_bwd_qk): the dQ / dK rows a wave holds in its accumulators go straight to the gradient of the raw QKV projection, the
+// stand-alone mmdit_qk_norm_rope_bwd pass (and the dQ / dK / dV round trip through HBM) disappears.  Same arithmetic as
+// qk_norm_rope_bwd_body in rowops.hip (reference: Attention.py:130-135, 178-194 under autograd), on the accumulator layout:
+// lane = row (l & 31), its 32 features f(db, g, e) = 32 db + 8 g + 4 (l >> 5) + e; the other 32 live in lane l ^ 32.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float partner32(float x, int lane);   // (defined with the forward kernels below)
+constexpr float QK_RMS_EPS = 1.1920929e-07f;     // nn.RMSNorm(eps=None) on fp32 input: finfo(float32).eps (= RMS_EPS of rowops.hip)
+
+struct QkFuse {
+  const bf16_t* qkv_x; const bf16_t* qkv_c;      // saved raw projections, row-major (rows, 3 * H * 64): [q | k | v] per row
+  const float* wq_x; const float* wk_x; const float* wq_c; const float* wk_c;   // norm weights (64)
+  const float* rcos; const float* rsin;          // RoPE factors (n_img, 64)
+  bf16_t* dqkv_x; bf16_t* dqkv_c;                // outputs, same geometry as qkv_x / qkv_c
+  float* dw_part;                                // (workgroups, 256) partial weight gradients: [wq_x | wk_x | wq_c | wk_c]
+};
+
+// The epilogue goes through the LDS: a wave parks its 32 x 64 fp32 accumulator tile row-major (stride QK_ROW_F floats: b128 writes of
+// the accumulator layout and b128 reads of the row layout are both conflict-free), then 8 lanes own one row (8 features = one 16-byte
+// piece of the bf16 row each), 8 rows per pass, 4 passes.  Every global access is then a full 128-byte row segment per 8 lanes
+// (the first version worked on the accumulator layout directly: 8-byte pieces of 32 different rows per instruction, 56 such
+// instructions per wave -- the texture addresser made the fused form SLOWER than the two-pass one, 401 vs 336 us at MMDIT-B).
+constexpr int QK_ROW_F = 68;
+constexpr int QK_WAVE_BYTES = 32 * QK_ROW_F * 4;          // 8704 B per wave
+template <int NW> constexpr int qk_lds_bytes() { return NW * QK_WAVE_BYTES + 128 * 4; }     // tiles + [image | text][64] weight-gradient sums
+
+__device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[2], float* tile, int lane) {
+  float* p = tile + (lane & 31) * QK_ROW_F + 4 * (lane >> 5);
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+      *LDS_PTR(f32x4, p + db * 32 + 8 * g) = (f32x4){acc[db][g * 4], acc[db][g * 4 + 1], acc[db][g * 4 + 2], acc[db][g * 4 + 3]};
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void lds_row8(const float* tile, int r, int c, float (&v)[8]) {
+  const f32x4 a = *LDS_PTR(const f32x4, tile + r * QK_ROW_F + 8 * c), b = *LDS_PTR(const f32x4, tile + r * QK_ROW_F + 8 * c + 4);
+#pragma unroll
+  for (int e = 0; e < 4; e++) { v[e] = a[e]; v[4 + e] = b[e]; }
+}
+// sum over the 8 lanes of a row (lane bits 2:0) on the DPP path (quad_perm 1032, quad_perm 2301, row_half_mirror): three dependent
+// VALU moves instead of three LDS round trips (ds_bpermute) -- the epilogue is a latency chain, not a throughput problem
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float x) {
+  x += dpp_f<0xB1>(x);
+  x += dpp_f<0x4E>(x);
+  return x + dpp_f<0x141>(x);
+}
+
+// tile: the wave's parked accumulators = gradient w.r.t. the normalised (and rotated) rows, to be multiplied by `mul`.  x0 / o0: raw
+// features / output slot of the wave's row 0 (this head, this part), `pitch` elements between rows; nvalid rows of the 32 exist.
+// cs0 / sn0: RoPE factors of row 0's token (image rows; rows are consecutive tokens), nullptr for text rows.  Adds this wave's
+// norm-weight gradient into sdw[64] (LDS atomics from 8 lanes).
+__device__ __forceinline__ void qk_bwd_tile(const float* tile, float mul, int lane, int nvalid, const bf16_t* x0, bf16_t* o0, int64_t pitch,
+                                            const float* w, const float* cs0, const float* sn0, float* sdw) {
+  const int c = lane & 7, rsub = lane >> 3;
+  float w8[8], dw[8];
+  ld8(w + 8 * c, w8);
+#pragma unroll
+  for (int e = 0; e < 8; e++) dw[e] = 0.f;
+  // the four passes' raw rows are requested up front (16 registers as packed bf16): their latency overlaps the first pass
+  u32x4 xr[4];
+#pragma unroll
+  for (int it = 0; it < 4; it++) xr[it] = __builtin_nontemporal_load((const u32x4*)(x0 + min(it * 8 + rsub, nvalid - 1) * pitch + 8 * c));   // (last use of the saved projection)
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int r = it * 8 + rsub;
+    const bool valid = r < nvalid;
+    const int rc = valid ? r : nvalid - 1;
+    float dz[8], x[8];
+#pragma unroll
+    for (int e = 0; e < 4; e++) { x[2 * e] = __builtin_bit_cast(float, xr[it][e] << 16); x[2 * e + 1] = __builtin_bit_cast(float, xr[it][e] & 0xffff0000u); }
+    lds_row8(tile, r, c, dz);
+#pragma unroll
+    for (int e = 0; e < 8; e++) dz[e] *= mul;
+    if (cs0) {   // transpose of the rotation: pairs (2p, 2p+1)
+      float c8[8], s8[8];
+      ld8(cs0 + rc * 64 + 8 * c, c8);
+      ld8(sn0 + rc * 64 + 8 * c, s8);
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        const float da = dz[2 * p], dbv = dz[2 * p + 1];
+        dz[2 * p] = da * c8[2 * p] + dbv * s8[2 * p + 1];
+        dz[2 * p + 1] = dbv * c8[2 * p + 1] - da * s8[2 * p];
+      }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) ss += x[e] * x[e];
+    const float rinv = rsqrtf(sum8(ss) * (1.f / 64.f) + QK_RMS_EPS);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      x[e] *= rinv;                                      // xhat
+      dw[e] += valid ? dz[e] * x[e] : 0.f;               // d(norm weight)
+      dz[e] *= w8[e];                                    // d(xhat)
+      dot += dz[e] * x[e];
+    }
+    dot = sum8(dot) * (1.f / 64.f);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) o[e] = rinv * (dz[e] - x[e] * dot);
+    if (valid) st8(o0 + r * pitch + 8 * c, o);
+  }
+  // the wave's 32 rows: lanes with equal c hold partial sums for features 8c .. 8c+7 (lane bits 5:3 = row lane)
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+    float v = dw[e];
+    v += __shfl_xor(v, 8, 64);
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (lane < 8) atomicAdd(&sdw[8 * c + e], v);
+  }
+}
+// dV rows: no arithmetic, the LDS round trip only makes the stores whole 128-byte rows
+__device__ __forceinline__ void rows_from_tile(const float* tile, int lane, int nvalid, bf16_t* o0, int64_t pitch) {
+  const int c = lane & 7, rsub = lane >> 3;
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int r = it * 8 + rsub;
+    float v[8];
+    lds_row8(tile, r, c, v);
+    if (r < nvalid) st8(o0 + r * pitch + 8 * c, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int NW, bool ORACLE>
@@ -940,16 +1069,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
 // ------------------------------------------------------------------------------------------------
 // backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
-template <int NW, typename TG>
-__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+template <int NW, typename TG, bool FUSE = false>
+__global__ __launch_bounds__(NW * 64, FUSE ? 4 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                const bf16_t* __restrict__ Ox, const bf16_t* __restrict__ Oc,
                                                                const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
-                                                               int BH, int H, int S, int n_img, float scale, TG* __restrict__ dQ) {
+                                                               int BH, int H, int S, int n_img, float scale, TG* __restrict__ dQ, QkFuse F = QkFuse()) {
   // delta[q] = sum_d dO[q,d] O[q,d] is formed here from the query's own dO / O rows (each lane holds half of the 64 features of its
   // query) and written out for the dK/dV kernel that follows on the same stream -- no separate preparation pass.
   constexpr int NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128];
+  // (fused epilogue: dynamic LDS of qk_lds_bytes<NW>() > 64 KB, whose head is the K / V tile pair of the main loop)
+  __shared__ __attribute__((aligned(16))) char smem_static[FUSE ? 16 : 2 * KT * 128];
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* smem = FUSE ? smem_dyn : smem_static;
   char* ktile = smem;
   char* vtile = smem + KT * 128;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1032,7 +1164,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
       }
     }
   }
-  if (q < S) {
+  if constexpr (FUSE) {
+    // dQ rows -> gradient of the raw q projection (RMSNorm + RoPE backward, qk_bwd_tile), norm-weight gradient partials of this workgroup
+    __syncthreads();                       // every wave has left the last K/V tile: the LDS is free
+    float* sdw = (float*)(smem + NW * QK_WAVE_BYTES);             // [image | text][64]
+    if (tid < 128) sdw[tid] = 0.f;
+    __syncthreads();
+    if (active) {
+      const int q0 = qtile * 32 * NW + wave * 32;
+      const bool img = q0 < n_img;                                   // wave-uniform: n_img % 32 == 0 (checked by the launcher)
+      const int n_txt = S - n_img, tok0 = img ? q0 : q0 - n_img, nvalid = min(32, (img ? n_img : S) - q0);
+      const int64_t pitch = 3 * (int64_t)(H * HD), off = (img ? b * n_img + tok0 : b * n_txt + tok0) * pitch + h * HD;
+      float* tile = (float*)(smem + wave * QK_WAVE_BYTES);
+      acc_to_lds(acc, tile, lane);
+      qk_bwd_tile(tile, scale, lane, nvalid, (img ? F.qkv_x : F.qkv_c) + off, (img ? F.dqkv_x : F.dqkv_c) + off, pitch, img ? F.wq_x : F.wq_c,
+                  img ? F.rcos + (int64_t)tok0 * 64 : nullptr, img ? F.rsin + (int64_t)tok0 * 64 : nullptr, sdw + (img ? 0 : 64));
+    }
+    __syncthreads();
+    if (tid < 128) F.dw_part[(int64_t)blockIdx.x * 256 + (tid >> 6) * 128 + (tid & 63)] = sdw[tid];    // columns [wq_x | . | wq_c | .]
+  } else if (q < S) {
     TG* dst = dQ + ((int64_t)bh * S + q) * HD;
 #pragma unroll
     for (int db = 0; db < 2; db++)
@@ -1049,13 +1199,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const bf16_t* __re
 //   S[q][key] = Q K^T, dP[q][key] = dO V^T  (lane owns key l&31, rows = queries)
 //   dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[hd][key] += Q^T[hd][q] dS[q][key]
 // ------------------------------------------------------------------------------------------------
-template <int NW, typename TG>
+template <int NW, typename TG, bool FUSE = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                            const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV) {
+                                                           int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV, QkFuse F = QkFuse()) {
   constexpr int NT = NW * 64;
-  __shared__ __attribute__((aligned(16))) char smem[2 * KT * 128 + 2 * KT * 4];
+  __shared__ __attribute__((aligned(16))) char smem_static[FUSE ? 16 : 2 * KT * 128 + 2 * KT * 4];
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];      // fused epilogue: qk_lds_bytes<NW>()
+  char* smem = FUSE ? smem_dyn : smem_static;
   char* qtile = smem;
   char* dotile = smem + KT * 128;
   float* lse_s = (float*)(smem + 2 * KT * 128);
@@ -1141,7 +1293,29 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
       }
     }
   }
-  if (key < S) {
+  if constexpr (FUSE) {
+    // dK rows -> gradient of the raw k projection (qk_bwd_tile), dV rows into the v part of the same output rows
+    __syncthreads();                       // every wave has left the last Q / dO tile
+    float* sdw = (float*)(smem + NW * QK_WAVE_BYTES);             // [image | text][64]
+    if (tid < 128) sdw[tid] = 0.f;
+    __syncthreads();
+    if (active) {
+      const int k0 = ktile * 32 * NW + wave * 32;
+      const bool img = k0 < n_img;                                   // wave-uniform: n_img % 32 == 0
+      const int tok0 = img ? k0 : k0 - n_img, nvalid = min(32, (img ? n_img : S) - k0);
+      const int64_t pitch = 3 * (int64_t)D, off = (img ? b * n_img + tok0 : b * n_txt + tok0) * pitch + D + h * HD;
+      bf16_t* ob = (img ? F.dqkv_x : F.dqkv_c) + off;
+      float* tile = (float*)(smem + wave * QK_WAVE_BYTES);
+      acc_to_lds(dk, tile, lane);
+      qk_bwd_tile(tile, scale, lane, nvalid, (img ? F.qkv_x : F.qkv_c) + off, ob, pitch, img ? F.wk_x : F.wk_c,
+                  img ? F.rcos + (int64_t)tok0 * 64 : nullptr, img ? F.rsin + (int64_t)tok0 * 64 : nullptr, sdw + (img ? 0 : 64));
+      __builtin_amdgcn_wave_barrier();
+      acc_to_lds(dv, tile, lane);
+      rows_from_tile(tile, lane, nvalid, ob + D, pitch);
+    }
+    __syncthreads();
+    if (tid < 128) F.dw_part[(int64_t)blockIdx.x * 256 + (tid >> 6) * 128 + 64 + (tid & 63)] = sdw[tid];   // columns [. | wk_x | . | wk_c]
+  } else if (key < S) {
     TG* pk = dK + ((int64_t)bh * S + key) * HD;
     TG* pv = dV + ((int64_t)bh * S + key) * HD;
 #pragma unroll
@@ -1237,6 +1411,30 @@ extern "C" int mmdit_probe_attn_fwd_dbg(const void* Q, const void* K, const void
 }
 
 #endif
+
+extern "C" int mmdit_attn_bwd_qk(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc, const void* dOx, const void* dOc,
+                                 const float* lse, float* delta, int batch, int heads, int S, int n_img, float scale,
+                                 const void* qkv_x, const void* qkv_c, const float* wq_x, const float* wk_x, const float* wq_c, const float* wk_c,
+                                 const float* rope_cos, const float* rope_sin, void* dqkv_x, void* dqkv_c, float* dw_part, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(Q && K && V && Ox && dOx && lse && delta && batch > 0 && heads > 0 && S > 0 && n_img > 0 && n_img <= S);
+  MMDIT_CHECK_ARG(Oc || n_img == S);
+  MMDIT_CHECK_ARG(qkv_x && wq_x && wk_x && rope_cos && rope_sin && dqkv_x && dw_part && (n_img == S || (qkv_c && wq_c && wk_c && dqkv_c)));
+  if (n_img % 32) return MMDIT_ERR_SHAPE;       // a wave's 32 rows must belong to one stream
+  const QkFuse F{(const bf16_t*)qkv_x, (const bf16_t*)qkv_c, wq_x, wk_x, wq_c, wk_c, rope_cos, rope_sin, (bf16_t*)dqkv_x, (bf16_t*)dqkv_c, dw_part};
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(((S + 255) / 256) * batch * heads);
+  constexpr int lds = qk_lds_bytes<8>();        // 70144 B: above the 64 KB default cap of dynamic LDS
+  static const hipError_t raised = [] {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  }();
+  if (raised != hipSuccess) return (int)raised;     // (positive: a HIP error code, as from mmdit_launch_status)
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<8, bf16_t, true>), grid, dim3(512), lds, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Ox,
+                     (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)nullptr, F);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, bf16_t, true>), grid, dim3(512), lds, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx,
+                     (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)nullptr, (bf16_t*)nullptr, F);
+  return mmdit_launch_status();
+}
 
 extern "C" int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc, const void* dOx, const void* dOc,
                               const float* lse, float* delta, int batch, int heads, int S, int n_img, float scale,

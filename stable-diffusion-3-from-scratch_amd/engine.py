@@ -423,7 +423,21 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
 _LN_PAIR = _os.environ.get("MMDIT_LN_PAIR", "1") != "0"      # image + text rows of the adaLN / QK-norm+RoPE / MLP-activation-backward kernels in one launch (A/B switch)
 _MX_FUSE = _os.environ.get("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
 _BATCH_WMOD = _os.environ.get("MMDIT_BATCH_WMOD", "1") != "0"   # single-rank backward: the modulation-matrix weight gradients of all blocks in one grouped launch (A/B switch)
+_QK_FUSE = _os.environ.get("MMDIT_ATTN_QK_FUSE", "1") != "0"     # QK-norm + RoPE backward inside the attention backward kernels (A/B switch)
 _FUSE_GATE = _os.environ.get("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
+
+
+def _qk_bwd_two_pass(m, w, sv, g, dOx, dOc, dims, rope, dev):
+    """Attention backward, then the QK-norm + RoPE backward as a pass of its own."""
+    B, N, Mt, H, d = dims
+    S = N + Mt
+    dQ, dK, dV = ops.attn_bwd(sv.Q, sv.K, sv.V, sv.Ox, sv.Oc, dOx, dOc, sv.lse, N, 64 ** -0.5, m.T)
+    if _LN_PAIR and dev.type == "cuda":
+        return ops.qk_norm_rope_bwd_pair(dQ, dK, dV, (sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], N, 0, g.wq_x, g.wk_x),
+                                         (sv.qkv_c, w.wq_c, w.wk_c, None, None, Mt, N, g.wq_c, g.wk_c), B, H, S, m.T)
+    dqkv_x = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, g.wq_x, g.wk_x, m.T)
+    dqkv_c = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, g.wq_c, g.wk_c, m.T)
+    return dqkv_x, dqkv_c
 
 
 def block_bwd_begin(m, w, sv, dims, dev, defer_cond=False):
@@ -531,13 +545,13 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None,
     dOx, dOc = dO[0], (dO[1] if both else None)   # the last block's text attention output is discarded (Attention.py:425)
 
     # ---- attention core + QK norm / RoPE
-    dQ, dK, dV = ops.attn_bwd(sv.Q, sv.K, sv.V, sv.Ox, sv.Oc, dOx, dOc, sv.lse, N, 64 ** -0.5, m.T)
-    if _LN_PAIR and dev.type == "cuda":
-        dqkv_x, dqkv_c = ops.qk_norm_rope_bwd_pair(dQ, dK, dV, (sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], N, 0, g.wq_x, g.wk_x),
-                                                   (sv.qkv_c, w.wq_c, w.wk_c, None, None, Mt, N, g.wq_c, g.wk_c), B, H, S, m.T)
+    # the QK-norm + RoPE backward runs in the epilogues of the attention backward kernels (ops.attn_bwd_qk) when the shapes allow it:
+    # no dQ / dK / dV round trip, one pass less (MMDIT_ATTN_QK_FUSE=0: the two-pass form)
+    if _QK_FUSE and m.fast and dev.type == "cuda" and ops.attn_bwd_qk_ok(sv.Q, N, sv.qkv_x) and g.wq_x.data_ptr() + 768 == g.wk_c.data_ptr():
+        dqkv_x, dqkv_c = ops.attn_bwd_qk(sv.Q, sv.K, sv.V, sv.Ox, sv.Oc, dOx, dOc, sv.lse, N, 64 ** -0.5, sv.qkv_x, sv.qkv_c, w.wq_x, w.wk_x, w.wq_c, w.wk_c,
+                                         rope[0], rope[1], torch.as_strided(g.wq_x, (256,), (1,)))
     else:
-        dqkv_x = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, g.wq_x, g.wk_x, m.T)
-        dqkv_c = ops.qk_norm_rope_bwd(dQ, dK, dV, sv.qkv_c, w.wq_c, w.wk_c, None, None, B, Mt, H, S, N, g.wq_c, g.wk_c, m.T)
+        dqkv_x, dqkv_c = _qk_bwd_two_pass(m, w, sv, g, dOx, dOc, dims, rope, dev)
     dln1 = _group(m, [dict(A=dqkv_x, B=w.Wqkv_x, b_kmajor=True, out_dtype=m.T), dict(A=dqkv_c, B=w.Wqkv_c, b_kmajor=True, out_dtype=m.T)])
     defer(g, "Wqkv_x", dqkv_x, sv.ln1x)
     defer(g, "Wqkv_c", dqkv_c, sv.ln1c)

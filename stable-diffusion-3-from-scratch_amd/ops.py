@@ -540,6 +540,28 @@ def attn_bwd(Q, K, V, Ox, Oc, dOx, dOc, lse, n_img, scale, out_dtype):
     return dQ, dK, dV
 
 
+def attn_bwd_qk(Q, K, V, Ox, Oc, dOx, dOc, lse, n_img, scale, qkv_x, qkv_c, wq_x, wk_x, wq_c, wk_c, rope_cos, rope_sin, dw4):
+    """Attention backward with the QK-norm + RoPE backward in its epilogues (mmdit_attn_bwd_qk): returns (dqkv_x, dqkv_c), the gradients
+    of the raw QKV projections, and ADDS the norm-weight gradients into dw4 = the contiguous fp32 [wq_x | wk_x | wq_c | wk_c] (256).
+    bf16 only; needs n_img % 32 == 0 (attn_bwd_qk_ok)."""
+    batch, heads, S, hd = Q.shape
+    delta = torch.empty((batch, heads, S), dtype=torch.float32, device=Q.device)
+    dqkv_x = torch.empty(qkv_x.shape, dtype=torch.bfloat16, device=Q.device)
+    dqkv_c = torch.empty(qkv_c.shape, dtype=torch.bfloat16, device=Q.device)
+    nwg = (S + 255) // 256 * batch * heads
+    part = torch.empty((nwg, 256), dtype=torch.float32, device=Q.device)
+    check(_lib.lib().mmdit_attn_bwd_qk(_p(Q), _p(K), _p(V), _p(Ox), _p(Oc), _p(_c(dOx)), _p(_c(dOc)), _p(lse), _p(delta), batch, heads, S, n_img, float(scale),
+                                       _p(_c(qkv_x)), _p(_c(qkv_c)), _p(wq_x), _p(wk_x), _p(wq_c), _p(wk_c), _p(rope_cos), _p(rope_sin),
+                                       _p(dqkv_x), _p(dqkv_c), _p(part), _s()), "mmdit_attn_bwd_qk")
+    colsum(part, dw4)
+    return dqkv_x, dqkv_c
+
+
+def attn_bwd_qk_ok(Q, n_img, qkv_x):
+    """The fused form's preconditions: bf16 operands, head_dim 64, image tokens a multiple of the 32-row wave blocks."""
+    return Q.is_cuda and Q.shape[-1] == 64 and n_img % 32 == 0 and n_img < Q.shape[2] and qkv_x.dtype == torch.bfloat16
+
+
 def mlp_act_fwd(gu, hidden, gelu=False):
     rows = gu.shape[0]
     h = torch.empty((rows, hidden), dtype=gu.dtype, device=gu.device)

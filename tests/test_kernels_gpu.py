@@ -448,6 +448,62 @@ def test_attention_fwd_bwd_at_mmdit_l_sequence_length(ops):
     print(f"[attention S=1178] fwd oracle-rounding mode {r1:.2e}, flash {r0:.2e}; bwd (dQ, dK, dV) {res[0]} / last block {res[1]}")
 
 
+@pytest.mark.parametrize("Bt,H,h2,w2,Mt,last", [(2, 3, 8, 8, 30, False), (1, 2, 16, 16, 154, False), (2, 2, 16, 16, 154, True), (1, 2, 32, 32, 154, False)])
+def test_attention_bwd_with_fused_qk_norm_rope_backward(ops, Bt, H, h2, w2, Mt, last):
+    """mmdit_attn_bwd_qk (attention backward whose epilogues run the RoPE + QK-RMSNorm backward on the fp32 accumulators and write
+    the gradient of the raw QKV GEMM outputs) against (a) the two-pass composition mmdit_attn_bwd + mmdit_qk_norm_rope_bwd_pair and
+    (b) torch autograd through norm -> RoPE -> exact softmax attention on the same bf16 operands."""
+    N = h2 * w2
+    S, d = N + Mt, H * 64
+    assert ops.attn_bwd_qk_ok(torch.empty((Bt, H, S, 64), dtype=torch.bfloat16, device="cuda"), N, torch.empty((Bt * N, 3 * d), dtype=torch.bfloat16, device="cuda"))
+    cos, sin = _rope_tables(h2, w2)
+    wqx, wkx, wqc, wkc = (1 + 0.1 * rnd(64, seed=i) for i in (1, 2, 3, 4))
+    qkv_x, qkv_c = rnd(Bt * N, 3 * d, seed=5).to(torch.bfloat16), rnd(Bt * Mt, 3 * d, seed=6).to(torch.bfloat16)
+    Q = torch.zeros((Bt, H, S, 64), dtype=torch.bfloat16, device="cuda")
+    K, V = torch.zeros_like(Q), torch.zeros_like(Q)
+    ops.qk_norm_rope_fwd_pair((qkv_x, wqx, wkx, cos, sin, N, 0), (qkv_c, wqc, wkc, None, None, Mt, N), Bt, H, S, Q, K, V)
+    Ox, Oc, lse = ops.attn_fwd(Q, K, V, N, 0.125, 0)
+    dOx = rnd(Bt, N, d, seed=7).to(torch.bfloat16)
+    dOc = None if last else rnd(Bt, Mt, d, seed=8).to(torch.bfloat16)
+    # (a) two passes
+    dQ, dK, dV = ops.attn_bwd(Q, K, V, Ox, Oc, dOx, dOc, lse, N, 0.125, torch.bfloat16)
+    dw2 = [torch.zeros(64, device="cuda") for _ in range(4)]
+    dx2, dc2 = ops.qk_norm_rope_bwd_pair(dQ, dK, dV, (qkv_x, wqx, wkx, cos, sin, N, 0, dw2[0], dw2[1]), (qkv_c, wqc, wkc, None, None, Mt, N, dw2[2], dw2[3]), Bt, H, S, torch.bfloat16)
+    # fused
+    dw4 = torch.zeros(256, device="cuda")
+    dx1, dc1 = ops.attn_bwd_qk(Q, K, V, Ox, Oc, dOx, dOc, lse, N, 0.125, qkv_x, qkv_c, wqx, wkx, wqc, wkc, cos, sin, dw4)
+    assert dx1.shape == dx2.shape and dc1.shape == dc2.shape and dx1.dtype == torch.bfloat16
+
+    # (b) autograd
+    def chain(qkv, L, rope, wq_, wk_):
+        q, k, v = qkv.reshape(Bt, L, 3, H, 64).permute(2, 0, 3, 1, 4)
+        q = F.rms_norm(q, (64,), wq_, torch.finfo(torch.float32).eps)
+        k = F.rms_norm(k, (64,), wk_, torch.finfo(torch.float32).eps)
+        if rope:
+            q, k = q * cos + _rot_half(q) * sin, k * cos + _rot_half(k) * sin
+        return q, k, v
+    xr, cr = qkv_x.float().requires_grad_(True), qkv_c.float().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in (wqx, wkx, wqc, wkc)]
+    qx, kx, vx = chain(xr, N, True, wr[0], wr[1])
+    qc, kc, vc = chain(cr, Mt, False, wr[2], wr[3])
+    bf = lambda t: t + (t.to(torch.bfloat16).float() - t).detach()          # the forward rounds Q, K, V to bf16 (straight-through)
+    Qr, Kr, Vr = bf(torch.cat([qx, qc], 2)), bf(torch.cat([kx, kc], 2)), bf(torch.cat([vx, vc], 2))
+    out = (((Qr @ Kr.mT) * 0.125).softmax(-1) @ Vr).permute(0, 2, 1, 3).reshape(Bt, S, d)
+    out.backward(torch.cat([dOx.float(), torch.zeros(Bt, Mt, d, device="cuda") if last else dOc.float()], 1))
+    ref = [xr.grad, cr.grad] + [w.grad for w in wr]
+    fused = [dx1, dc1] + list(dw4.reshape(4, 64))
+    two = [dx2, dc2] + dw2
+    e1 = [rel(a, r) for a, r in zip(fused, ref)]
+    e2 = [rel(a, r) for a, r in zip(two, ref)]
+    e12 = [rel(a, b) for a, b in zip(fused, two)]
+    print(f"[attn bwd + qk fused] S={S} vs autograd: fused {['%.2e' % e for e in e1]}, two-pass {['%.2e' % e for e in e2]}; fused vs two-pass {['%.2e' % e for e in e12]}")
+    # bf16 P / dS operands: ~1e-2 relative, as for mmdit_attn_bwd; the fused form skips one bf16 rounding (dQ, dK), so it may not be worse
+    assert max(e1) < 1.5e-2, e1
+    assert max(e12) < 1.2e-2, e12
+    for a, b in zip(e1, e2):
+        assert a < b * 1.1 + 1e-4, (e1, e2)
+
+
 def test_attention_oracle_mode_matches_cpu_oracle(ops):
     """mode 1 must reproduce the reference's CPU attention branch far below the 1e-3 parity bar."""
     from oracle.mmdit_oracle import attention_core

@@ -48,3 +48,22 @@ o.backward(do)
 of = torch.cat([Ox[:nb].view(nb, N, H, hd), Oc[:nb].view(nb, M, H, hd)], 1).permute(0, 2, 1, 3).float()
 rel = lambda a, b: float((a - b).norm() / b.norm())
 print(f"rel err: O {rel(of, o.detach()):.2e}  dQ {rel(dQ[:nb].float(), q.grad):.2e}  dK {rel(dK[:nb].float(), k.grad):.2e}  dV {rel(dV[:nb].float(), v.grad):.2e}")
+
+# attention backward + QK-RMSNorm / RoPE backward: two passes (mmdit_attn_bwd + mmdit_qk_norm_rope_bwd_pair) vs the fused epilogues
+d = H * hd
+qkv_x, qkv_c = rnd(B * N, 3 * d), rnd(B * M, 3 * d)
+wts = [1 + 0.1 * torch.randn(64, generator=g, device="cuda") for _ in range(4)]
+ang = torch.rand(N, 64, generator=g, device="cuda") * 6.28
+cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+dw = [torch.zeros(64, device="cuda") for _ in range(4)]
+dw4 = torch.zeros(256, device="cuda")
+
+
+def two_pass():
+    a, b_, c = ops.attn_bwd(Q, K, V, Ox, Oc, dOx, dOc, lse, N, scale, torch.bfloat16)
+    return ops.qk_norm_rope_bwd_pair(a, b_, c, (qkv_x, wts[0], wts[1], cos, sin, N, 0, dw[0], dw[1]), (qkv_c, wts[2], wts[3], None, None, M, N, dw[2], dw[3]), B, H, S, torch.bfloat16)
+
+
+_, t2 = timed(two_pass)
+_, t1 = timed(lambda: ops.attn_bwd_qk(Q, K, V, Ox, Oc, dOx, dOc, lse, N, scale, qkv_x, qkv_c, *wts, cos, sin, dw4))
+print(f"attn bwd + qk-norm/rope bwd: two passes {t2 * 1e6:8.1f} us   fused {t1 * 1e6:8.1f} us")
