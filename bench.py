@@ -224,10 +224,19 @@ def main():
             if args.graph:
                 raise
             print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr, flush=True)
-        if trainer._graph is not None:
-            for _ in range(2):          # (the first replays also warm the graph's own memory)
-                step += 1
-                trainer.train_step(step)
+        if world > 1:
+            # the launch mode is a collective decision: a rank whose capture failed while the others replay would still issue the same
+            # collectives per step, but the ranks must agree before anything else is enqueued (MIN over "my capture succeeded")
+            ok = torch.tensor([1 if trainer._graph is not None else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0 and trainer._graph is not None:
+                trainer._graph = None
+                launch = "eager"
+                if rank == 0:
+                    print("bench: hipGraph capture failed on another rank; every rank times eager launches", file=sys.stderr, flush=True)
+        for _ in range(2):              # (the first replays also warm the graph's own memory; eager fallback: the same step count on every rank)
+            step += 1
+            trainer.train_step(step)
     warmup_effective = step
     sync()
     check0 = param_checksum()

@@ -9,6 +9,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
+#include <cstring>
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
 
@@ -234,6 +236,21 @@ int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IONBF, 0);
   const long bytes = 26240L * 16384 + (1 << 20);
   char* d; hipMalloc(&d, bytes); hipMemset(d, 1, bytes);
+  if (getenv("GLDS_RANDOM")) {   // pseudo-random bf16 operands (N(0,1)-ish) instead of the constant fill: what the matrix pipes' power draw depends on
+    const size_t n = bytes / 2;
+    unsigned short* h = (unsigned short*)malloc(n * 2);
+    unsigned x = 12345u;
+    for (size_t i = 0; i < n; i++) {
+      float s = 0.f;
+      for (int t = 0; t < 4; t++) { x = x * 1664525u + 1013904223u; s += (float)(x >> 8) * (1.f / 16777216.f) - 0.5f; }
+      s *= 1.7f;
+      unsigned u; memcpy(&u, &s, 4);
+      h[i] = (unsigned short)(u >> 16);
+    }
+    hipMemcpy(d, h, n * 2, hipMemcpyHostToDevice);
+    free(h);
+    printf("operands: pseudo-random bf16\n");
+  }
   unsigned* sink; hipMalloc(&sink, 64);
   for (long ld : {1536L, 16384L}) {
     if (only_gemm) break;

@@ -21,6 +21,51 @@ __global__ __launch_bounds__(512) void k(float* out, int iters) {
   if (s == 12345.f) out[0] = s;
 }
 
+// the same loop on operands that CHANGE between MFMAs: NOP pairs of pseudo-random bf16 fragments (normal-ish values from a hash of
+// lane / block / index) rotate through the instruction stream -- data toggling is what a real GEMM's matrix pipes see, and the chip's
+// power management prices it (a constant-operand loop holds the top clock, see main)
+template <int NACC, int NOP>
+__global__ __launch_bounds__(512) void krand(float* out, int iters, float scale) {
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; i++)
+    for (int r = 0; r < 16; r++) acc[i][r] = 0.f;
+  bf16x8 a[NOP], b[NOP];
+  unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+  for (int p = 0; p < NOP; p++)
+    for (int e = 0; e < 8; e++) {
+      float s = 0.f;
+      for (int t = 0; t < 4; t++) { h = h * 1664525u + 1013904223u; s += (float)(h >> 8) * (1.f / 16777216.f) - 0.5f; }   // ~N(0, 1/3)
+      a[p][e] = (__bf16)(s * scale);
+      for (int t = 0; t < 4; t++) { h = h * 1664525u + 1013904223u; s += (float)(h >> 8) * (1.f / 16777216.f) - 0.5f; }
+      b[p][e] = (__bf16)(s * scale);
+    }
+  for (int it = 0; it < iters; it += NOP) {
+#pragma unroll
+    for (int r = 0; r < NOP; r++)       // (compile-time rotation: the fragment arrays stay in registers)
+#pragma unroll
+      for (int i = 0; i < NACC; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i % NOP], b[(i + r) % NOP], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; i++) s += acc[i][0];
+  if (s == 12345.f) out[0] = s;
+}
+
+template <int NACC, int NOP>
+void run_rand(int waves_per_cu, int iters, float scale, float* d) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  const int threads = 64 * waves_per_cu;
+  for (int rep = 0; rep < 3; rep++) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((krand<NACC, NOP>), dim3(256), dim3(threads), 0, 0, d, iters, scale);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    double fl = 256.0 * waves_per_cu * (double)iters * NACC * 32768.0;
+    printf("RANDOM operands (%d rotating pairs, scale %g) nacc=%d waves/CU=%d iters=%d: %.3f ms  %.1f TFLOP/s\n", NOP, scale, NACC, waves_per_cu, iters, ms, fl / ms / 1e9);
+  }
+}
+
 template <int NACC>
 void run(int waves_per_cu, int iters, float* d) {
   hipEvent_t e0, e1;
@@ -44,5 +89,11 @@ int main() {
   run<8>(8, 200000, d);
   run<4>(8, 40000, d);
   run<2>(8, 80000, d);
+  run_rand<8, 4>(8, 200000, 1.f, d);
+  run_rand<8, 8>(8, 200000, 1.f, d);
+  run_rand<8, 8>(8, 200000, 1e-3f, d);
+  run_rand<8, 8>(8, 200000, 0.f, d);      // same instruction stream, all-zero operands
+  run_rand<8, 8>(4, 200000, 1.f, d);
+  run<8>(8, 200000, d);
   return 0;
 }
