@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
 // backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
 template <int NW, typename TG, bool FUSE = false>
-__global__ __launch_bounds__(NW * 64, FUSE ? 4 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                const bf16_t* __restrict__ Ox, const bf16_t* __restrict__ Oc,
                                                                const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
@@ -1149,16 +1149,27 @@ __global__ __launch_bounds__(NW * 64, FUSE ? 4 : 1) void attn_bwd_dq_kernel(cons
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(ktile, kb * 32, ks, lane), qf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(vtile, kb * 32, ks, lane), dof[ks], dp, 0, 0, 0);
       }
+      // per 8-row half: softmax arithmetic, pack, the half's two dQ MFMAs -- s / dp die as they are consumed (the kernel sits at its
+      // 128-VGPR cap), and the second half's VALU work issues behind the first half's MFMAs.
+      // Padding keys exist in the last K/V tile only: a wave-uniform branch.  (Written as a per-element `ragged && ...` select the
+      // compiler evaluated index, compare and two selects for EVERY score of EVERY tile: 4 of the loop's ~11 VALU slots per score.)
       const bool ragged = (j + 1) * KT > S;
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        float p = fast_exp2(fmaf(s[r], scale * LOG2E, -lq));
-        if (ragged && j * KT + kb * 32 + acc_row(r, lane) >= S) p = 0.f;
-        s[r] = p * (dp[r] - dq_delta);
-      }
-#pragma unroll
       for (int h8 = 0; h8 < 2; h8++) {
-        const bf16x8 dsf = pack_frag(s, h8);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 d8;      // (only elements [8 h8, 8 h8 + 8) are used: pack_frag's register window)
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+          const int r = 8 * h8 + i;
+          const float p = fast_exp2(fmaf(s[r], scale * LOG2E, -lq));
+          d8[r] = p * (dp[r] - dq_delta);
+        }
+        if (ragged) {
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            if (j * KT + kb * 32 + acc_row(8 * h8 + i, lane) >= S) d8[8 * h8 + i] = 0.f;
+        }
+        const bf16x8 dsf = pack_frag(d8, h8);
 #pragma unroll
         for (int db = 0; db < 2; db++) acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_d(ktile, kb * 32, h8, db, lane), dsf, acc[db], 0, 0, 0);
       }
@@ -1199,11 +1210,22 @@ __global__ __launch_bounds__(NW * 64, FUSE ? 4 : 1) void attn_bwd_dq_kernel(cons
 //   S[q][key] = Q K^T, dP[q][key] = dO V^T  (lane owns key l&31, rows = queries)
 //   dV^T[d][key] += dO^T[d][q] P[q][key],  dK^T[hd][key] += Q^T[hd][q] dS[q][key]
 // ------------------------------------------------------------------------------------------------
-template <int NW, typename TG, bool FUSE = false>
+// TRACE (probes build, tools/probes/attn_bwd_trace.py): lane 0 of every wave of the first 2048 workgroups records the cycle counter at
+// the phase boundaries (72 slots per wave)
+template <int NW, typename TG, bool FUSE = false, bool TRACE = false>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                            const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
-                                                           int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV, QkFuse F = QkFuse()) {
+                                                           int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV, QkFuse F = QkFuse(),
+                                                           unsigned long long* __restrict__ trace = nullptr) {
+  int tpos = 0;
+  auto stamp = [&]() {
+    if constexpr (TRACE) {
+      if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0 && tpos < 72) trace[((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 72 + tpos] = __builtin_readcyclecounter();
+      tpos++;
+    }
+  };
+  stamp();                                   // 0: start
   constexpr int NT = NW * 64;
   __shared__ __attribute__((aligned(16))) char smem_static[FUSE ? 16 : 2 * KT * 128 + 2 * KT * 4];
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];      // fused epilogue: qk_lds_bytes<NW>()
@@ -1239,8 +1261,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
     for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
 
   const int nq = (S + KT - 1) / KT;
-  for (int jq = 0; jq < nq; jq++) {
-    u32x4 sq[tile_chunks<NT>()], sd[tile_chunks<NT>()];
+  // The next Q / dO tile (+ its lse / delta) is requested into registers BEFORE this tile's arithmetic and parked in LDS after it: with
+  // one workgroup per CU (204 VGPRs) nothing else hides the ~2 us of a tile's round trip.  (NW = 8: one 16-byte chunk of each per thread.)
+  u32x4 sq[tile_chunks<NT>()], sd[tile_chunks<NT>()];
+  float lv = 0.f, dl = 0.f;
+  auto request = [&](int jq) {
     tile_g2r<NT>(sq, Qb, jq * KT, S, tid);
 #pragma unroll
     for (int i = 0; i < tile_chunks<NT>(); i++) {
@@ -1248,14 +1273,24 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
       const bf16_t* p = (c < 512 && s < S) ? tok_ptr(dOx, dOc, b, s, n_img, n_txt, D, h) : nullptr;
       sd[i] = p ? *(const u32x4*)(p + kc * 8) : (u32x4){0, 0, 0, 0};
     }
-    float lv = 0.f, dl = 0.f;
-    if (tid < KT && jq * KT + tid < S) { lv = lse[(int64_t)bh * S + jq * KT + tid] * LOG2E; dl = delta[(int64_t)bh * S + jq * KT + tid]; }
+    lv = 0.f, dl = 0.f;
+    if (tid < KT && jq * KT + tid < S) { lv = lse[(int64_t)bh * S + jq * KT + tid]; dl = delta[(int64_t)bh * S + jq * KT + tid]; }   // (no arithmetic on the loaded values here: it would put the wait in front of the tile's MFMAs)
+  };
+  request(0);
+  stamp();                                   // 1: K / V fragments and the first tile requested
+  for (int jq = 0; jq < nq; jq++) {
     __syncthreads();
+    stamp();                                 // per tile +0: everyone has left the previous tile
     tile_r2s_sw<NT>(sq, qtile, tid);
     tile_r2s_sw<NT>(sd, dotile, tid);
-    if (tid < KT) { lse_s[tid] = lv; del_s[tid] = dl; }
+    if (tid < KT) { lse_s[tid] = lv * LOG2E; del_s[tid] = dl; }
+    stamp();                                 // +1: this tile's chunks have landed and are parked in LDS
     __syncthreads();
-    if (!active) continue;
+    stamp();                                 // +2: ... everybody's
+#ifndef MMDIT_DKV_NO_PREFETCH
+    if (jq + 1 < nq) request(jq + 1);
+#endif
+    if (active) {
 #pragma unroll
     for (int qb = 0; qb < 2; qb++) {
       if (jq * KT + qb * 32 >= S) continue;   // (wave-uniform) 32 padding queries contribute nothing
@@ -1267,6 +1302,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(qtile, qb * 32, ks, lane), kf[ks], s, 0, 0, 0);
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(dotile, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
       }
+      if constexpr (TRACE) stamp();            // +3 / +6: S / dP MFMAs issued
       f32x16 ds;
 #pragma unroll
       for (int g = 0; g < 4; g++) {
@@ -1276,12 +1312,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 #pragma unroll
         for (int e = 0; e < 4; e++) {
           const int r = g * 4 + e;
-          const bool ok = (key < S) && (jq * KT + r0 + e < S);
-          const float p = ok ? fast_exp2(fmaf(s[r], scale * LOG2E, -l4[e])) : 0.f;
+          const float p = fast_exp2(fmaf(s[r], scale * LOG2E, -l4[e]));
           s[r] = p;
           ds[r] = p * (dp[r] - d4[e]);
         }
       }
+      // No per-score masks in the steady state: a lane whose key is padding (key >= S) works on the clamped last key and its dK / dV
+      // column is never stored; padding QUERIES exist in the last Q / dO tile only (their rows are zero-filled, lse = delta = 0, so
+      // they would contribute exact zeros anyway; masked in a wave-uniform branch to keep P and dS themselves zero there).
+      if ((jq + 1) * KT > S) {
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            if (jq * KT + qb * 32 + 8 * g + 4 * (lane >> 5) + e >= S) { s[g * 4 + e] = 0.f; ds[g * 4 + e] = 0.f; }
+      }
+      if constexpr (TRACE) stamp();            // +4 / +7: softmax arithmetic issued
 #pragma unroll
       for (int h8 = 0; h8 < 2; h8++) {
         const bf16x8 pf = pack_frag(s, h8), dsf = pack_frag(ds, h8);
@@ -1291,8 +1337,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
           dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_d(qtile, qb * 32, h8, db, lane), dsf, dk[db], 0, 0, 0);
         }
       }
+      if constexpr (TRACE) stamp();            // +5 / +8: dV / dK MFMAs issued
     }
+    }
+    if constexpr (TRACE) { const int done = !active ? 0 : (jq * KT + 32 >= S ? 1 : 2); for (int i = done * 3; i < 6; i++) stamp(); }   // (fixed slot count per tile)
+#ifdef MMDIT_DKV_NO_PREFETCH
+    if (jq + 1 < nq) request(jq + 1);
+#endif
   }
+  stamp();                                   // loop end
   if constexpr (FUSE) {
     // dK rows -> gradient of the raw k projection (qk_bwd_tile), dV rows into the v part of the same output rows
     __syncthreads();                       // every wave has left the last Q / dO tile
@@ -1328,6 +1381,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
         st4(pv + db * 32 + 8 * g + 4 * (lane >> 5), v4);
       }
   }
+  if constexpr (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp();                                   // stores done
 }
 
 // waves (32 queries / keys each) per workgroup: all waves of a workgroup share one stream of 64-row K/V (or Q/dO) tiles, so
@@ -1410,6 +1465,18 @@ extern "C" int mmdit_probe_attn_fwd_dbg(const void* Q, const void* K, const void
   return mmdit_launch_status();
 }
 
+#endif
+
+#ifdef MMDIT_PROBES
+// measurement aid (tools/probes/attn_bwd_trace.py; not declared in include/mmdit_hip.h): the dK/dV kernel (plain or fused epilogue) with per-phase
+// cycle stamps, trace = 2048 workgroups x 8 waves x 72 slots of 8 bytes.  delta must already hold rowsum(dO * O) (run mmdit_attn_bwd first).
+extern "C" int mmdit_probe_attn_bwd_dkv_trace(const void* Q, const void* K, const void* V, const void* dOx, const void* dOc, const float* lse, const float* delta,
+                                              int batch, int heads, int S, int n_img, float scale, void* dK, void* dV, void* trace, mmdit_stream_t stream) {
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, bf16_t, false, true>), dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K,
+                     (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)dK, (bf16_t*)dV, QkFuse(),
+                     (unsigned long long*)trace);
+  return mmdit_launch_status();
+}
 #endif
 
 extern "C" int mmdit_attn_bwd_qk(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc, const void* dOx, const void* dOc,

@@ -153,7 +153,19 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_like(const char* __restrict
       for (int i = 0; i < MI; i++) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jj = 0; jj < NJ; jj++) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][jj], a[i], acc[i][jj], 0, 0, 0);
+        for (int jj = 0; jj < NJ; jj++) {
+#ifdef SKEL_MFMA16   // the same FLOPs as two 16x16x32 instructions per 32x32x16 slot (power / rate experiment only: the fragment layouts are not those of a real 16x16 kernel)
+          typedef __attribute__((ext_vector_type(4))) float f32x4_;
+          f32x4_ lo = {acc[i][jj][0 + 8 * ks], acc[i][jj][1 + 8 * ks], acc[i][jj][2 + 8 * ks], acc[i][jj][3 + 8 * ks]};
+          f32x4_ hi = {acc[i][jj][4 + 8 * ks], acc[i][jj][5 + 8 * ks], acc[i][jj][6 + 8 * ks], acc[i][jj][7 + 8 * ks]};
+          lo = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[c][jj], a[i], lo, 0, 0, 0);
+          hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[c][jj], hi, 0, 0, 0);
+#pragma unroll
+          for (int e = 0; e < 4; e++) { acc[i][jj][e + 8 * ks] = lo[e]; acc[i][jj][4 + e + 8 * ks] = hi[e]; }
+#else
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][jj], a[i], acc[i][jj], 0, 0, 0);
+#endif
+        }
         if constexpr (READS) a[i] = frag(rs, (wm * (MI * 32) + i * 32) & 255, ks ^ 1);
         const int q = ks * MI + i;
         constexpr int DS = (2 * MI) / PP > 0 ? (2 * MI) / PP : 1;
