@@ -127,7 +127,8 @@ int mmdit_gemm_zero_mask(const mmdit_gemm_args* args, int count, unsigned* mask)
  * otherwise the LDS-DMA kernel (gemm_dma.hip) with tile configuration (value & 15): 0 = 128x128, 1 = 256x128,
  * 2 = 256x256, 3 = 320x256 (lean kernel only), plus 16 if the stream-K decomposition is used, plus 32 for the full-rounds +
  * split-K-tail schedule (the default K decomposition of stream_k launches), plus 128 when the lean hot-path kernel
- * (csrc/gemm_lean.hip: bf16 in / bf16 out, bias / SiLU only) takes the launch.  Negative = the MMDIT_ERR_* the launch would return.
+ * (csrc/gemm_lean.hip: bf16 in / bf16 out, bias / SiLU only; with k-major A: its weight-gradient kernel, fp32 out) takes the launch.
+ * Negative = the MMDIT_ERR_* the launch would return.
  * Lets profilers / benchmarks attribute timings to the exact kernel symbol. */
 int mmdit_gemm_plan(const mmdit_gemm_args* args, int count);
 

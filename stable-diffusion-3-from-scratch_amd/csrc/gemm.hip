@@ -471,9 +471,19 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     }
     *zero_mask = mask;
   }
-  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean ? 128 : 0)) : 64;   // see mmdit_gemm_plan
+  // lean weight-gradient kernel (gemm_lean.hip, gemm_kk_kernel): both operands k-major, fp32 C, 256x256 tiles, the round + tail (or
+  // caller-split) schedule, nothing but store / accumulate / atomic add in the epilogue.  MMDIT_GEMM_KK=0: the general kernel.
+  static const char* kk_env = getenv("MMDIT_GEMM_KK");
+  bool kk = dma && (!kk_env || atoi(kk_env)) && !fp8 && !conv && !gp.stream_k && cfg == CFG_256x256 && a0->a_kmajor && a0->b_kmajor &&
+            a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE;
+  for (int i = 0; i < count && kk; i++) {
+    const mmdit_gemm_args* a = &args[i];
+    kk = !a->bias && !a->gate && !a->residual && !a->aux && a->N % 4 == 0 && a->ldc % 4 == 0 && aligned16(a->C);
+  }
+  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
   if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
+  if (kk) return launch_lean_wgrad(gp, s);
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, fp8, gp, s);
   if (a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16) return dispatch_out<bf16_t, bf16_t, false>(a0, aux_dt, gp, s);
   if (a0->precision == MMDIT_PREC_SPLIT && a0->a_dtype == MMDIT_F32 && a0->b_dtype == MMDIT_F32) return dispatch_out<float, float, true>(a0, aux_dt, gp, s);

@@ -236,5 +236,6 @@ inline void dma_cfg_tile(int cfg, int& bm, int& bn) { bm = cfg == CFG_128x128 ? 
 int launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool fp8, const GroupParams& gp, hipStream_t s);
 // lean hot-path kernel: bf16 row-major A, bf16 B (row- or k-major), bf16 C, bias / SiLU only; cfg CFG_256x256 or CFG_320x256
 int launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t s);
+int launch_lean_wgrad(const GroupParams& gp, hipStream_t s);   // gemm_lean.hip: k-major x k-major -> fp32, 256x256, K-decomposed schedule
 
 }  // namespace gemm

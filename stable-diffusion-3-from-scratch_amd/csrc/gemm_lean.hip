@@ -404,7 +404,238 @@ int launch_wide(const GroupParams& gp, hipStream_t s) {
   return mmdit_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Lean weight-gradient kernel: C[M,N] (fp32) = A^T B with BOTH operands k-major (A [K,M], B [K,N] row-major: dW = dY^T X), the
+// K-decomposed schedule of gemm.hip (whole-K tiles in rounds + a split tail whose partial tiles are added atomically into a
+// pre-zeroed C, optionally the balanced tail), plain / accumulating / atomic fp32 epilogue -- and nothing else.  The general
+// kernel (gemm_dma_kernel<2,4,4,2,true,true,float,float>) carries the same loop, but with every feature compiled in its
+// wave-uniform state no longer fits the scalar registers (106 SGPRs + 28 spilled to VGPR lanes, 18 k lines of ISA); here the state
+// is the cursor's item, the current item and five words of the previous one.
+// ------------------------------------------------------------------------------------------------------------------------------
+template <int MI, int NJ>
+__device__ __forceinline__ void epilogue_f32_plain(f32x16 (&acc)[MI][NJ], const Problem& p, int m0, int n0, int wm, int wn, int lane, char* stage,
+                                                   bool atomic_out, bool accumulate) {
+  float* C = (float*)p.C;
+  const int wr = lane & 31, wc = lane >> 5;          // write side: row, 16-B chunk parity
+  const int rr = lane >> 3, rc = lane & 7;           // read side: row within the 8-row pass, 16-B chunk
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int col = n0 + wn * (NJ * 32) + j * 32 + rc * 4;
+      const int row0 = m0 + wm * (MI * 32) + i * 32 + rr;
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *LDS_PTR(f32x4, stage + wr * 128 + (((2 * g + wc) ^ (wr & 7)) << 4)) =
+            (f32x4){acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = row0 + it * 8;
+        if (row >= p.M || col >= p.N) continue;
+        float* cp = C + (int64_t)row * p.ldc + col;
+        if (atomic_out) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) atomicAdd(cp + e, t[e]);
+          continue;
+        }
+        if (accumulate) {
+          const f32x4 c4 = *(const f32x4*)cp;
+          t += c4;
+        }
+        __builtin_nontemporal_store(t, (f32x4*)cp);     // next read by the optimizer, a whole backward later: streaming store
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+    }
+  }
+}
+
+template <int WM, int WN, int MI, int NJ>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kk_kernel(GroupParams gp) {
+  constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
+  constexpr int HA = TBM * 64, HB = TBN * 64, H = HA + HB;           // bytes of one ring slot (a 32-deep K half)
+  constexpr int PA = TBM / 16 / NW, PB = TBN / 16 / NW, PP = PA + PB; // 1-KiB DMA pieces per wave and half
+  constexpr int DSTRIDE = (2 * MI) / PP > 0 ? (2 * MI) / PP : 1;
+  static_assert(PA >= 1 && PB >= 1 && PP <= 2 * MI && NW * EP32_WAVE_BYTES <= H && NJ == 2, "piece schedule / staging in a ring slot");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = uni(tid >> 6);
+  MMDIT_YOUNG_HALF_PRIO();
+  const int wm = wave / WN, wn = wave % WN;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const int G = (int)gridDim.x;
+
+  int pos = (int)blockIdx.x, end = total_work(gp);
+  if (gp.tail_first >= 0) {   // balanced tail: this workgroup's share of the tail units (none if its first tile is a long one)
+    const int e = xcd_chunk((int)blockIdx.x, gp.full_tiles) - gp.tail_first, E = gp.tail_G - gp.tail_first;
+    const int left = (gp.total_tiles - gp.full_tiles) * gp.split_k - e;
+    end = gp.full_tiles + (e < 0 || left <= 0 ? 0 : (left + E - 1) / E) * gp.tail_G;
+  }
+  end = uni(end);
+
+  // ---- DMA cursor: (item, half) the next issued half belongs to; wave-uniform ---------------------------------------
+  Item cit = item_at(gp, pos, end);
+  while (cit.valid && cit.h0 >= cit.h1) cit = item_at(gp, cit.pos + G, end);
+  int ch = cit.h0;
+  uint32_t va[PA], vb[PB];
+  const char* sa = nullptr;
+  const char* sb = nullptr;
+  int64_t stepa = 0, stepb = 0;
+  auto cursor_setup = [&]() {
+    const Problem& q = gp.p[cit.pi];
+#pragma unroll
+    for (int i = 0; i < PA; i++) va[i] = piece_voff<true, TBM>(wave * PA + i, lane, q.lda, cit.tm * TBM, q.M);
+#pragma unroll
+    for (int i = 0; i < PB; i++) vb[i] = piece_voff<true, TBN>(wave * PB + i, lane, q.ldb, cit.tn * TBN, q.N);
+    stepa = (int64_t)BKH * q.lda * 2;
+    stepb = (int64_t)BKH * q.ldb * 2;
+    sa = (const char*)q.A + ch * stepa;
+    sb = (const char*)q.B + ch * stepb;
+  };
+  auto cursor_advance = [&]() {   // past the end of the stream the last half is requested again (into a free slot; never read)
+    if (!cit.valid) return;
+    if (ch + 1 < cit.h1) {
+      ch++;
+      sa += stepa;
+      sb += stepb;
+      return;
+    }
+    Item nx = cit;
+    do nx = item_at(gp, nx.pos + G, end); while (nx.valid && nx.h0 >= nx.h1);
+    if (nx.valid) {
+      cit = nx;
+      ch = cit.h0;
+      cursor_setup();
+    } else {
+      cit.valid = false;
+    }
+  };
+  auto issue_piece = [&](int q, int slot) {
+    const uint32_t dst = lds0 + slot * H;
+    if (q < PA) glds16(va[q], sa, dst + (wave * PA + q) * 1024);
+    else glds16(vb[q - PA], sb, dst + HA + (wave * PB + (q - PA)) * 1024);
+  };
+
+  f32x16 acc[MI][NJ];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < MI; i++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+  };
+  int cslot = 0, dslot = 0;
+  auto bump = [](int s) { return s + 1 == RING ? 0 : s + 1; };
+
+  if (cit.valid) {
+    cursor_setup();
+#pragma unroll 1
+    for (int s = 0; s < RING - 1; s++) {
+#pragma unroll
+      for (int q = 0; q < PP; q++) issue_piece(q, dslot);
+      dslot = bump(dslot);
+      cursor_advance();
+    }
+  }
+
+  bf16x8 a[MI], b[2][NJ];
+  auto half_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 3) * PP) : "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+  auto half_body = [&]() {
+    const int nslot = bump(cslot);
+    const char* ta = smem + cslot * H;
+    const char* tb = ta + HA;
+    const char* na = smem + nslot * H;   // (after the last half of the stream: read, never used)
+    const char* nb = na + HA;
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {
+      const int c = ks & 1, nx = c ^ 1;
+      const bool last = ks == 1;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) b[nx][j] = load_frag_h<true, TBN>(last ? nb : tb, wn * (NJ * 32) + j * 32, last ? 0 : ks + 1, lane);
+#pragma unroll
+      for (int i = 0; i < MI; i++) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[c][j], a[i], acc[i][j], 0, 0, 0);
+        a[i] = load_frag_h<true, TBM>(last ? na : ta, wm * (MI * 32) + i * 32, last ? 0 : ks + 1, lane);
+        const int q = ks * MI + i;   // compile-time after unrolling
+        if (q % DSTRIDE == 0 && q / DSTRIDE < PP) {
+          __builtin_amdgcn_sched_barrier(0);
+          issue_piece(q / DSTRIDE, dslot);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    dslot = bump(dslot);
+    cslot = nslot;
+    cursor_advance();
+  };
+
+  // the previous item, as far as its epilogue needs it
+  int p_pi = 0, p_tm = 0, p_tn = 0;
+  bool p_atomic = false, pending = false, first = true;
+  auto run_epilogue = [&]() {
+    char* stage = smem + dslot * H + wave * EP32_WAVE_BYTES;   // dslot: free until the next issue
+    epilogue_f32_plain<MI, NJ>(acc, gp.p[p_pi], p_tm * TBM, p_tn * TBN, wm, wn, lane, stage, p_atomic, gp.accumulate != 0);
+  };
+  Item item = item_at(gp, pos, end);
+  while (item.valid) {
+    const int n = item.h1 - item.h0;
+    if (n > 0) half_sync();
+    else __builtin_amdgcn_s_barrier();
+    if (pending) {   // the previous tile's epilogue, deferred to here: its stores drain under the MFMAs that follow
+      run_epilogue();
+      __builtin_amdgcn_s_barrier();   // staging reads done before the DMA below refills that slot
+    }
+    zero_acc();
+    if (n > 0) {
+      if (first) {   // fragments of a tile's first half are carried over from the previous tile, except at the start of the stream
+        first = false;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) b[0][j] = load_frag_h<true, TBN>(smem + HA, wn * (NJ * 32) + j * 32, 0, lane);
+#pragma unroll
+        for (int i = 0; i < MI; i++) a[i] = load_frag_h<true, TBM>(smem, wm * (MI * 32) + i * 32, 0, lane);
+      }
+      half_body();
+#pragma unroll 1
+      for (int u = 1; u < n; u++) {
+        half_sync();
+        half_body();
+      }
+    }
+    pending = true;   // (an empty split-K slice still reaches the epilogue: it adds zeros)
+    p_pi = item.pi; p_tm = item.tm; p_tn = item.tn; p_atomic = item.atomic;
+    item = item_at(gp, item.pos + G, end);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (unused) DMA pieces must land before the LDS is reused / released
+  __builtin_amdgcn_s_barrier();                      // every wave has left the last half (its slot is the staging slot)
+  if (pending) run_epilogue();
+}
+
+int launch_kk(const GroupParams& gp, hipStream_t s) {
+  constexpr int smem = RING * (256 + 256) * 64;
+  auto k = gemm_kk_kernel<2, 4, 4, 2>;
+  static bool attr_done = false;  // idempotent; a benign race only repeats the call
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  const int work = total_work(gp);
+  const int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gp);
+  return mmdit_launch_status();
+}
+
 }  // namespace
+
+// C fp32 = A^T B, both operands k-major, 256x256 tiles, no bias / gate / residual / aux / activation (gemm.hip has checked that)
+int gemm::launch_lean_wgrad(const GroupParams& gp, hipStream_t s) { return launch_kk(gp, s); }
 
 int gemm::launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t s) {
   // wide-slot variant (128-byte DMA rows, double buffer): default; MMDIT_GEMM_WIDE=0 selects the 4-slot ring of 32-wide halves.

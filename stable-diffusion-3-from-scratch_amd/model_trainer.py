@@ -358,6 +358,14 @@ class model_trainer:
         if not in_graph:
             self._slots = [tuple(x.to(self.device).clone() for x in self._draw()) for _ in range(self.accumulation_steps)]
         torch.cuda.synchronize(self.device)
+        if self.reducer.enabled and self.device.type == "cuda":
+            # The process group's watchdog thread polls the completion events of the EAGER steps' collectives every 100 ms.  Those
+            # events were recorded on the communicator's internal stream, which joins this capture at the first captured collective;
+            # HIP then refuses hipEventQuery on them ("event last recorded in a capturing stream"), the watchdog thread throws and the
+            # process aborts -- an intermittent crash (seen once in three suite runs).  Everything is complete after the synchronize
+            # above: give the watchdog time to retire its work list before any stream starts capturing.
+            import time
+            time.sleep(0.5)
         self.optim.sync_lr(self.device)
         self.optim.prepare_capture()
         # the loss leaves the graph through a persistent buffer written by a kernel of the graph (not through a tensor of the graph's

@@ -163,6 +163,8 @@ def _variant(arr, n, outs):
     if plan == 64:
         ab = "t,t" if a.precision == PREC_BF16 else "f,f"
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
+    if plan & 128 and a.a_kmajor:
+        return "gemm_kk_kernel<2,4,4,2>" + ("+ktail" if plan & 32 else "")
     if plan & 128:
         kern = "gemm_lean_kernel" if os.environ.get("MMDIT_GEMM_WIDE", "1") == "0" else "gemm_wide_kernel"
         return f"{kern}<{_CFG[plan & 15]},{int(bool(a.b_kmajor))}>" + ("+swiglu" if a.act == ACT_SWIGLU else "")

@@ -6,6 +6,8 @@ DB=$(find gpurun_out/prof_$R -name "*.db" | head -1)
 # steps in the trace: 3 eager warm-up steps (capture needs >= 3) + 2 warm replays + 10 timed replays
 python tools/rocpd_stats.py $DB 15 60 > gpurun_out/${R}_bench_kernel_stats.txt
 python tools/rocpd_gaps.py $DB > gpurun_out/${R}_step_gaps.txt 2>&1
+# dispatches of ONE replayed step (between the last two adamw launches), by kernel: the per-step launch counts without the eager warm-up steps
+( python tools/rocpd_sequence.py $DB | awk '{print $NF}' | sort | uniq -c | sort -rn; echo "total dispatches in the step: $(python tools/rocpd_sequence.py $DB | wc -l)" ) > gpurun_out/${R}_step_dispatch_hist.txt 2>&1
 rm -rf gpurun_out/prof_$R
 bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
 ( echo "== tools/gemm_bench.py"; python tools/gemm_bench.py 2>&1 | grep -v amdgpu
