@@ -422,6 +422,9 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
         const double c = (double)((r * S + G - 1) / G) / S + (S > 1 ? 0.0028 * r * S : 0.0);
         if (c < best) { best = c; tail_split = S; }
       }
+      static const char* ts_env = getenv("MMDIT_GEMM_TAIL_S");   // experiments: force the K split of the tail tiles
+      const int ts_force = ts_env ? atoi(ts_env) : 0;
+      if (ts_force > 0 && ts_force * 2 <= nk_min) { tail_split = ts_force; best = -1.0; }
       // Balanced tail (one full round, problems of different K): in the first round the tiles of the shorter problems finish
       // early; give the tail units to exactly those workgroups (E of them) instead of stacking them on top of the longest tiles.
       if (full_tiles == G && !kdec_plain) {

@@ -67,6 +67,15 @@ def main():
             fl += 2.0 * Mr * N * K
     t = bench(lambda: ops.gemm_grouped(probs), args.reps)
     print(f"{'block wgrads, 8 problems grouped':<34}{'':>21}{t * 1e6:>10.1f}{fl / t / 1e12:>10.1f}")
+    # the weight gradients of TWO blocks, grouped by stream (equal K inside a launch) instead of by block (image + text mixed)
+    for label, Mr in (("image", Mx), ("text", Mc)):
+        probs, fl = [], 0.0
+        for _ in range(2):
+            for name, N, K in shapes:
+                probs.append(dict(A=rnd(Mr, N), B=rnd(Mr, K), a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
+                fl += 2.0 * Mr * N * K
+        t = bench(lambda: ops.gemm_grouped(probs), args.reps)
+        print(f"{'two blocks, ' + label + ' wgrads (8 problems)':<34}{'':>21}{t * 1e6:>10.1f}{fl / t / 1e12:>10.1f}")
     # square reference shapes
     for n in (4096, 8192):
         A, Bm = rnd(n, n), rnd(n, n)
