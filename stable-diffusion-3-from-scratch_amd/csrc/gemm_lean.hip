@@ -627,7 +627,11 @@ int launch_kk(const GroupParams& gp, hipStream_t s) {
     attr_done = true;
   }
   const int work = total_work(gp);
-  const int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
+  int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
+  // experiments (MMDIT_WGRAD_STREAM=1): leave CUs to the kernels of the main stream; only without the balanced tail (MMDIT_GEMM_KDEC=plain),
+  // whose unit -> workgroup map is built for 256 workgroups
+  static const char* g_env = getenv("MMDIT_GEMM_KK_GRID");
+  if (g_env && gp.tail_first < 0 && atoi(g_env) > 0 && atoi(g_env) < grid) grid = atoi(g_env);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gp);
   return mmdit_launch_status();
 }

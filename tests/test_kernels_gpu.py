@@ -579,6 +579,56 @@ def test_gemm_stream_k_grouped_wgrad(ops):
         assert rel(o, r) < 1e-5
 
 
+def test_gemm_lean_weight_gradient_kernel(ops):
+    """gemm_kk_kernel (csrc/gemm_lean.hip: both operands k-major, fp32 out, 256x256 tiles) on the schedules it runs: whole-K rounds
+    only, rounds + a split tail (atomic partial tiles into the pre-zeroed output), the balanced tail of a block's mixed image + text
+    launch, a caller-requested split-K, accumulation into an existing gradient, and ragged M / N edges -- against fp64 references of the
+    same bf16 operands, and against the general kernel (MMDIT_GEMM_KK=0 is read once per process, so that comparison is the reference)."""
+    def make(shapes, seed, **kw):
+        probs, refs = [], []
+        for i, (rows, M, N) in enumerate(shapes):
+            dY, X = rnd(rows, M, seed=seed + 2 * i, dtype=torch.bfloat16), rnd(rows, N, seed=seed + 2 * i + 1, dtype=torch.bfloat16)
+            probs.append(dict(A=dY, B=X, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, **kw))
+            refs.append(dY.double().T @ X.double())
+        return probs, refs
+
+    def plan(probs):
+        arr = (ops.GemmArgs * len(probs))()
+        for i, p in enumerate(probs):
+            ops._fill_gemm(arr[i], **p)
+        return ops._lib.lib().mmdit_gemm_plan(arr, len(probs))
+
+    if os.environ.get("MMDIT_GEMM_KK") == "0":
+        pytest.skip("the lean weight-gradient kernel is switched off (MMDIT_GEMM_KK=0)")
+    # (a) a block-like group: 4 "image" + 4 "text" problems, 288 tiles of 256x256 -> one round + balanced split tail
+    shapes = [(4096, 2304, 768), (2432, 2304, 768), (4096, 768, 768), (2432, 768, 768), (4096, 6144, 768), (2432, 6144, 768), (4096, 768, 3072), (2432, 768, 3072)]
+    probs, refs = make(shapes, 100, stream_k=True)
+    code = plan(probs)
+    assert code & 128 and code & 32 and (code & 15) == 2, code          # lean kernel, round + tail schedule, 256x256
+    outs = ops.gemm_grouped(probs)
+    for o, r in zip(outs, refs):
+        assert rel(o, r) < 1e-5
+    # (b) one round exactly / ragged edges (M = 200, N = 328: partial tiles in both directions) / K = 64 (a single K tile)
+    for shapes in ([(1024, 2048, 2048)], [(1024, 200, 328), (640, 520, 72)], [(64, 512, 256)]):
+        probs, refs = make(shapes, 200, stream_k=True)
+        if shapes[0][0] >= 512:
+            assert plan(probs) & 128, (shapes, plan(probs))
+        for o, r in zip(ops.gemm_grouped(probs), refs):
+            assert rel(o, r) < 1e-5, shapes
+    # (c) caller-requested split-K (every tile in three atomic slices)
+    probs, refs = make([(1536, 512, 512)], 300, split_k=3)
+    for o, r in zip(ops.gemm_grouped(probs), refs):
+        assert rel(o, r) < 1e-5
+    # (d) accumulation into an existing gradient (second micro-batch of an accumulated step)
+    probs, refs = make([(2048, 2304, 3072), (2048, 6144, 768)], 400)          # 180 tiles of 256x256: one round
+    base = [rnd(2304, 3072, seed=410), rnd(6144, 768, seed=411)]
+    for p, b in zip(probs, base):
+        p["out"], p["accumulate"] = b.clone(), True
+    assert plan(probs) & 128, plan(probs)
+    for o, r, b in zip(ops.gemm_grouped(probs), refs, base):
+        assert rel(o, r + b.double()) < 1e-5
+
+
 @pytest.mark.parametrize("M,h,K,bias", [(1000, 256, 128, True), (16384, 3072, 768, True), (300, 128, 64, False)])
 def test_gemm_swiglu_epilogue_equals_gemm_plus_row_kernel(ops, M, h, K, bias):
     """act=ACT_SWIGLU (activation formed in the w12 GEMM's epilogue) must be BIT-identical to the plain bf16 GEMM followed by
