@@ -51,7 +51,7 @@ typedef void* mmdit_stream_t;   /* hipStream_t */
  * (MMDIT_LIB=...) with another layout fails loudly instead of reading past a struct.  mmdit_struct_size(which): sizeof of
  * 0 mmdit_gemm_args, 1 mmdit_ln_fwd_problem, 2 mmdit_ln_bwd_problem, 3 mmdit_qk_problem, 4 mmdit_mlp_bwd_problem,
  * 5 mmdit_adamw_tensor, 6 mmdit_cast_tensor; -1 for an unknown id. */
-#define MMDIT_ABI_VERSION 3
+#define MMDIT_ABI_VERSION 4
 int mmdit_abi_version(void);
 int mmdit_struct_size(int which);
 const char* mmdit_build_arch(void);
@@ -123,6 +123,13 @@ int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t st
  * problems that own tiles of the split tail (MMDiT-B: one of a block's eight weight gradients); whole-K tiles are stored, not added,
  * and need no zero-fill.  Same planner as the launch itself (nothing is launched). */
 int mmdit_gemm_zero_mask(const mmdit_gemm_args* args, int count, unsigned* mask);
+/* Optional device workspace for the weight-gradient launches (k-major x k-major, fp32 out, K-decomposed): with it the partial tiles of
+ * the split tail are stored to per-slice slots and summed by the last slice to arrive (ticket counters) instead of being added with fp32
+ * atomics -- faster (an atomic 256x256 partial costs ~0.6 us of launch time), deterministic, and the outputs need no zero-fill
+ * (mmdit_gemm_zero_mask reports none).  Layout: 4 KiB of tickets, ZERO-FILLED by the caller once, then 256 KiB slots; a launch that
+ * needs more slots than fit falls back to atomics.  One workspace per process: launches that use it must be stream-ordered.
+ * ptr = NULL, bytes = 0 removes it.  The library never allocates. */
+int mmdit_gemm_set_workspace(void* ptr, long long bytes);
 /* Which kernel mmdit_gemm_grouped would launch for these problems (no launch): 64 = register-staged kernel (gemm.hip);
  * otherwise the LDS-DMA kernel (gemm_dma.hip) with tile configuration (value & 15): 0 = 128x128, 1 = 256x128,
  * 2 = 256x256, 3 = 320x256 (lean kernel only), plus 16 if the stream-K decomposition is used, plus 32 for the full-rounds +

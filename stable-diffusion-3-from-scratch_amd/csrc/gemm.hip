@@ -251,6 +251,10 @@ int check_problem(const mmdit_gemm_args* a) {
 
 // Tile-configuration heuristic of the LDS-DMA path.  Bigger tiles halve the L2->CU traffic per FLOP (a 128x128
 // tile needs ~64 B/clk/CU at full MFMA rate, about what the L2 can deliver) but need enough tiles to fill 256 CUs.
+// workspace of the lean weight-gradient kernel's split tail (device memory owned by the caller; first 4 KiB: zero-initialised tickets)
+static void* g_ws = nullptr;
+static long long g_ws_bytes = 0;
+
 static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k, bool lean_ok) {
   static const char* force = getenv("MMDIT_GEMM_CFG");
   if (force) return atoi(force) == CFG_320x256 && !lean_ok ? CFG_256x256 : atoi(force);
@@ -463,17 +467,6 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     MMDIT_CHECK_ARG(dma && a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE && !a0->accumulate && split_k <= 64);
     for (int i = 0; i < count; i++) MMDIT_CHECK_ARG(!args[i].aux && !args[i].gate);
   }
-  if (zero_mask) {
-    // which outputs receive ATOMIC partial tiles (and therefore must be zero when the launch starts): every problem under stream-K or
-    // a caller-requested split-K; with the round + tail schedule only the problems that own tiles of the split tail; none otherwise
-    unsigned mask = 0;
-    for (int i = 0; i < count; i++) {
-      const Problem& q = gp.p[i];
-      const bool atomic = dma && (gp.stream_k || (gp.split_k > 1 && q.tile_start + q.tiles_m * q.tiles_n > gp.full_tiles));
-      if (atomic) mask |= 1u << order[i];
-    }
-    *zero_mask = mask;
-  }
   // lean weight-gradient kernel (gemm_lean.hip, gemm_kk_kernel): both operands k-major, fp32 C, 256x256 tiles, the round + tail (or
   // caller-split) schedule, nothing but store / accumulate / atomic add in the epilogue.  MMDIT_GEMM_KK=0: the general kernel.
   static const char* kk_env = getenv("MMDIT_GEMM_KK");
@@ -482,6 +475,27 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   for (int i = 0; i < count && kk; i++) {
     const mmdit_gemm_args* a = &args[i];
     kk = !a->bias && !a->gate && !a->residual && !a->aux && a->N % 4 == 0 && a->ldc % 4 == 0 && aligned16(a->C);
+  }
+  // ... whose split tail goes through the registered workspace (mmdit_gemm_set_workspace) instead of fp32 atomics when it is large enough:
+  // 4 KiB of tickets + one 256x256 fp32 slot per (tail tile, K slice)
+  gp.ws_slots = nullptr; gp.ws_count = nullptr;
+  if (kk && g_ws && gp.split_k > 1) {
+    const long long tail_tiles = tiles - full_tiles;
+    if (tail_tiles <= 1024 && 4096 + tail_tiles * gp.split_k * 65536LL * 4 <= g_ws_bytes) {
+      gp.ws_count = (int*)g_ws;
+      gp.ws_slots = (float*)((char*)g_ws + 4096);
+    }
+  }
+  if (zero_mask) {
+    // which outputs receive ATOMIC partial tiles (and therefore must be zero when the launch starts): every problem under stream-K or
+    // a caller-requested split-K; with the round + tail schedule only the problems that own tiles of the split tail; none otherwise
+    unsigned mask = 0;
+    for (int i = 0; i < count; i++) {
+      const Problem& q = gp.p[i];
+      const bool atomic = dma && !gp.ws_slots && (gp.stream_k || (gp.split_k > 1 && q.tile_start + q.tiles_m * q.tiles_n > gp.full_tiles));
+      if (atomic) mask |= 1u << order[i];
+    }
+    *zero_mask = mask;
   }
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
@@ -494,6 +508,13 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
 }
 
 extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) { return gemm_grouped_impl(args, count, stream, false); }
+
+extern "C" int mmdit_gemm_set_workspace(void* ptr, long long bytes) {
+  MMDIT_CHECK_ARG((ptr == nullptr && bytes == 0) || (ptr != nullptr && bytes >= 4096 + 65536 * 4 && ((uintptr_t)ptr & 15) == 0));
+  g_ws = ptr;
+  g_ws_bytes = bytes;
+  return 0;
+}
 
 extern "C" int mmdit_gemm_plan(const mmdit_gemm_args* args, int count) { return gemm_grouped_impl(args, count, nullptr, true); }
 

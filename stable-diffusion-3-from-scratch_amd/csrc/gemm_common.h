@@ -32,6 +32,11 @@ struct GroupParams {
   int tail_first, tail_rounds, tail_G;
   int stream_k, total_units, persistent;   // stream-K: every workgroup gets an equal share of the (tile, K-tile) units
   int mx;                                  // fp8 operands: scale_a / scale_b are E8M0 block-scale tensors (MX), not per-tensor fp32 scalars
+  // lean weight-gradient kernel: the partial tiles of the split tail go through a workspace instead of fp32 atomics -- slice sk of tail
+  // tile tt is stored to ws_slots + (tt * split_k + sk) * 65536, the LAST of the tile's split_k slices to arrive (ticket ws_count[tt])
+  // sums the slots in slice order and writes C (deterministic; C needs no zero-fill).  nullptr: atomics.
+  float* ws_slots;
+  int* ws_count;
 };
 
 // block id -> (problem, m-tile, n-tile, split-K slice).

@@ -452,6 +452,34 @@ __device__ __forceinline__ void epilogue_f32_plain(f32x16 (&acc)[MI][NJ], const 
   }
 }
 
+// a partial tile of the split tail into its workspace slot (row-major [TBM][TBN] fp32, whole tile, no bounds: the slot is private)
+template <int MI, int NJ>
+__device__ __forceinline__ void epilogue_f32_slot(f32x16 (&acc)[MI][NJ], float* slot, int ld, int wm, int wn, int lane, char* stage) {
+  const int wr = lane & 31, wc = lane >> 5;
+  const int rr = lane >> 3, rc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *LDS_PTR(f32x4, stage + wr * 128 + (((2 * g + wc) ^ (wr & 7)) << 4)) =
+            (f32x4){acc[i][j][g * 4], acc[i][j][g * 4 + 1], acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3]};
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        // device-scope write-through store (sc1): the slot is read by a workgroup on another XCD, whose L2 is not coherent with this one;
+        // a release FENCE would write back this XCD's whole L2 instead (measured: the fenced version was slower than the atomics)
+        float* dst = slot + (int64_t)(wm * (MI * 32) + i * 32 + r) * ld + wn * (NJ * 32) + j * 32 + rc * 4;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(t) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
 template <int WM, int WN, int MI, int NJ>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kk_kernel(GroupParams gp) {
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
@@ -577,11 +605,73 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kk_kernel(GroupParams gp) {
   };
 
   // the previous item, as far as its epilogue needs it
-  int p_pi = 0, p_tm = 0, p_tn = 0;
+  int p_pi = 0, p_tm = 0, p_tn = 0, p_sk = 0, p_tile = 0;
   bool p_atomic = false, pending = false, first = true;
+  __shared__ int s_ticket;
   auto run_epilogue = [&]() {
     char* stage = smem + dslot * H + wave * EP32_WAVE_BYTES;   // dslot: free until the next issue
-    epilogue_f32_plain<MI, NJ>(acc, gp.p[p_pi], p_tm * TBM, p_tn * TBN, wm, wn, lane, stage, p_atomic, gp.accumulate != 0);
+    const Problem& q = gp.p[p_pi];
+    if (p_atomic && gp.ws_slots) {
+      // Partial tile of the split tail: no fp32 atomics (each 256x256 partial costs ~0.6 us of L2 atomic throughput for the WHOLE
+      // launch).  Store it to the slice's workspace slot, publish (release fence + ticket); the last of the tile's slices to arrive sums
+      // the slots in slice order -- deterministic -- and writes C.  No workgroup ever waits for another one.
+      constexpr int TE = TBM * TBN;
+      const int tt = p_tile - gp.full_tiles, S = gp.split_k;
+      float* slots = gp.ws_slots + (int64_t)tt * S * TE;
+      epilogue_f32_slot<MI, NJ>(acc, slots + (int64_t)p_sk * TE, TBN, wm, wn, lane, stage);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores of this wave have reached memory
+      __syncthreads();                                   // ... of every wave
+      if (tid == 0) s_ticket = atomicAdd(gp.ws_count + tt, 1);   // (device-scope atomic, performed at the memory side)
+      __syncthreads();
+      if (s_ticket == S - 1) {               // (workgroup-uniform) every slice of this tile has been published
+        float* C = (float*)q.C;
+        const int m0 = p_tm * TBM, n0 = p_tn * TBN;
+        // device-scope (sc1) loads past this XCD's L2, 8 chunks x up to 4 slices in flight per lane; the loads are issued from asm (the
+        // compiler has no sc1 load), so their destinations are handed to it only through the wait that follows them
+        constexpr int NCH = TE / 4 / (64 * NW);     // 16-byte chunks per lane (32 for the 256x256 tile)
+        static_assert(NCH % 4 == 0, "chunk batches");
+#pragma unroll 1
+        for (int b0 = 0; b0 < NCH; b0 += 4) {
+          f32x4 t[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) t[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+          for (int s0 = 0; s0 < S; s0 += 4) {
+            f32x4 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int idx = tid + (b0 + u) * (64 * NW), r = idx / (TBN / 4), c = (idx % (TBN / 4)) * 4;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const float* src = slots + (int64_t)min(s0 + k, S - 1) * TE + (int64_t)r * TBN + c;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u][k]) : "v"(src) : "memory");
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory");
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if (s0 + k < S) t[u] += v[u][k];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int idx = tid + (b0 + u) * (64 * NW), r = idx / (TBN / 4), c = (idx % (TBN / 4)) * 4;
+            if (m0 + r < q.M && n0 + c < q.N) {
+              float* cp = C + (int64_t)(m0 + r) * q.ldc + n0 + c;
+              if (gp.accumulate) t[u] += *(const f32x4*)cp;
+              __builtin_nontemporal_store(t[u], (f32x4*)cp);
+            }
+          }
+        }
+        if (tid == 0) gp.ws_count[tt] = 0;   // ready for the next launch (stream order)
+      }
+      __syncthreads();                       // (s_ticket is reused by the next partial tile of this workgroup)
+      return;
+    }
+    epilogue_f32_plain<MI, NJ>(acc, q, p_tm * TBM, p_tn * TBN, wm, wn, lane, stage, p_atomic, gp.accumulate != 0);
   };
   Item item = item_at(gp, pos, end);
   while (item.valid) {
@@ -609,7 +699,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kk_kernel(GroupParams gp) {
       }
     }
     pending = true;   // (an empty split-K slice still reaches the epilogue: it adds zeros)
-    p_pi = item.pi; p_tm = item.tm; p_tn = item.tn; p_atomic = item.atomic;
+    p_pi = item.pi; p_tm = item.tm; p_tn = item.tn; p_atomic = item.atomic; p_sk = item.sk; p_tile = item.tile;
     item = item_at(gp, item.pos + G, end);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (unused) DMA pieces must land before the LDS is reused / released

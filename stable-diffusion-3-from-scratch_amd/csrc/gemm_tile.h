@@ -380,6 +380,7 @@ struct Item {
   int pi;   // problem index (kept as an index so that every access stays a scalar kernarg load)
   int tm, tn, h0, h1, sk;
   bool atomic;   // partial tile: added atomically into the pre-zeroed fp32 C
+  int tile;      // index in the launch's tile order (the split tail: tile - full_tiles names the workspace slots)
   int pos;
   bool valid;
 };
@@ -391,6 +392,7 @@ __device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end)
   it.pi = 0;
   it.tm = it.tn = it.h0 = it.h1 = it.sk = 0;
   it.atomic = false;
+  it.tile = 0;
   if (!it.valid) return it;
   if (gp.stream_k) {
     // stream-K: the (tile, K-tile) units of all problems are split evenly over the resident workgroups; a workgroup
@@ -429,6 +431,7 @@ __device__ __forceinline__ Item item_at(const GroupParams& gp, int pos, int end)
     it.h1 = 2 * kt1;
     it.sk = sk;
     it.atomic = S > 1;
+    it.tile = t;
   }
   return it;
 }

@@ -171,10 +171,29 @@ def _variant(arr, n, outs):
     return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "") + ("+swiglu" if a.act == ACT_SWIGLU else "")
 
 
+# Workspace of the weight-gradient launches' split tail (mmdit_gemm_set_workspace): 4 KiB of zeroed tickets + 256 slots of 256 KiB, one per
+# process, allocated at the first K-decomposed launch on a GPU and kept for the life of the process (a captured hipGraph holds its address).
+# MMDIT_GEMM_WS=0: fp32 atomics instead (the round-2 path).
+_GEMM_WS = {}
+_GEMM_WS_ON = os.environ.get("MMDIT_GEMM_WS", "1") != "0"
+
+
+def _ensure_gemm_workspace(device):
+    if not _GEMM_WS_ON or _GEMM_WS:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        return          # (never allocate the process-wide workspace inside a capture: the eager warm-up steps do it)
+    ws = torch.zeros(4096 + 256 * 65536 * 4, dtype=torch.uint8, device=device)
+    check(_lib.lib().mmdit_gemm_set_workspace(ws.data_ptr(), ws.numel()), "mmdit_gemm_set_workspace")
+    _GEMM_WS[device] = ws
+
+
 def gemm_grouped(problems):
     """problems: list of dicts of gemm() keyword arguments (plus 'A', 'B'), all of one kernel variant.
     One launch; returns the list of outputs."""
     n = len(problems)
+    if problems[0]["A"].is_cuda and (problems[0].get("stream_k") or problems[0].get("split_k", 1) > 1):
+        _ensure_gemm_workspace(problems[0]["A"].device)
     arr = (GemmArgs * n)()
     outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
     if any(getattr(o, "_mmdit_zero_check", None) is not None for o in outs):

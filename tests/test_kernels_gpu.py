@@ -697,10 +697,25 @@ def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
     assert rel(y.float(), A.float() @ W.float().t() + bias) < 6e-2
 
 
-def test_gemm_zero_mask_marks_exactly_the_outputs_that_receive_atomics(ops):
+@pytest.mark.parametrize("workspace", [False, True])
+def test_gemm_zero_mask_marks_exactly_the_outputs_that_receive_atomics(ops, workspace):
     """mmdit_gemm_zero_mask: in a K-decomposed grouped launch (a block's weight gradients) only the problems that own tiles of the
     split tail are accumulated atomically.  Every other output is pre-filled with NaN here and must come out fully overwritten and
-    correct; the flagged ones start from zero."""
+    correct; the flagged ones start from zero.  With the split-tail workspace registered (mmdit_gemm_set_workspace: partial tiles through
+    per-slice slots, the last slice to arrive sums them) NO output needs a zero-fill, the result is the same and it is deterministic."""
+    import ctypes
+    from sd3_amd import _lib
+    ws = torch.zeros(4096 + 256 * 65536 * 4, dtype=torch.uint8, device="cuda") if workspace else None
+    prev = ops._GEMM_WS.get(torch.device("cuda", torch.cuda.current_device()))
+    assert _lib.lib().mmdit_gemm_set_workspace(ws.data_ptr() if workspace else None, ws.numel() if workspace else 0) == 0
+    try:
+        _zero_mask_case(ops, workspace)
+    finally:        # back to the process-wide workspace of ops (or none)
+        torch.cuda.synchronize()
+        assert _lib.lib().mmdit_gemm_set_workspace(prev.data_ptr() if prev is not None else None, prev.numel() if prev is not None else 0) == 0
+
+
+def _zero_mask_case(ops, workspace):
     import ctypes
     from sd3_amd import _lib
     g = torch.Generator(device="cuda").manual_seed(9)
@@ -718,13 +733,22 @@ def test_gemm_zero_mask_marks_exactly_the_outputs_that_receive_atomics(ops):
     mask = ctypes.c_uint(0)
     assert _lib.lib().mmdit_gemm_zero_mask(arr, n, ctypes.byref(mask)) == 0
     flagged = [(mask.value >> i) & 1 for i in range(n)]
-    assert 0 < sum(flagged) < n, flagged                    # 288 tiles on 256 workgroups: a tail exists, and it is not everything
-    for o, f in zip(outs, flagged):
-        o.fill_(0.0 if f else float("nan"))
-    ops.gemm_grouped([dict(out=o, **p) for o, p in zip(outs, probs)])
+    if workspace:
+        assert sum(flagged) == 0, flagged                   # nothing is accumulated in place
+    else:
+        assert 0 < sum(flagged) < n, flagged                # 288 tiles on 256 workgroups: a tail exists, and it is not everything
+    runs = []
+    for _ in range(2):
+        for o, f in zip(outs, flagged):
+            o.fill_(0.0 if f else float("nan"))
+        # (straight through the C ABI: ops.gemm_grouped would register the process-wide workspace)
+        assert _lib.lib().mmdit_gemm_grouped(arr, n, torch.cuda.current_stream().cuda_stream) == 0
+        runs.append([o.clone() for o in outs])
     for o, p in zip(outs, probs):
         ref = p["A"].float().t() @ p["B"].float()
         assert torch.isfinite(o).all() and rel(o, ref) < 2e-5
+    if workspace:       # fixed summation order of the slices: bit-identical from launch to launch (the atomics are not)
+        assert all(torch.equal(a, b) for a, b in zip(*runs))
 
 
 @pytest.mark.parametrize("res", [False, True])
