@@ -285,13 +285,13 @@ int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int batch, int h
  * epilogues of its two kernels: the dQ / dK rows go from the accumulators straight to the gradient of the raw QKV projections
  * dqkv_x (batch * n_img, 3 * heads * 64) / dqkv_c (batch * (S - n_img), 3 * heads * 64) [q | k | v per row, bf16], dV rows are stored into
  * their v part -- no dQ / dK / dV tensors, no separate mmdit_qk_norm_rope_bwd pass.  qkv_x / qkv_c: the saved raw projections (bf16, same
- * geometry); wq_* / wk_*: the norm weights (64); rope_cos / rope_sin (n_img, 64).  dw_part: (workgroups, 256) fp32 workspace,
- * workgroups = ceil(S / 256) * batch * heads: every workgroup's partial norm-weight gradients [wq_x | wk_x | wq_c | wk_c], to be
- * column-summed by the caller (mmdit_colsum).  n_img % 32 == 0 (else MMDIT_ERR_SHAPE: use the two-pass form). */
+ * geometry); wq_* / wk_*: the norm weights (64); rope_cos / rope_sin (n_img, 64).  dw: (256) fp32, the norm-weight gradients
+ * [wq_x | wk_x | wq_c | wk_c], ACCUMULATED (every workgroup adds its LDS-reduced sums with one atomic per feature: zero or hold the
+ * running gradient on entry).  n_img % 32 == 0 (else MMDIT_ERR_SHAPE: use the two-pass form). */
 int mmdit_attn_bwd_qk(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc, const void* dOx, const void* dOc,
                       const float* lse, float* delta, int batch, int heads, int S, int n_img, float scale,
                       const void* qkv_x, const void* qkv_c, const float* wq_x, const float* wk_x, const float* wq_c, const float* wk_c,
-                      const float* rope_cos, const float* rope_sin, void* dqkv_x, void* dqkv_c, float* dw_part, mmdit_stream_t stream);
+                      const float* rope_cos, const float* rope_sin, void* dqkv_x, void* dqkv_c, float* dw, mmdit_stream_t stream);
 int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc,
                    const void* dOx, const void* dOc, const float* lse, float* delta,
                    int batch, int heads, int S, int n_img, float scale,

@@ -127,7 +127,7 @@ struct QkFuse {
   const float* wq_x; const float* wk_x; const float* wq_c; const float* wk_c;   // norm weights (64)
   const float* rcos; const float* rsin;          // RoPE factors (n_img, 64)
   bf16_t* dqkv_x; bf16_t* dqkv_c;                // outputs, same geometry as qkv_x / qkv_c
-  float* dw_part;                                // (workgroups, 256) partial weight gradients: [wq_x | wk_x | wq_c | wk_c]
+  float* dw;                                     // (256) norm-weight gradients [wq_x | wk_x | wq_c | wk_c], accumulated (one atomic add per workgroup and feature)
 };
 
 // The epilogue goes through the LDS: a wave parks its 32 x 64 fp32 accumulator tile row-major (stride QK_ROW_F floats: b128 writes of
@@ -1192,7 +1192,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_bwd_dq_kernel(c
                   img ? F.rcos + (int64_t)tok0 * 64 : nullptr, img ? F.rsin + (int64_t)tok0 * 64 : nullptr, sdw + (img ? 0 : 64));
     }
     __syncthreads();
-    if (tid < 128) F.dw_part[(int64_t)blockIdx.x * 256 + (tid >> 6) * 128 + (tid & 63)] = sdw[tid];    // columns [wq_x | . | wq_c | .]
+    if (tid < 128 && sdw[tid] != 0.f) atomicAdd(F.dw + (tid >> 6) * 128 + (tid & 63), sdw[tid]);    // [wq_x | . | wq_c | .]  (a workgroup is all image or mostly one stream: half of the adds are exact zeros)
   } else if (q < S) {
     TG* dst = dQ + ((int64_t)bh * S + q) * HD;
 #pragma unroll
@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
       rows_from_tile(tile, lane, nvalid, ob + D, pitch);
     }
     __syncthreads();
-    if (tid < 128) F.dw_part[(int64_t)blockIdx.x * 256 + (tid >> 6) * 128 + 64 + (tid & 63)] = sdw[tid];   // columns [. | wk_x | . | wk_c]
+    if (tid < 128 && sdw[tid] != 0.f) atomicAdd(F.dw + (tid >> 6) * 128 + 64 + (tid & 63), sdw[tid]);   // [. | wk_x | . | wk_c]
   } else if (key < S) {
     TG* pk = dK + ((int64_t)bh * S + key) * HD;
     TG* pv = dV + ((int64_t)bh * S + key) * HD;
@@ -1482,12 +1482,12 @@ extern "C" int mmdit_probe_attn_bwd_dkv_trace(const void* Q, const void* K, cons
 extern "C" int mmdit_attn_bwd_qk(const void* Q, const void* K, const void* V, const void* Ox, const void* Oc, const void* dOx, const void* dOc,
                                  const float* lse, float* delta, int batch, int heads, int S, int n_img, float scale,
                                  const void* qkv_x, const void* qkv_c, const float* wq_x, const float* wk_x, const float* wq_c, const float* wk_c,
-                                 const float* rope_cos, const float* rope_sin, void* dqkv_x, void* dqkv_c, float* dw_part, mmdit_stream_t stream) {
+                                 const float* rope_cos, const float* rope_sin, void* dqkv_x, void* dqkv_c, float* dw, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(Q && K && V && Ox && dOx && lse && delta && batch > 0 && heads > 0 && S > 0 && n_img > 0 && n_img <= S);
   MMDIT_CHECK_ARG(Oc || n_img == S);
-  MMDIT_CHECK_ARG(qkv_x && wq_x && wk_x && rope_cos && rope_sin && dqkv_x && dw_part && (n_img == S || (qkv_c && wq_c && wk_c && dqkv_c)));
+  MMDIT_CHECK_ARG(qkv_x && wq_x && wk_x && rope_cos && rope_sin && dqkv_x && dw && (n_img == S || (qkv_c && wq_c && wk_c && dqkv_c)));
   if (n_img % 32) return MMDIT_ERR_SHAPE;       // a wave's 32 rows must belong to one stream
-  const QkFuse F{(const bf16_t*)qkv_x, (const bf16_t*)qkv_c, wq_x, wk_x, wq_c, wk_c, rope_cos, rope_sin, (bf16_t*)dqkv_x, (bf16_t*)dqkv_c, dw_part};
+  const QkFuse F{(const bf16_t*)qkv_x, (const bf16_t*)qkv_c, wq_x, wk_x, wq_c, wk_c, rope_cos, rope_sin, (bf16_t*)dqkv_x, (bf16_t*)dqkv_c, dw};
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(((S + 255) / 256) * batch * heads);
   constexpr int lds = qk_lds_bytes<8>();        // 70144 B: above the 64 KB default cap of dynamic LDS

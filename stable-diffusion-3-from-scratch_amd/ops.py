@@ -569,12 +569,11 @@ def attn_bwd_qk(Q, K, V, Ox, Oc, dOx, dOc, lse, n_img, scale, qkv_x, qkv_c, wq_x
     delta = torch.empty((batch, heads, S), dtype=torch.float32, device=Q.device)
     dqkv_x = torch.empty(qkv_x.shape, dtype=torch.bfloat16, device=Q.device)
     dqkv_c = torch.empty(qkv_c.shape, dtype=torch.bfloat16, device=Q.device)
-    nwg = (S + 255) // 256 * batch * heads
-    part = torch.empty((nwg, 256), dtype=torch.float32, device=Q.device)
+    if dw4.dtype != torch.float32 or dw4.numel() != 256 or not dw4.is_contiguous():
+        raise RuntimeError("attn_bwd_qk: dw4 is the contiguous fp32 [wq_x | wk_x | wq_c | wk_c] accumulator (256)")
     check(_lib.lib().mmdit_attn_bwd_qk(_p(Q), _p(K), _p(V), _p(Ox), _p(Oc), _p(_c(dOx)), _p(_c(dOc)), _p(lse), _p(delta), batch, heads, S, n_img, float(scale),
                                        _p(_c(qkv_x)), _p(_c(qkv_c)), _p(wq_x), _p(wk_x), _p(wq_c), _p(wk_c), _p(rope_cos), _p(rope_sin),
-                                       _p(dqkv_x), _p(dqkv_c), _p(part), _s()), "mmdit_attn_bwd_qk")
-    colsum(part, dw4)
+                                       _p(dqkv_x), _p(dqkv_c), _p(dw4), _s()), "mmdit_attn_bwd_qk")
     return dqkv_x, dqkv_c
 
 
