@@ -91,16 +91,17 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const TI* __restrict__ x,
   for (int e = 0; e < 8; e++) { a1[e] = 0.f; a2[e] = 0.f; }
   const int r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
   if (ty < nty) {
-    for (int r = r0 + ty; r < r1; r += 2 * nty) {
-      float v[8], w[8];
-      const int r2 = r + nty;
-      ld8(x + ((int64_t)b * HW + r) * C + tx * 8, v);
-      if (r2 < r1) ld8(x + ((int64_t)b * HW + r2) * C + tx * 8, w);
+    // four rows in flight per thread, loaded unconditionally from a clamped row (a row past the end re-reads the last one and is
+    // dropped): under `if (r < r1)` the loads of an iteration were serialised round trips
+    for (int r = r0 + ty; r < r1; r += 4 * nty) {
+      float v[4][8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { a1[e] += v[e]; a2[e] += v[e] * v[e]; }
-      if (r2 < r1) {
+      for (int k = 0; k < 4; k++) ld8_nt(x + ((int64_t)b * HW + min(r + k * nty, r1 - 1)) * C + tx * 8, v[k]);
 #pragma unroll
-        for (int e = 0; e < 8; e++) { a1[e] += w[e]; a2[e] += w[e] * w[e]; }
+      for (int k = 0; k < 4; k++) {
+        if (r + k * nty >= r1) break;
+#pragma unroll
+        for (int e = 0; e < 8; e++) { a1[e] += v[k][e]; a2[e] += v[k][e] * v[k][e]; }
       }
     }
     const int cpg = C / G;
@@ -236,7 +237,11 @@ extern "C" int mmdit_vae_groupnorm(const void* x, int x_dtype, const float* gamm
                                    float* sums_zeroed, void* y_bf16, int pad, mmdit_stream_t stream) {
   MMDIT_CHECK_ARG(x && gamma && beta && sums_zeroed && y_bf16 && batch > 0 && H > 0 && W > 0 && C % 8 == 0 && C / 8 <= 256 && groups > 0 && groups <= 64 && C % groups == 0);
   hipStream_t s = (hipStream_t)stream;
-  const int rpb = 128, HW = H * W;
+  const int HW = H * W;
+  // statistics: ~2048 workgroups per launch, whatever the tensor size -- every workgroup ends with 2 * groups global atomics onto the
+  // batch * 2 * groups sums (at 128 rows per workgroup a 512^2 x 128 x 16 tensor made 2 M atomics onto 1024 addresses: 1.2 TB/s)
+  int rpb = 128;
+  while ((int64_t)((HW + rpb - 1) / rpb) * batch > 2048 && rpb < HW) rpb *= 2;
   const int ppb = 128;   // pixels per apply workgroup
   dim3 g1((HW + rpb - 1) / rpb, batch), g2((HW + ppb - 1) / ppb, batch);
   if (x_dtype == MMDIT_F32) {
