@@ -175,7 +175,7 @@ def _variant(arr, n, outs):
 # process, allocated at the first K-decomposed launch on a GPU and kept for the life of the process (a captured hipGraph holds its address).
 # MMDIT_GEMM_WS=0: fp32 atomics instead (the round-2 path).
 _GEMM_WS = {}
-_GEMM_WS_ON = os.environ.get("MMDIT_GEMM_WS", "1") != "0"
+_GEMM_WS_ON = os.environ.get("MMDIT_GEMM_WS", "1") != "0" and os.environ.get("MMDIT_WGRAD_STREAM", "0") != "1"   # (one workspace: its launches must be stream-ordered -- not with the weight-gradient side stream)
 
 
 def _ensure_gemm_workspace(device):
