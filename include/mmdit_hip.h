@@ -50,8 +50,8 @@ typedef void* mmdit_stream_t;   /* hipStream_t */
  * Python binding (_lib.py) refuses a library whose version or struct sizes differ from what it was written for, so a scratch build
  * (MMDIT_LIB=...) with another layout fails loudly instead of reading past a struct.  mmdit_struct_size(which): sizeof of
  * 0 mmdit_gemm_args, 1 mmdit_ln_fwd_problem, 2 mmdit_ln_bwd_problem, 3 mmdit_qk_problem, 4 mmdit_mlp_bwd_problem,
- * 5 mmdit_adamw_tensor, 6 mmdit_cast_tensor; -1 for an unknown id. */
-#define MMDIT_ABI_VERSION 4
+ * 5 mmdit_adamw_tensor, 6 mmdit_cast_tensor, 7 mmdit_qk_epilogue; -1 for an unknown id. */
+#define MMDIT_ABI_VERSION 5
 int mmdit_abi_version(void);
 int mmdit_struct_size(int which);
 const char* mmdit_build_arch(void);
@@ -123,6 +123,23 @@ int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t st
  * problems that own tiles of the split tail (MMDiT-B: one of a block's eight weight gradients); whole-K tiles are stored, not added,
  * and need no zero-fill.  Same planner as the launch itself (nothing is launched). */
 int mmdit_gemm_zero_mask(const mmdit_gemm_args* args, int count, unsigned* mask);
+/* The QKV projection of an attention block with the per-head QK RMSNorm, the axial RoPE and the joint-layout store in the GEMM's epilogue
+ * (Attention.py:118-135, 174-194, 258-261): one launch for the image and the text stream (count = 1 or 2 problems, in that order).
+ * args[i]: bf16 row-major A (rows, K), bf16 row-major packed weight B (3 * heads * 64, K) = [q | k | v] rows, bf16 C (rows, 3 * heads * 64)
+ * = the raw projection, kept for backward: its q and k columns exactly as mmdit_gemm writes them, its v columns NOT written (V below is
+ * the same data; the backward kernels read only q and k of C); no bias, no activation.  In addition the rows are written
+ * to Q, K, V (batch, heads, s_total, 64) bf16: token n of sample b of stream i (row b * tokens + n) at position tok0 + n; q and k are
+ * RMS-normalised over the 64 features of their head (weights wq / wk, eps = finfo(float32).eps) and, when rope_cos / rope_sin (tokens, 64)
+ * are given, rotated -- the arithmetic of mmdit_qk_norm_rope_fwd on the ROUNDED raw values, i.e. the same results without its pass.
+ * MMDIT_ERR_SHAPE when the planner would not give these problems to the lean wide-slot kernel (run mmdit_gemm_grouped +
+ * mmdit_qk_norm_rope_fwd_pair instead). */
+typedef struct mmdit_qk_epilogue {
+  const float* wq; const float* wk;
+  const float* rope_cos; const float* rope_sin;
+  int tokens, tok0;
+} mmdit_qk_epilogue;
+int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogue* qk, int count, int heads, int s_total,
+                             void* Q, void* K, void* V, mmdit_stream_t stream);
 /* Optional device workspace for the weight-gradient launches (k-major x k-major, fp32 out, K-decomposed): with it the partial tiles of
  * the split tail are stored to per-slice slots and summed by the last slice to arrive (ticket counters) instead of being added with fp32
  * atomics -- faster (an atomic 256x256 partial costs ~0.6 us of launch time), deterministic, and the outputs need no zero-fill

@@ -63,6 +63,11 @@ class MlpBwdProblem(ctypes.Structure):     # mirrors mmdit_mlp_bwd_problem
     _fields_ = [("dh", ctypes.c_void_p), ("gu", ctypes.c_void_p), ("dgu", ctypes.c_void_p), ("rows", ctypes.c_int), ("dbias", ctypes.c_void_p)]
 
 
+class QkEpilogue(ctypes.Structure):
+    """mmdit_qk_epilogue"""
+    _fields_ = [("wq", _vp), ("wk", _vp), ("rope_cos", _vp), ("rope_sin", _vp), ("tokens", _i), ("tok0", _i)]
+
+
 _SIGNATURES = {
     "mmdit_abi_version": ([], _i),
     "mmdit_struct_size": ([_i], _i),
@@ -71,6 +76,7 @@ _SIGNATURES = {
     "mmdit_gemm_grouped": ([ctypes.POINTER(GemmArgs), _i, _vp], _i),
     "mmdit_gemm_plan": ([ctypes.POINTER(GemmArgs), _i], _i),
     "mmdit_gemm_set_workspace": ([_vp, ctypes.c_longlong], _i),
+    "mmdit_gemm_qkv_norm_rope": ([ctypes.POINTER(GemmArgs), ctypes.POINTER(QkEpilogue), _i, _i, _i, _vp, _vp, _vp, _vp], _i),
     "mmdit_gemm_zero_mask": ([ctypes.POINTER(GemmArgs), _i, ctypes.POINTER(ctypes.c_uint)], _i),
     "mmdit_fp8_amax": ([_vp, _i, _i64, _vp, _vp], _i),
     "mmdit_fp8_quantize": ([_vp, _i, _i64, _vp, _vp, _vp, _vp], _i),
@@ -122,10 +128,10 @@ _SIGNATURES = {
     "mmdit_cast_multi": ([_vp, _vp, _vp, _i, _vp], _i),
 }
 ADAMW_CHUNK = 65536   # MMDIT_ADAMW_CHUNK
-ABI_VERSION = 4       # MMDIT_ABI_VERSION of include/mmdit_hip.h this binding mirrors
+ABI_VERSION = 5       # MMDIT_ABI_VERSION of include/mmdit_hip.h this binding mirrors
 # struct ids of mmdit_struct_size() -> ctypes mirrors (None: laid out with numpy record dtypes in optim.py / ops.py: 48 / 24 bytes)
 _STRUCTS = [("mmdit_gemm_args", GemmArgs), ("mmdit_ln_fwd_problem", LnFwdProblem), ("mmdit_ln_bwd_problem", LnBwdProblem),
-            ("mmdit_qk_problem", QkProblem), ("mmdit_mlp_bwd_problem", MlpBwdProblem), ("mmdit_adamw_tensor", None), ("mmdit_cast_tensor", None)]
+            ("mmdit_qk_problem", QkProblem), ("mmdit_mlp_bwd_problem", MlpBwdProblem), ("mmdit_adamw_tensor", None), ("mmdit_cast_tensor", None), ("mmdit_qk_epilogue", QkEpilogue)]
 
 _lib = None
 
@@ -166,6 +172,9 @@ def lib():
                 raise RuntimeError(f"{LIB_PATH}: sizeof({name}) = {L.mmdit_struct_size(which)}, the binding's ctypes mirror has {ctypes.sizeof(struct)} bytes")
         _lib = L
     return _lib
+
+
+ERR_ARG, ERR_DTYPE, ERR_SHAPE = -1, -2, -3      # MMDIT_ERR_* of include/mmdit_hip.h
 
 
 def check(status: int, what: str):

@@ -284,7 +284,14 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
 
 static inline int split_k_of(const mmdit_gemm_args* a) { return a->split_k > 1 ? a->split_k : 1; }
 
-static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only, unsigned* zero_mask = nullptr) {
+// QKV epilogue request of mmdit_gemm_qkv_norm_rope (nullptr: a plain launch)
+struct QkRequest {
+  const mmdit_qk_epilogue* qk;
+  int heads, s_total;
+  void* Q; void* K; void* V;
+};
+
+static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only, unsigned* zero_mask = nullptr, const QkRequest* qkr = nullptr) {
   MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
   const mmdit_gemm_args* a0 = &args[0];
   GroupParams gp;
@@ -479,6 +486,20 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   // ... whose split tail goes through the registered workspace (mmdit_gemm_set_workspace) instead of fp32 atomics when it is large enough:
   // 4 KiB of tickets + one 256x256 fp32 slot per (tail tile, K slice)
   gp.ws_slots = nullptr; gp.ws_count = nullptr;
+  gp.qk_on = 0; gp.qkQ = gp.qkK = gp.qkV = nullptr; gp.qk_heads = 0; gp.qk_s_total = 0;
+  if (qkr) {
+    // the fused QKV epilogue exists in the wide-slot lean kernel only, for one or two streams in the caller's order, [q | k | v] columns
+    if (!lean || count > 2 || a0->act != MMDIT_ACT_NONE || a0->b_kmajor) return MMDIT_ERR_SHAPE;
+    for (int i = 0; i < count; i++) {
+      if (order[i] != i || args[i].bias || args[i].N != 3 * qkr->heads * 64 || qkr->qk[i].tokens <= 0 || args[i].M % qkr->qk[i].tokens) return MMDIT_ERR_SHAPE;
+      gp.qk[i].wq = qkr->qk[i].wq; gp.qk[i].wk = qkr->qk[i].wk;
+      gp.qk[i].rcos = qkr->qk[i].rope_cos; gp.qk[i].rsin = qkr->qk[i].rope_sin;
+      gp.qk[i].tokens = qkr->qk[i].tokens; gp.qk[i].tok0 = qkr->qk[i].tok0;
+    }
+    if (count == 1) gp.qk[1] = gp.qk[0];
+    gp.qk_on = 1; gp.qk_heads = qkr->heads; gp.qk_s_total = qkr->s_total;
+    gp.qkQ = (bf16_t*)qkr->Q; gp.qkK = (bf16_t*)qkr->K; gp.qkV = (bf16_t*)qkr->V;
+  }
   if (kk && g_ws && gp.split_k > 1) {
     const long long tail_tiles = tiles - full_tiles;
     if (tail_tiles <= 1024 && 4096 + tail_tiles * gp.split_k * 65536LL * 4 <= g_ws_bytes) {
@@ -508,6 +529,17 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
 }
 
 extern "C" int mmdit_gemm_grouped(const mmdit_gemm_args* args, int count, mmdit_stream_t stream) { return gemm_grouped_impl(args, count, stream, false); }
+
+extern "C" int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogue* qk, int count, int heads, int s_total,
+                                        void* Q, void* K, void* V, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(args && qk && count >= 1 && count <= 2 && heads > 0 && s_total > 0 && Q && K && V);
+  for (int i = 0; i < count; i++) {
+    MMDIT_CHECK_ARG(qk[i].wq && qk[i].wk && qk[i].tokens > 0 && qk[i].tok0 >= 0 && qk[i].tok0 + qk[i].tokens <= s_total);
+    MMDIT_CHECK_ARG((qk[i].rope_cos == nullptr) == (qk[i].rope_sin == nullptr));
+  }
+  const QkRequest r{qk, heads, s_total, Q, K, V};
+  return gemm_grouped_impl(args, count, stream, false, nullptr, &r);
+}
 
 extern "C" int mmdit_gemm_set_workspace(void* ptr, long long bytes) {
   MMDIT_CHECK_ARG((ptr == nullptr && bytes == 0) || (ptr != nullptr && bytes >= 4096 + 65536 * 4 && ((uintptr_t)ptr & 15) == 0));

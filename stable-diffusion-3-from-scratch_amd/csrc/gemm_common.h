@@ -22,6 +22,12 @@ struct Problem {
   const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (device scalars), C = sa*sb*(A_q B_q^T); MX mode: E8M0 bytes (mx_scale_index)
   unsigned char* c_scales;                      // SwiGLU epilogue with an MX e4m3 output: E8M0 scales of C (C then holds e4m3 codes)
 };
+// QKV projection with the per-head QK RMSNorm + axial RoPE + joint-layout store in its epilogue (gemm_lean.hip, mmdit_gemm_qkv_norm_rope)
+struct QkEpi {
+  const float* wq; const float* wk;          // (64) norm weights of this stream
+  const float* rcos; const float* rsin;      // (tokens, 64) RoPE factors, nullptr: no rotation (text stream)
+  int tokens, tok0;                          // row = b * tokens + n;  joint position = tok0 + n
+};
 struct GroupParams {
   Problem p[MAXG];
   int count, total_tiles, act, accumulate, split_k, raster, debug, epi_direct;
@@ -37,6 +43,11 @@ struct GroupParams {
   // sums the slots in slice order and writes C (deterministic; C needs no zero-fill).  nullptr: atomics.
   float* ws_slots;
   int* ws_count;
+  // QKV epilogue (qk_on): problems 0 / 1 = image / text stream, C = the raw projection [q | k | v] as always, plus Q / K / V (batch, heads,
+  // s_total, 64) bf16 written from the rounded raw values (Attention.py:130-135, 178-194, 258-261)
+  QkEpi qk[2];
+  bf16_t* qkQ; bf16_t* qkK; bf16_t* qkV;
+  int qk_on, qk_heads, qk_s_total;
 };
 
 // block id -> (problem, m-tile, n-tile, split-K slice).

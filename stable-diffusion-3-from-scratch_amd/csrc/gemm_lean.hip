@@ -227,9 +227,10 @@ int launch_lean(const GroupParams& gp, hipStream_t s) {
 // two 32-row half images of the kernel above back to back.  The DMA cursor runs ONE slot ahead (its pieces are issued between the
 // first MFMA rows of the slot being multiplied), fragments are pipelined inside a slot only.
 // ------------------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false>
+template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false, bool QK = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GroupParams gp) {
   static_assert(!SWIGLU || (!B_KM && WN == 4 && NJ == 2), "SwiGLU epilogue: row-major packed weight, 256-column tile");
+  static_assert(!QK || (!B_KM && !SWIGLU && NJ == 2), "QKV epilogue: row-major weight, one head per wave");
   constexpr int TBM = WM * MI * 32, TBN = WN * NJ * 32, NW = WM * WN;
   constexpr int HA = TBM * 128, HB = TBN * 128, H = HA + HB;        // bytes of one slot (64-wide K step)
   constexpr int PA = TBM / 8 / NW, PB = TBN / 8 / NW, PPS = PA + PB; // 1-KiB DMA pieces per wave and slot
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GroupParams gp)
   auto run_epilogue = [&](const TileRef& t) {
     char* stage = smem + (cbuf ^ 1) * H + wave * EP32_WAVE_BYTES;   // the idle buffer: free until the next issue
     if constexpr (SWIGLU) epilogue_swiglu<MI, false>(acc, gp.p[t.pi], t.tm * TBM, t.tn, wm, wn, lane, stage, 1.f);
+    else if constexpr (QK) epilogue_bf16_qk<MI, NJ>(acc, gp.p[t.pi], gp, gp.qk[t.pi & 1], t.tm * TBM, t.tn * TBN, wm, wn, lane, stage);
     else epilogue_bf16<MI, NJ>(acc, gp.p[t.pi], gp, t.tm * TBM, t.tn * TBN, wm, wn, lane, stage);
   };
   auto ldB = [&](const char* tb, int j, int ks) -> bf16x8 {
@@ -389,10 +391,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GroupParams gp)
   if (pending) run_epilogue(prev);
 }
 
-template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false>
+template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false, bool QK = false>
 int launch_wide(const GroupParams& gp, hipStream_t s) {
   constexpr int smem = 2 * (WM * MI * 32 + WN * NJ * 32) * 128;
-  auto k = gemm_wide_kernel<WM, WN, MI, NJ, B_KM, SWIGLU>;
+  auto k = gemm_wide_kernel<WM, WN, MI, NJ, B_KM, SWIGLU, QK>;
   static bool attr_done = false;  // idempotent; a benign race only repeats the call
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -736,6 +738,12 @@ int gemm::launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t
   // Measured on the MMDiT-B shapes (tools/gemm_bench.py): out-proj 37.6 -> 34.7 us, w3 113 -> 106 / 123 -> 117 us, qkv 117.5 -> 114 us,
   // w12 dgrad 228 -> 222 us, 8192^3 1218 -> 1247 TF; the step 31.36 -> 31.19 ms.
   static const char* wide_env = getenv("MMDIT_GEMM_WIDE");
+  if (gp.qk_on) {   // QKV projection with the QK-norm + RoPE + joint-layout store in the epilogue: wide-slot kernel only
+    if (b_km || gp.act != MMDIT_ACT_NONE || (wide_env && !atoi(wide_env))) return MMDIT_ERR_SHAPE;
+    if (cfg == CFG_320x256) return launch_wide<2, 4, 5, 2, false, false, true>(gp, s);
+    if (cfg == CFG_256x256) return launch_wide<2, 4, 4, 2, false, false, true>(gp, s);
+    return MMDIT_ERR_SHAPE;
+  }
   if (!wide_env || atoi(wide_env)) {
     if (gp.act == MMDIT_ACT_SWIGLU) {
       if (b_km) return MMDIT_ERR_ARG;

@@ -259,6 +259,83 @@ __device__ __forceinline__ void epilogue_bf16(f32x16 (&acc)[MI][NJ], const Probl
   }
 }
 
+// QKV projection: epilogue_bf16 (no bias / activation) that ALSO writes the attention operands.  A wave's 64 columns are exactly one head of
+// one part (q / k / v) -- the row layout of the read-back side (8 lanes x 8 features per row) is the thread layout of the stand-alone
+// mmdit_qk_norm_rope_fwd kernel, and the arithmetic below is that kernel's, applied to the ROUNDED raw values: same results, no second
+// pass over the 2 x 115 MiB of a block's raw projection.
+template <int MI, int NJ>
+__device__ __forceinline__ void epilogue_bf16_qk(f32x16 (&acc)[MI][NJ], const Problem& p, const GroupParams& gp, const QkEpi& e, int m0, int n0, int wm, int wn,
+                                                 int lane, char* stage) {
+  static_assert(NJ == 2, "wave sub-tile must be 64 columns wide");
+  bf16_t* C = (bf16_t*)p.C;
+  const int wr = lane & 31, wc = lane >> 5;
+  const int rr = lane >> 3, rc = lane & 7;
+  const int colw = n0 + wn * 64;                     // first column of this wave: a multiple of 64
+  const int D = gp.qk_heads * 64, part = colw / D, head = (colw - part * D) >> 6;
+  const bool live = colw < p.N;                      // (wave-uniform)
+  float w8[8], c8[8], s8[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) w8[q] = 0.f;
+  if (live && part < 2) ld8((part == 0 ? e.wq : e.wk) + rc * 8, w8);
+  bf16_t* obase = part == 0 ? gp.qkQ : part == 1 ? gp.qkK : gp.qkV;
+#pragma unroll
+  for (int i = 0; i < MI; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const u32x2 pk = {pack_bf2(acc[i][j][g * 4], acc[i][j][g * 4 + 1]), pack_bf2(acc[i][j][g * 4 + 2], acc[i][j][g * 4 + 3])};
+        *LDS_PTR(u32x2, stage + wr * 128 + (((j * 4 + g) ^ (wr & 7)) << 4) + wc * 8) = pk;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+    const int col = colw + rc * 8;
+    // (sample, token) of the block's first row by ONE wave-uniform division; its 32 rows are consecutive and a sample has more than 32
+    // tokens or the rows wrap more than once -- the per-row division then
+    const int rowb = m0 + wm * (MI * 32) + i * 32;
+    const int b0 = __builtin_amdgcn_readfirstlane(rowb / e.tokens), n0r = rowb - b0 * e.tokens;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+      const int row = rowb + r;
+      if (!live || row >= p.M) continue;             // (the 8 lanes of a row agree)
+      int b = b0, n = n0r + r;
+      if (e.tokens >= 32) { if (n >= e.tokens) { n -= e.tokens; b++; } }
+      else { b = row / e.tokens; n = row - b * e.tokens; }
+      bf16_t* dst = obase + (((int64_t)b * gp.qk_heads + head) * gp.qk_s_total + e.tok0 + n) * 64 + rc * 8;
+      if (part == 2) {       // v: the attention operand IS the raw projection -- one store (backward never reads the v columns of C)
+        *(u32x4*)dst = t;
+        continue;
+      }
+      *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { x[2 * q] = __builtin_bit_cast(float, t[q] << 16); x[2 * q + 1] = __builtin_bit_cast(float, t[q] & 0xffff0000u); }
+      if (e.rcos) {      // (requesting the factors one pass ahead measured no gain: the epilogue is store-bound)
+        ld8(e.rcos + (int64_t)n * 64 + rc * 8, c8);
+        ld8(e.rsin + (int64_t)n * 64 + rc * 8, s8);
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; q++) ss += x[q] * x[q];
+      ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+      const float rinv = rsqrtf(ss * (1.f / 64.f) + 1.1920929e-07f);     // nn.RMSNorm(eps=None) on fp32 input: finfo(float32).eps
+#pragma unroll
+      for (int q = 0; q < 8; q++) x[q] = x[q] * rinv * w8[q];
+      if (e.rcos) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float a = x[2 * q], bb = x[2 * q + 1];
+          x[2 * q] = a * c8[2 * q] - bb * s8[2 * q];
+          x[2 * q + 1] = bb * c8[2 * q + 1] + a * s8[2 * q + 1];
+        }
+      }
+      st8(dst, x);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+}
+
 // ---- SwiGLU-fused w12 GEMM (MMDIT_ACT_SWIGLU): B = packed [2h, K] weight (gate rows 0..h-1, up rows h..2h-1) -----------------
 // A 256-column tile covers hidden indices [128 tn, 128 tn + 128): tile-local B row r = 64 wn + 32 j + c is the gate (j = 0)
 // or up (j = 1) row of hidden index 128 tn + 32 wn + c, so every lane holds g and u of the same (row, hidden index) in

@@ -953,6 +953,7 @@ extern "C" int mmdit_struct_size(int which) {
     case 4: return (int)sizeof(mmdit_mlp_bwd_problem);
     case 5: return (int)sizeof(mmdit_adamw_tensor);
     case 6: return (int)sizeof(mmdit_cast_tensor);
+    case 7: return (int)sizeof(mmdit_qk_epilogue);
     default: return -1;
   }
 }

@@ -346,10 +346,21 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
            and w.mlp_x.hidden % 128 == 0 and (w.last or (not w.mlp_c.gelu and w.mlp_c.hidden % 128 == 0)) and _MX_FUSE)
 
     (sv.X, sv.ln1x, sv.mu1x, sv.rs1x), (sv.C, sv.ln1c, sv.mu1c, sv.rs1c) = _norm_pair(m, (X, ms.scale1x, ms.shift1x, N), (C, ms.scale1c, ms.shift1c, Mt), mx=mxf)
-    sv.qkv_x, sv.qkv_c = _group(m, [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T)], fp8=True)
     sv.Q = torch.empty((B, H, S, 64), dtype=BF16, device=dev)
     sv.K, sv.V = torch.empty_like(sv.Q), torch.empty_like(sv.Q)
-    if _LN_PAIR and dev.type == "cuda":      # image + text rows in one launch
+    fused = None
+    if _QKV_FUSE and m.fast and dev.type == "cuda" and m.T == BF16 and not m.fp8 and d == H * 64:
+        # QK-norm + RoPE + joint-layout store in the QKV GEMM's epilogue (one launch, no second pass over the raw projection); None: the
+        # planner would not give these problems to the lean wide-slot kernel
+        fused = ops.gemm_qkv_norm_rope([dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T, precision=m.prec), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T, precision=m.prec)],
+                                       [(w.wq_x, w.wk_x, rope[0], rope[1], N, 0), (w.wq_c, w.wk_c, None, None, Mt, N)], H, S, sv.Q, sv.K, sv.V)
+    if fused is not None:
+        sv.qkv_x, sv.qkv_c = fused
+    else:
+        sv.qkv_x, sv.qkv_c = _group(m, [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T)], fp8=True)
+    if fused is not None:
+        pass
+    elif _LN_PAIR and dev.type == "cuda":      # image + text rows in one launch
         ops.qk_norm_rope_fwd_pair((sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], N, 0), (sv.qkv_c, w.wq_c, w.wk_c, None, None, Mt, N), B, H, S, sv.Q, sv.K, sv.V)
     else:
         ops.qk_norm_rope_fwd(sv.qkv_x, w.wq_x, w.wk_x, rope[0], rope[1], B, N, H, S, 0, sv.Q, sv.K, sv.V)
@@ -423,6 +434,7 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
 _LN_PAIR = _os.environ.get("MMDIT_LN_PAIR", "1") != "0"      # image + text rows of the adaLN / QK-norm+RoPE / MLP-activation-backward kernels in one launch (A/B switch)
 _MX_FUSE = _os.environ.get("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
 _BATCH_WMOD = _os.environ.get("MMDIT_BATCH_WMOD", "1") != "0"   # single-rank backward: the modulation-matrix weight gradients of all blocks in one grouped launch (A/B switch)
+_QKV_FUSE = _os.environ.get("MMDIT_QKV_FUSE", "1") != "0"        # QK-norm + RoPE + joint-layout store inside the QKV GEMM epilogue (A/B switch)
 _QK_FUSE = _os.environ.get("MMDIT_ATTN_QK_FUSE", "1") != "0"     # QK-norm + RoPE backward inside the attention backward kernels (A/B switch)
 _FUSE_GATE = _os.environ.get("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
 

@@ -229,6 +229,31 @@ def gemm_grouped(problems):
     return outs
 
 
+def gemm_qkv_norm_rope(problems, streams, heads, s_total, Q, K, V):
+    """The QKV projection with QK-RMSNorm + RoPE + joint-layout store in the GEMM epilogue (mmdit_gemm_qkv_norm_rope): one launch.
+    problems: 1 or 2 dicts of gemm() arguments (A = normed stream rows, B = packed [q | k | v] weight, out_dtype bf16; image stream first);
+    streams[i] = (wq, wk, rope_cos | None, rope_sin | None, tokens per sample, joint position of token 0).  Returns the raw projections
+    (kept for backward: q and k columns; the v columns are not written, V holds them) or None when the planner would not run these problems on the lean wide-slot kernel (caller: GEMM + row kernel)."""
+    n = len(problems)
+    arr = (GemmArgs * n)()
+    outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
+    qk = (_lib.QkEpilogue * n)()
+    for i, (wq, wk, rc, rs, tokens, tok0) in enumerate(streams):
+        qk[i].wq, qk[i].wk, qk[i].rope_cos, qk[i].rope_sin, qk[i].tokens, qk[i].tok0 = _p(wq), _p(wk), _p(rc), _p(rs), int(tokens), int(tok0)
+    L = _lib.lib()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = L.mmdit_gemm_qkv_norm_rope(arr, qk, n, int(heads), int(s_total), _p(Q), _p(K), _p(V), _s())
+    if rc == _lib.ERR_SHAPE:
+        return None
+    check(rc, "mmdit_gemm_qkv_norm_rope")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((_variant(arr, n, outs) + "+qk", sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
+    return outs
+
+
 def gemm(A, B, **kw):
     """C[M,N] = epilogue(A[M,K] B[N,K]^T).  A: (M,K) or k-major (K,M); B: (N,K) or k-major (K,N).
     gate may be a strided 2-D view (rows = batch) with unit inner stride."""

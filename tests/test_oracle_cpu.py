@@ -196,7 +196,7 @@ def test_library_exports_every_declared_symbol():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert _lib.lib().mmdit_abi_version() == _lib.ABI_VERSION == 4 and _lib.lib().mmdit_struct_size(0) == ctypes.sizeof(_lib.GemmArgs) and _lib.lib().mmdit_build_arch() == b"gfx950"
+    assert _lib.lib().mmdit_abi_version() == _lib.ABI_VERSION == 5 and _lib.lib().mmdit_struct_size(0) == ctypes.sizeof(_lib.GemmArgs) and _lib.lib().mmdit_build_arch() == b"gfx950"
 
 
 def test_product_path_fails_loudly_without_gpu():
