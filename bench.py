@@ -48,7 +48,10 @@ def pmc_traffic(kernel):
         # the profiler prints every template argument: <..., FP8, SWIGLU> follow the ones ops._variant names
         sw = "+swiglu" in kernel
         lean = name.startswith(("gemm_lean_kernel", "gemm_wide_kernel"))   # <..., B_KM, SWIGLU>; the general kernel: <..., FP8, SWIGLU>
-        for key in (name[:-1] + ((",1>" if sw else ",0>") if lean else (",0,1>" if sw else ",0,0>")), name, name.split("<")[0]):
+        qk = "+qk" in kernel
+        cands = [name[:-1] + ((",1,0>" if sw else ",0,1>" if qk else ",0,0>") if lean else (",0,1>" if sw else ",0,0>")),
+                 name[:-1] + ((",1>" if sw else ",0>") if lean else ""), name, name.split("<")[0]]
+        for key in cands:
             if key in d:
                 return d[key]["hbm_bytes_per_launch"], d[key]["mfma_util"], os.path.relpath(f, ROOT)
     return None, None, None
