@@ -1069,8 +1069,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __re
 // ------------------------------------------------------------------------------------------------
 // backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
 // ------------------------------------------------------------------------------------------------
+#ifndef MMDIT_DQ_WAVES
+#define MMDIT_DQ_WAVES 4
+#endif
 template <int NW, typename TG, bool FUSE = false>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+__global__ __launch_bounds__(NW * 64, NW == 8 ? MMDIT_DQ_WAVES : 1) void attn_bwd_dq_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                                const bf16_t* __restrict__ Ox, const bf16_t* __restrict__ Oc,
                                                                const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
                                                                const float* __restrict__ lse, float* __restrict__ delta,
@@ -1079,12 +1082,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_bwd_dq_kernel(c
   // query) and written out for the dK/dV kernel that follows on the same stream -- no separate preparation pass.
   constexpr int NT = NW * 64;
   // (fused epilogue: dynamic LDS of qk_lds_bytes<NW>() > 64 KB, whose head is the K / V tile pair of the main loop)
-  __shared__ __attribute__((aligned(16))) char smem_static[FUSE ? 16 : 2 * KT * 128];
+  // NW == 8: the K / V tiles arrive through a DQ_ST-stage LDS-DMA ring (global_load_lds, no staging registers, two tiles in flight behind
+  // the one being multiplied) -- the register-staged copy of the other widths pays a tile's round trip between two barriers every tile.
+  constexpr bool DMA = NW == 8;
+  constexpr int DQ_ST = 3;
+  __shared__ __attribute__((aligned(16))) char smem_static[FUSE ? 16 : (DMA ? DQ_ST : 1) * 2 * KT * 128];
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   char* smem = FUSE ? smem_dyn : smem_static;
   char* ktile = smem;
   char* vtile = smem + KT * 128;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   MMDIT_YOUNG_HALF_PRIO();
   int qtile, bh;
   map_block((S + 32 * NW - 1) / (32 * NW), BH, qtile, bh);
@@ -1129,14 +1136,38 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_bwd_dq_kernel(c
     for (int r = 0; r < 16; r++) acc[db][r] = 0.f;
 
   const int nkv = (S + KT - 1) / KT;
-  u32x4 sk[tile_chunks<NT>()], sv[tile_chunks<NT>()];
+  u32x4 sk[DMA ? 1 : tile_chunks<NT>()], sv[DMA ? 1 : tile_chunks<NT>()];
+  // DMA: this lane's 16 bytes of a tile -- key row 8 * wave + (lane >> 3), LDS slot lane & 7 holds chunk slot ^ sw2(row) (the layout
+  // tile_r2s_sw writes and row_frag_d / tr_frag_d read); rows past the end re-read the last key (masked below in the ragged tile)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const int rl = 8 * wave + (lane >> 3), dcol = ((lane & 7) ^ sw2(rl)) * 8;
+  auto issue = [&](int j, int stage) {     // wave-uniform bases (SGPR pairs) + one 32-bit lane offset: the kernel sits at its 128-VGPR cap
+    const uint32_t voff = (uint32_t)min(min(j, nkv - 1) * KT + rl, S - 1) * (HD * 2) + dcol * 2;
+    attn_glds16s(voff, (const char*)Kb, lds0 + stage * (2 * KT * 128) + wave * 1024);
+    attn_glds16s(voff, (const char*)Vb, lds0 + stage * (2 * KT * 128) + KT * 128 + wave * 1024);
+  };
+  int stage = 0;
+  if constexpr (DMA) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the Q / dO / O / lse loads above: from here on only DMA pieces are counted)
+#pragma unroll
+    for (int st = 0; st < DQ_ST - 1; st++) issue(st, st);
+  }
   for (int j = 0; j < nkv; j++) {
-    tile_g2r<NT>(sk, Kb, j * KT, S, tid);
-    tile_g2r<NT>(sv, Vb, j * KT, S, tid);
-    __syncthreads();
-    tile_r2s_sw<NT>(sk, ktile, tid);
-    tile_r2s_sw<NT>(sv, vtile, tid);
-    __syncthreads();
+    if constexpr (DMA) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (DQ_ST - 2)) : "memory");   // tile j has landed (DQ_ST - 2 younger tiles may be in flight)
+      __builtin_amdgcn_s_barrier();                                             // ... for every wave; and everyone has left tile j - 1
+      issue(j + DQ_ST - 1, stage == 0 ? DQ_ST - 1 : stage - 1);                 // refill the stage of tile j - 1
+      ktile = smem + stage * (2 * KT * 128);
+      vtile = ktile + KT * 128;
+      stage = stage + 1 == DQ_ST ? 0 : stage + 1;
+    } else {
+      tile_g2r<NT>(sk, Kb, j * KT, S, tid);
+      tile_g2r<NT>(sv, Vb, j * KT, S, tid);
+      __syncthreads();
+      tile_r2s_sw<NT>(sk, ktile, tid);
+      tile_r2s_sw<NT>(sv, vtile, tid);
+      __syncthreads();
+    }
     if (!active) continue;
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
@@ -1175,6 +1206,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 4 : 1) void attn_bwd_dq_kernel(c
       }
     }
   }
+  if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is reused / released
   if constexpr (FUSE) {
     // dQ rows -> gradient of the raw q projection (RMSNorm + RoPE backward, qk_bwd_tile), norm-weight gradient partials of this workgroup
     __syncthreads();                       // every wave has left the last K/V tile: the LDS is free
