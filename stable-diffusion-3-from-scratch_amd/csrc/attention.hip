@@ -1085,7 +1085,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? MMDIT_DQ_WAVES : 1) void attn_bw
   // NW == 8: the K / V tiles arrive through a DQ_ST-stage LDS-DMA ring (global_load_lds, no staging registers, two tiles in flight behind
   // the one being multiplied) -- the register-staged copy of the other widths pays a tile's round trip between two barriers every tile.
   constexpr bool DMA = NW == 8;
-  constexpr int DQ_ST = 3;
+#ifndef MMDIT_DQ_STAGES
+#define MMDIT_DQ_STAGES 3
+#endif
+  constexpr int DQ_ST = MMDIT_DQ_STAGES;
   __shared__ __attribute__((aligned(16))) char smem_static[FUSE ? 16 : (DMA ? DQ_ST : 1) * 2 * KT * 128];
   extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
   char* smem = FUSE ? smem_dyn : smem_static;
