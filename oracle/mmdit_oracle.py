@@ -225,6 +225,27 @@ def attention_core(q, k, v, scale: float, mode: str):
         l = p.sum(dim=-1, keepdim=True)
         o = (_rb(p) @ vb) / l
         return _rb(o)
+    if mode == "flash_bf16_tiled":
+        # the same rounding points as "flash_bf16", placed as a TILED online softmax places them (csrc/attention.hip attn_fwd_dma_kernel:
+        # 64-key tiles; the running maximum of a query row moves tile by tile; p = exp2(s c - m_running) is rounded to bf16 for the P V
+        # product while the row sum adds the unrounded p; accumulator and sum are rescaled by exp2(m_old - m_new)).  Rounding p relative
+        # to the running instead of the final maximum is not the same rounding (exp(m_run - m_final) is no power of two), which is the
+        # whole difference to "flash_bf16": ~1e-3 of the output where the attention is peaked, nothing where it is diffuse.
+        qb, kb, vb = _rb(q), _rb(k), _rb(v)
+        c2 = scale * 1.4426950408889634
+        S = k.shape[-2]
+        m = torch.full(q.shape[:-1] + (1,), float("-inf"), dtype=q.dtype)
+        l = torch.zeros_like(m)
+        o = torch.zeros_like(q)
+        for j in range(0, S, 64):
+            sj = (qb @ kb[..., j:j + 64, :].mT) * c2
+            mn = torch.maximum(m, sj.amax(dim=-1, keepdim=True))
+            alpha = torch.exp2(m - mn)
+            p = torch.exp2(sj - mn)
+            l = l * alpha + p.sum(dim=-1, keepdim=True)
+            o = o * alpha + _rb(p) @ vb[..., j:j + 64, :]
+            m = mn
+        return _rb(o / l)
     raise ValueError(mode)
 
 

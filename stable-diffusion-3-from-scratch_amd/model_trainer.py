@@ -57,8 +57,24 @@ def init_distributed():
     if "RANK" not in os.environ:
         return
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # the flight recorder's per-group status (last enqueued / last completed collective) is what capture_graph() polls to know that
+    # the watchdog has retired every eager collective (_wait_for_watchdog); it only exists while the recorder is on
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
     backend = "nccl" if torch.cuda.is_available() else "gloo"
     dist.init_process_group(backend, init_method="env://", world_size=int(os.environ["WORLD_SIZE"]), rank=int(os.environ["RANK"]))
+
+
+def _watchdog_status():
+    """{process group id: (last collective enqueued to the watchdog, last one it retired)} from the flight recorder, or None when
+    the recorder is off / the build does not publish it (see model_trainer._wait_for_watchdog)."""
+    try:
+        from torch._C import _distributed_c10d as c10d
+        doc = json.loads(c10d._dump_nccl_trace_json(includeCollectives=False, onlyActive=True))
+        st = doc.get("pg_status") or {}
+        out = {k: (int(v["last_enqueued_collective"]), int(v["last_completed_collective"])) for k, v in st.items()}
+        return out or None
+    except Exception:
+        return None
 
 
 class SyntheticData:
@@ -189,6 +205,9 @@ class model_trainer:
         self.inf_padded_latents = bool(inf_padded_latents)
         self.last_loss = None
         self._graph, self._slots, self._loss_out, self._graph_loss = None, None, None, None
+        self._slots_primed = False   # the batches drawn at capture time are the inputs of the first replay (nothing drawn is dropped)
+        self.replayed_steps = 0      # optimizer steps served by the hipGraph so far
+        self.keep_losses, self.loss_history = False, []     # keep_losses: train() appends every step's loss (device scalars)
         self.last_grad_norm = None   # hip_optimizer: device scalar, the unscaled gradient norm of the last step
         if is_main_process():
             total_params = sum(p.numel() for p in self.model.parameters()) / 1e6
@@ -359,13 +378,7 @@ class model_trainer:
             self._slots = [tuple(x.to(self.device).clone() for x in self._draw()) for _ in range(self.accumulation_steps)]
         torch.cuda.synchronize(self.device)
         if self.reducer.enabled and self.device.type == "cuda":
-            # The process group's watchdog thread polls the completion events of the EAGER steps' collectives every 100 ms.  Those
-            # events were recorded on the communicator's internal stream, which joins this capture at the first captured collective;
-            # HIP then refuses hipEventQuery on them ("event last recorded in a capturing stream"), the watchdog thread throws and the
-            # process aborts -- an intermittent crash (seen once in three suite runs).  Everything is complete after the synchronize
-            # above: give the watchdog time to retire its work list before any stream starts capturing.
-            import time
-            time.sleep(0.5)
+            self._wait_for_watchdog()
         self.optim.sync_lr(self.device)
         self.optim.prepare_capture()
         # the loss leaves the graph through a persistent buffer written by a kernel of the graph (not through a tensor of the graph's
@@ -394,7 +407,41 @@ class model_trainer:
         self.optim.zero_grad()      # (host bookkeeping only: the graph owns the gradient buffers)
         self.optim.after_replay()   # (the capture itself executed nothing: the eager pointer table / copies bookkeeping is void)
         self._graph = g
+        self._slots_primed = self._slots is not None     # the capture executed nothing: the slots still hold an untrained-on draw
         return g
+
+    def _wait_for_watchdog(self, timeout_s=None):
+        """Block until RCCL's watchdog thread has retired every EAGER collective of this process.
+
+        Why: the watchdog polls the completion events of enqueued collectives (hipEventQuery) every 100 ms.  Those events were
+        recorded on the communicator's internal stream, which joins the capture at the first captured collective; HIP then refuses
+        the query ("event last recorded in a capturing stream"), the watchdog thread throws and the process aborts.  Collectives
+        issued DURING a capture are never handed to the watchdog, so the hazard is only the eager ones still on its list.
+        How: after the device synchronize every eager collective is complete, and the watchdog retires a completed one at its next
+        sweep; the flight recorder publishes, per process group, the sequence numbers of the last collective ENQUEUED to the watchdog
+        and the last one it COMPLETED (retired).  Poll until they are equal for every group (typically one or two sweeps).  If the
+        recorder is off (TORCH_FR_BUFFER_SIZE=0 set by the user) or the build does not expose the status, fall back to the
+        HEURISTIC of round 3 -- sleep MMDIT_CAPTURE_SETTLE_S seconds (default 0.5 = five sweeps) -- and say so once on stderr."""
+        import sys
+        import time
+        timeout_s = float(os.environ.get("MMDIT_CAPTURE_WATCHDOG_TIMEOUT_S", "10")) if timeout_s is None else timeout_s
+        status = _watchdog_status()
+        if status is None:
+            if not getattr(model_trainer, "_warned_settle", False):
+                model_trainer._warned_settle = True
+                print("[model_trainer] flight-recorder status unavailable: waiting a fixed MMDIT_CAPTURE_SETTLE_S before the capture (heuristic)", file=sys.stderr)
+            time.sleep(float(os.environ.get("MMDIT_CAPTURE_SETTLE_S", "0.5")))
+            return False
+        t0 = time.time()
+        while any(enq != done for enq, done in status.values()):
+            if time.time() - t0 > timeout_s:
+                # (ten seconds are a hundred sweeps: the counters do not mean what this code assumes on this build -- say so and go on,
+                #  the wait so far is already 20 x the fixed delay that was enough in round 3)
+                print(f"[model_trainer] watchdog status did not settle in {timeout_s} s ({status}); capturing anyway", file=sys.stderr)
+                return False
+            time.sleep(0.02)
+            status = _watchdog_status()
+        return True
 
     def graph_node_types(self):
         """Histogram of the captured step's node kinds {"kernel": n, "memcpy": n, "memset": n, ...} (needs keep_graph=True before
@@ -436,7 +483,9 @@ class model_trainer:
         torch.cuda.synchronize(self.device)
 
     def _replay(self, step):
-        if self._slots is not None:
+        if self._slots is not None and self._slots_primed:
+            self._slots_primed = False      # first replay: the slots already hold the batches drawn at capture time
+        elif self._slots is not None:
             inputs = [self._draw() for _ in range(self.accumulation_steps)]
             if any(tuple(a.shape) != tuple(b.shape) or a.dtype != b.dtype for slot, inp in zip(self._slots, inputs) for a, b in zip(slot, inp)):
                 return self._eager_step(step, inputs)     # another bucket shape: not the captured step
@@ -447,8 +496,9 @@ class model_trainer:
         self._graph.replay()
         self.optim.after_replay()
         self.scheduler.step(step)
-        self.last_loss = self._loss_out
-        return self._loss_out
+        self.replayed_steps += 1
+        self.last_loss = self._loss_out.clone()      # (a fresh tensor per step, as the eager step returns: callers may keep it)
+        return self.last_loss
 
     def update_ema(self):
         """ema = ema * decay + param * (1 - decay)  (model_trainer.py:537-541), on the GPU copy when there is one."""
@@ -503,6 +553,8 @@ class model_trainer:
             if self.graph_after is not None and self._graph is None and step - opt_steps == max(3, self.graph_after) and self.can_capture() is None:
                 self.capture_graph(step + 1)
             loss = self.train_step(step + 1)
+            if self.keep_losses:
+                self.loss_history.append(loss)
             n = step + 1
             batch_loss += float(loss) if n % self.log_steps == 0 else 0.0
             if n % self.log_steps == 0 and is_main_process():

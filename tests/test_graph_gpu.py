@@ -114,11 +114,9 @@ def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reduc
         net(x, torch.tensor([0.3, 0.7]), c, cp).sum().backward()      # (one eager pass refreshes the bf16 copies outside the capture)
         tr.optim.zero_grad()
         rng_set(snap_r)
-        if slots:                                   # the capture draws one batch per micro-step to size its input slots: give it back
-            tr.capture_graph(4)
-            rng_set(snap_r)
-        else:
-            tr.capture_graph(4)
+        # (static slots: the capture draws one batch per micro-step to fill its input slots; the first replay trains on exactly those,
+        #  so the data / RNG order of an eager-then-replayed run is the eager run's -- nothing drawn is dropped)
+        tr.capture_graph(4)
         assert tr._graph is not None
         l1, p1 = steps()
     finally:

@@ -448,6 +448,44 @@ def test_attention_fwd_bwd_at_mmdit_l_sequence_length(ops):
     print(f"[attention S=1178] fwd oracle-rounding mode {r1:.2e}, flash {r0:.2e}; bwd (dQ, dK, dV) {res[0]} / last block {res[1]}")
 
 
+def test_attention_fwd_bwd_at_the_1024px_stage_sequence_length(ops):
+    """S = 4250 (the reference's 1024^2 training stage, README.md:251-252 / src/train.py:47: 64 x 64 image tokens + 154 text tokens;
+    66 full 64-key tiles + a 26-key tail, seventeen 256-query workgroups with a 154-query tail), head count 19-odd-like (3 heads, batch
+    1): forward in both modes and backward against the CPU oracle's attention core, as at S = 1178 above; also the last block's
+    shape (no text output gradient).  The long sequence is where the online-softmax rescale branch and the running sums see the
+    most tiles."""
+    from oracle.mmdit_oracle import attention_core
+    Bt, H, N, Mt = 1, 3, 4096, 154
+    S = N + Mt
+    Q, K, V = [rnd(Bt, H, S, 64, seed=s) for s in (21, 22, 23)]
+    # a few keys that dominate late in the sequence force accumulator rescales deep into the tile loop (guide rule 26)
+    K[:, :, 4000:4003] *= 4.0
+    Qb, Kb, Vb = Q.to(torch.bfloat16), K.to(torch.bfloat16), V.to(torch.bfloat16)
+    merge = lambda o: o.permute(0, 2, 1, 3).reshape(Bt, S, H * 64)
+    Ox, Oc, _ = ops.attn_fwd(Qb, Kb, Vb, N, 0.125, 1)
+    ref1 = merge(attention_core(Q.cpu(), K.cpu(), V.cpu(), 0.125, "oracle_bf16"))
+    r1 = rel(torch.cat([Ox, Oc], 1).cpu(), ref1)
+    Ox, Oc, lse = ops.attn_fwd(Qb, Kb, Vb, N, 0.125, 0)
+    qr, kr, vr = [t.float().cpu().requires_grad_(True) for t in (Qb, Kb, Vb)]
+    ref0 = merge(attention_core(qr, kr, vr, 0.125, "fp32"))
+    r0 = rel(torch.cat([Ox, Oc], 1).cpu(), ref0.detach())
+    assert r1 < 3e-3 and r0 < 5e-3, (r1, r0)
+    assert (lse.cpu() - torch.logsumexp((qr.detach() @ kr.detach().mT) * 0.125, -1)).abs().max() < 2e-2
+    res = []
+    for last in (False, True):
+        dOx = rnd(Bt, N, H * 64, seed=24).to(torch.bfloat16)
+        dOc = None if last else rnd(Bt, Mt, H * 64, seed=25).to(torch.bfloat16)
+        dQ, dK, dV = ops.attn_bwd(Qb, Kb, Vb, Ox, Oc, dOx, dOc, lse, N, 0.125, torch.float32)
+        for t in (qr, kr, vr):
+            t.grad = None
+        dO = torch.cat([dOx.float().cpu(), torch.zeros(Bt, Mt, H * 64) if last else dOc.float().cpu()], 1)
+        ref0.backward(dO, retain_graph=True)
+        errs = (rel(dQ.cpu(), qr.grad), rel(dK.cpu(), kr.grad), rel(dV.cpu(), vr.grad))
+        res.append(errs)
+        assert max(errs) < 1.5e-2, (last, errs)
+    print(f"[attention S=4250] fwd oracle-rounding mode {r1:.2e}, flash {r0:.2e}; bwd (dQ, dK, dV) {res[0]} / last block {res[1]}")
+
+
 @pytest.mark.parametrize("Bt,H,h2,w2,Mt,last", [(2, 3, 8, 8, 30, False), (1, 2, 16, 16, 154, False), (2, 2, 16, 16, 154, True), (1, 2, 32, 32, 154, False)])
 def test_attention_bwd_with_fused_qk_norm_rope_backward(ops, Bt, H, h2, w2, Mt, last):
     """mmdit_attn_bwd_qk (attention backward whose epilogues run the RoPE + QK-RMSNorm backward on the fp32 accumulators and write

@@ -86,6 +86,9 @@ def test_forward_parity_mode_vs_reference_golden(case, golden_dir):
         import json
         floor = json.load(open(os.path.join(golden_dir, "noise_floor_b.json")))[case[0]]["ref8_vs_ref1"]
         assert r < max(1e-3, 1.1 * floor), (r, floor)
+        # north_star's number, kept as a hard bar next to the floor-relative one: this binary measures 9.8e-4 on b_plain
+        # (deterministic forward: the same figure on every box, it moves only when a forward kernel is recompiled)
+        assert r < 1e-3, r
     else:
         assert r < 1e-3
     # in-place null masking of the caller's tensors is part of the contract (diff_model.py:278-287)

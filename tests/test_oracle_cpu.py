@@ -13,7 +13,8 @@ import torch
 from oracle import mmdit_oracle as O
 from oracle.weights import make_inputs, make_state_dict, state_dict_spec
 
-CONFIGS = {"micro": dict(dim=128, num_heads=2, num_blocks=3), "xs": dict(dim=256, num_heads=4, num_blocks=2), "b": dict(dim=768, num_heads=12, num_blocks=12)}
+CONFIGS = {"micro": dict(dim=128, num_heads=2, num_blocks=3), "xs": dict(dim=256, num_heads=4, num_blocks=2), "b": dict(dim=768, num_heads=12, num_blocks=12),
+           "trained": dict(dim=1216, num_heads=19, num_blocks=19)}
 CASES = [
     ("micro_plain", "micro", 16, 16, 0, [0.3, 0.7], 1.0, None),
     ("micro_nulls", "micro", 16, 16, 1, [0.02, 0.98], 30.0, ([1, 0], [0, 1], [1, 1])),
@@ -54,6 +55,34 @@ def test_oracle_forward_matches_reference_golden(case, golden_dir):
         for k_or, k_gold in [("y_proj", "tap_y_proj"), ("norm1_x", "tap_norm1_x"), ("norm1_c", "tap_norm1_c"), ("attn_x", "tap_attn_x"),
                              ("attn_c", "tap_attn_c"), ("mlp_x", "tap_mlp_x")]:
             assert rel(b0[k_or], torch.from_numpy(gold[k_gold])) < 1e-6, k_or
+
+
+@pytest.mark.parametrize("case,h,w,seed,tvals,nulls", [("trained_sq", 32, 32, 70, [0.25, 0.8], ([0, 1], [0, 0], [1, 0])), ("trained_nonsq", 24, 40, 71, [0.6, 0.05], None)])
+def test_oracle_at_the_trained_width_matches_reference_golden(case, h, w, seed, tvals, nulls, golden_dir):
+    """The reference's own trained width and head count (src/train.py:35-41: dim 1216 = 64 x 19, 19 heads; 3 blocks deep) -- output and
+    the 8 token rows of every block's image / text output that the fixture keeps (tools/make_goldens_trained.py, real reference);
+    the tiled flash restatement (the HIP kernel's summation schedule) stays within bf16 distance of the untiled one."""
+    cfg = dict(dim=1216, num_heads=19, num_blocks=3)
+    gold = np.load(os.path.join(golden_dir, f"forward_{case}.npz"))
+    x, c, cp = make_inputs(seed, 2, h, w, text_scale=30.0)
+    assert np.allclose(gold["inputs_checksum"], checksum(x, c, cp), rtol=1e-9)
+    nl = [None] * 3 if nulls is None else [torch.tensor(n).bool() for n in nulls]
+    sd = make_state_dict(0, **cfg)
+    taps = {}
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        v = O.forward(sd, O.OracleConfig(**cfg), x, torch.tensor(tvals), c, cp, *nl, taps=taps)
+    assert rel(v, torch.from_numpy(gold["v"])) < 1e-5
+    assert np.allclose(gold["c_after"], checksum(c, cp), rtol=1e-9)
+    for bi, (X, C) in enumerate(taps["blocks"]):
+        for nm, val in (("X", X), ("c", C)):
+            k = f"block{bi}_{nm}"
+            assert rel(val[:, torch.from_numpy(gold["taprows_" + k])], torch.from_numpy(gold["tap_" + k])) < 1e-5, k
+            assert np.allclose(gold["tapsum_" + k], checksum(val), rtol=1e-5), k
+    q, k_, v_ = [torch.randn((1, 2, 300, 64), generator=torch.Generator().manual_seed(s)) for s in (1, 2, 3)]
+    a, b = O.attention_core(q, k_, v_, 0.125, "flash_bf16_tiled"), O.attention_core(q, k_, v_, 0.125, "flash_bf16")
+    ex = O.attention_core(q, k_, v_, 0.125, "fp32")
+    assert rel(a, b) < 3e-3 and rel(a, ex) < 4e-3 and rel(b, ex) < 4e-3
 
 
 def test_oracle_b_depth_golden(golden_dir):
@@ -211,14 +240,14 @@ def test_product_path_fails_loudly_without_gpu():
             net(torch.zeros(1, 16, 4, 4), torch.tensor([0.5]), torch.zeros(1, 154, 2304), torch.zeros(1, 768))
 
 
-@pytest.mark.parametrize("name,mt", [("micro", "swiglu"), ("micro", "gelu"), ("xs", "swiglu"), ("b", "swiglu")])
+@pytest.mark.parametrize("name,mt", [("micro", "swiglu"), ("micro", "gelu"), ("xs", "swiglu"), ("b", "swiglu"), ("trained", "swiglu")])
 def test_state_dict_layout_matches_reference(name, mt, golden_dir):
     import sd3_amd  # noqa: F401
     from sd3_amd.models.diff_model import diff_model
     spec = json.load(open(os.path.join(golden_dir, f"state_dict_spec_{name}_{mt}.json")))
     assert [[k, list(s)] for k, s in state_dict_spec(MLP_type=mt, **CONFIGS[name])] == [[k, s] for k, s, _ in spec["state_dict"]]
-    if name == "b":
-        return  # 315 M parameters: the spec check above is enough on CPU
+    if name in ("b", "trained"):
+        return  # 315 M / 1.25 G parameters: the spec check above is enough on CPU (the GPU suite builds the trained model)
     net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type=mt, device="cpu",
                      positional_encoding="RoPE2d", **CONFIGS[name])
     sd = net.state_dict()
