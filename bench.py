@@ -220,23 +220,11 @@ def main():
                 trainer.train_step(step)
             sync()
             eager_ms = (time.perf_counter() - t0) / n_eager * 1e3
-        try:
-            trainer.capture_graph(step + 1)
+        # the launch mode is a collective decision (model_trainer.capture_graph_agreed): every rank tries the capture, the ranks agree
+        # (MIN over "my capture succeeded") before anything else is enqueued, a failure anywhere means eager launches everywhere --
+        # the measurement is never lost to the capture.  --graph makes this rank's own capture error fatal (after the agreement).
+        if trainer.capture_graph_agreed(step + 1, strict=args.graph):
             launch = "hipGraph replay"
-        except Exception as e:       # never lose the measurement to the capture (capture_graph has put the host state back): eager launches
-            if args.graph:
-                raise
-            print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr, flush=True)
-        if world > 1:
-            # the launch mode is a collective decision: a rank whose capture failed while the others replay would still issue the same
-            # collectives per step, but the ranks must agree before anything else is enqueued (MIN over "my capture succeeded")
-            ok = torch.tensor([1 if trainer._graph is not None else 0], device=dev, dtype=torch.int32)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok) == 0 and trainer._graph is not None:
-                trainer._graph = None
-                launch = "eager"
-                if rank == 0:
-                    print("bench: hipGraph capture failed on another rank; every rank times eager launches", file=sys.stderr, flush=True)
         for _ in range(2):              # (the first replays also warm the graph's own memory; eager fallback: the same step count on every rank)
             step += 1
             trainer.train_step(step)

@@ -410,6 +410,38 @@ class model_trainer:
         self._slots_primed = self._slots is not None     # the capture executed nothing: the slots still hold an untrained-on draw
         return g
 
+    def capture_graph_agreed(self, step, strict=False):
+        """capture_graph() as a COLLECTIVE decision: every rank tries, then the ranks agree (all-reduce MIN over "my capture
+        succeeded") before anything else is enqueued; if any rank failed, every rank drops its graph and goes on issuing eager steps --
+        a rank that replays while another launches from the host would still run the same collectives per step, but mixed modes are
+        not a state anybody has tested, and a rank that RAISES while the others wait in a collective would hang the job.  Returns True
+        when every rank replays from now on.  strict=True re-raises this rank's capture error after the agreement (so that the
+        other ranks are not left waiting).  Each rank logs its own outcome and its reducer to stderr."""
+        import sys
+        err = None
+        try:
+            why = self.can_capture()
+            if why is not None:
+                raise RuntimeError("capture_graph: " + why)
+            self.capture_graph(step)
+        except Exception as e:       # capture_graph has put the host state back (_abandon_capture): eager steps can continue
+            err = e
+            self._graph = None
+        ok_local = self._graph is not None
+        ok_all = ok_local
+        if dist.is_initialized() and self.world > 1:
+            flag = torch.tensor([1 if ok_local else 0], dtype=torch.int32,
+                                device=self.device if dist.get_backend(self.subgroup) == "nccl" else torch.device("cpu"))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.subgroup)
+            ok_all = bool(int(flag))
+        if not ok_all and ok_local:
+            self._graph, self._slots = None, None
+        print(f"[model_trainer rank {self.rank}/{self.world}] step capture: {'ok' if ok_local else 'FAILED (' + type(err).__name__ + ': ' + str(err) + ')'}; "
+              f"launch mode for all ranks: {'hipGraph replay' if ok_all else 'eager'}; {self.reducer.describe()}", file=sys.stderr, flush=True)
+        if err is not None and strict:
+            raise err
+        return ok_all
+
     def _wait_for_watchdog(self, timeout_s=None):
         """Block until RCCL's watchdog thread has retired every EAGER collective of this process.
 
@@ -550,8 +582,8 @@ class model_trainer:
         batch_loss, t0 = 0.0, time.time()
         opt_steps = self.start_step // self.accumulation_steps
         for step in range(opt_steps, self.totalSteps):
-            if self.graph_after is not None and self._graph is None and step - opt_steps == max(3, self.graph_after) and self.can_capture() is None:
-                self.capture_graph(step + 1)
+            if self.graph_after is not None and self._graph is None and step - opt_steps == max(3, self.graph_after):
+                self.capture_graph_agreed(step + 1)      # (every rank reaches this line at the same step: the decision is collective)
             loss = self.train_step(step + 1)
             if self.keep_losses:
                 self.loss_history.append(loss)

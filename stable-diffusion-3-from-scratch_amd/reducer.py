@@ -45,10 +45,17 @@ class GradReducer:
         self._pending = []       # tensors waiting for a bucket
         self._pending_bytes = 0
         self._inflight = []      # (flat, tensors to copy back into | None)
+        self._works = []         # non-RCCL backends: (Work, flat) of all-reduces still running on the backend's own threads
         self._after = None
         self.skip = False        # True on non-final gradient-accumulation micro-steps (no_sync semantics)
         self._views_wanted = False
         self.buckets = 0         # buckets averaged so far (tests / logs)
+
+    def describe(self):
+        """One line for the logs: what this rank's reducer will do."""
+        backend = dist.get_backend(self.group) if dist.is_initialized() else "none"
+        wire = "bf16" if self.wire_dtype == torch.bfloat16 else "fp32"
+        return f"GradReducer(world={self.world}, enabled={self.enabled}, backend={backend}, algorithm={self.algorithm}, wire={wire})"
 
     def _side(self, device):
         if self._stream is None:
@@ -64,9 +71,12 @@ class GradReducer:
         nccl = dist.get_backend(self.group) == "nccl"
         algo = self.algorithm if (n % W == 0 and n > 0) else "allreduce"
         if algo == "allreduce":
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
-            if not nccl:
-                flat.div_(W)
+            if nccl:
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:
+                # gloo (the CPU tests, CUDA tensors over gloo): a synchronous call would block the HOST in the middle of the backward;
+                # keep the overlap by waiting in finish() (the division by the world size follows the wait)
+                self._works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat))
             return
         s = n // W
         if algo == "rs_ag":
@@ -76,6 +86,7 @@ class GradReducer:
                 shard.div_(W)
             dist.all_gather_into_tensor(flat, shard, group=self.group)
             return
+        # (rs_ag / direct on a non-RCCL backend are multi-step and stay synchronous: test-only there)
         # direct: shard j of every rank -> rank j (one all-to-all), fp32 sum there, averaged shard -> everyone (one all-to-all)
         wire = self.wire_dtype or flat.dtype
         send = flat if wire == flat.dtype else flat.to(wire)
@@ -181,6 +192,10 @@ class GradReducer:
         if not self.enabled or self.skip:
             return
         self.flush()
+        for work, flat in self._works:
+            work.wait()
+            flat.div_(self.world)
+        self._works = []
         for flat, tensors in self._inflight:
             if tensors is None:
                 continue
@@ -198,7 +213,7 @@ class GradReducer:
 
     def reset(self):
         """Forget everything queued or in flight (a graph capture that raised: its collectives were never launched)."""
-        self._pending, self._pending_bytes, self._inflight, self._views_wanted = [], 0, [], False
+        self._pending, self._pending_bytes, self._inflight, self._views_wanted, self._works = [], 0, [], False, []
 
     def attach_hooks(self, params):
         """Fallback for modules without an engine callback: reduce each parameter's gradient as soon as

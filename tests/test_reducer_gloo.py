@@ -6,6 +6,7 @@ import os
 import socket
 import sys
 
+import numpy as np
 import pytest
 import torch
 import torch.distributed as dist
@@ -349,3 +350,145 @@ def test_engine_arenas_are_shardable():
     assert views[3].data_ptr() == prefix.data_ptr() + 4 * prefix.numel()       # scratch views start right behind the padded prefix
     assert all(float(v.abs().sum()) == 0 for v in views)
     assert engine.ARENA_QUANTUM % 8 == 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Eight ranks (the node size the driver's SCALE run uses), arenas with the MMDiT-B block's REAL gradient element counts.
+def _b_block_arena_sizes():
+    """Per-block flat gradient arena sizes of MMDiT-B as the engine lays them out (engine.block_bwd: the block's weight gradients in one
+    arena padded to engine.ARENA_QUANTUM elements), for a middle block and the last block (no text MLP / out-projection / gates)."""
+    from oracle.weights import state_dict_spec
+    import sd3_amd  # noqa: F401
+    from sd3_amd import engine
+    spec = state_dict_spec(dim=768, num_heads=12, num_blocks=12)
+    out = []
+    for blk in (5, 11):
+        n = sum(int(np.prod(shape)) for name, shape in spec if name.startswith(f"blocks.{blk}.") and not name.endswith("freqs"))
+        out.append(-(-n // engine.ARENA_QUANTUM) * engine.ARENA_QUANTUM)
+    return out
+
+
+def _eight_worker(rank, world, port, algo, wire, sizes, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sd3_amd  # noqa: F401
+    from sd3_amd.reducer import GradReducer
+    red = GradReducer(algorithm=algo, wire_dtype=torch.bfloat16 if wire == "bf16" else None)
+    g = torch.Generator().manual_seed(900 + rank)
+    arenas = [torch.randn(n, generator=g) for n in sizes]
+    for a in arenas:                       # one bucket per block, handed over as the backward reaches it
+        assert red.add_bucket([a[: a.numel() // 2], a[a.numel() // 2:]], arenas=[a]) is None
+    odd = torch.randn(1001, generator=g)   # not a multiple of 8: that bucket falls back to all-reduce inside any algorithm
+    assert red.add_bucket([odd], arenas=[odd]) is None
+    red.finish()
+    assert red.buckets == len(sizes) + 1
+    h = [float(a.double().sum()) for a in arenas + [odd]] + [float(a.double().abs().sum()) for a in arenas + [odd]]
+    q.put((rank, h, arenas[0][:4096].numpy().copy(), odd.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo,wire", [("allreduce", "f32"), ("rs_ag", "f32"), ("direct", "f32"), ("direct", "bf16")])
+def test_eight_rank_gloo_bucket_algorithms_on_b_block_arenas(algo, wire):
+    """world_size 8 (one node of MI355X): every bucket algorithm on arenas whose lengths have the divisibility of the real MMDiT-B
+    block arenas (the real element counts -- 7.9 M for a middle block, 4.3 M for the last -- scaled down 64x in bytes: the counts are
+    multiples of ARENA_QUANTUM = 1024, the scaled ones keep (count / 1024) mod 8, i.e. the same shard geometry for 8 ranks), plus
+    a bucket that 8 does not divide.  All ranks end bit-identical; fp32 wire equals the fp64 mean to fp32 rounding; bf16 wire to 2^-7."""
+    real = _b_block_arena_sizes()
+    assert all(n % 1024 == 0 for n in real) and real[0] > 7_000_000 and real[1] > 4_000_000, real
+    sizes = [1024 * ((n // 1024) % 8 + 8 * ((n // 1024) // 512)) for n in real]        # ~64x smaller, same (n / 1024) mod 8
+    assert all(s % 8 == 0 and (s // 1024) % 8 == (n // 1024) % 8 for s, n in zip(sizes, real))
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, algo, wire, sizes, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(1, world):
+        assert res[r][0] == res[0][0], "ranks diverged (checksums)"
+        assert (res[r][1] == res[0][1]).all() and (res[r][2] == res[0][2]).all(), "ranks diverged"
+    gens = [torch.Generator().manual_seed(900 + r) for r in range(world)]
+    per = [[torch.randn(n, generator=g) for n in sizes] + [torch.randn(1001, generator=g)] for g in gens]
+    want0 = torch.stack([p[0][:4096].double() for p in per]).mean(0)
+    want_odd = torch.stack([p[-1].double() for p in per]).mean(0)
+    got0, got_odd = torch.from_numpy(res[0][1]).double(), torch.from_numpy(res[0][2]).double()
+    tol = 2 ** -7 if wire == "bf16" else 1e-6
+    assert float((got0 - want0).abs().max()) <= tol * float(want0.abs().max()) + 1e-7
+    assert float((got_odd - want_odd).abs().max()) <= 1e-6 * float(want_odd.abs().max()) + 1e-7      # (the fallback bucket is always fp32 all-reduce)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The launch mode of a data-parallel run is a collective decision (model_trainer.capture_graph_agreed; bench.py and train() use it).
+def _agree_worker(rank, world, port, fail_rank, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sd3_amd  # noqa: F401
+    net = _EngineLike()
+    tr = _make_trainer(net, 1, 3)
+    micro = [0]
+
+    def source():
+        x, t = _trainer_data(micro[0], rank, world, 3)
+        tr._t = t
+        micro[0] += 1
+        return x, torch.zeros(3, 154, 4), torch.zeros(3, 8)
+
+    tr.data_source = source
+    tr._sample_conditioning = lambda n: (tr._t, None, None, None)
+    tr.train_step(1)
+    # a stand-in for the GPU capture (no GPU here): succeeds by installing a graph object, or raises on the chosen rank
+    tr.can_capture = lambda: None
+    sentinel = object()
+
+    def fake_capture(step):
+        if rank == fail_rank:
+            raise RuntimeError("hipErrorStreamCaptureInvalidated (simulated)")
+        tr._graph = sentinel
+        return sentinel
+
+    tr.capture_graph = fake_capture
+    agreed = tr.capture_graph_agreed(2)
+    kept = tr._graph is sentinel
+    strict_raised = False
+    if fail_rank is not None:
+        tr._graph = None
+        try:                       # strict: the failing rank raises -- AFTER the agreement, so nobody is left waiting in the all-reduce
+            tr.capture_graph_agreed(2, strict=True)
+        except RuntimeError:
+            strict_raised = True
+        assert tr._graph is None
+    tr._graph = None               # (the sentinel cannot replay) -- the eager path must still work on every rank, in step
+    losses = [float(tr.train_step(s)) for s in (2, 3)]
+    q.put((rank, agreed, kept, strict_raised, losses, [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fail_rank", [None, 1])
+def test_launch_mode_is_agreed_across_ranks_and_falls_back_to_eager(fail_rank):
+    """2 gloo ranks: when the capture fails on one rank (simulated), capture_graph_agreed() returns False on BOTH, the rank whose
+    capture succeeded drops its graph, nobody hangs, strict mode raises only on the failing rank and only after the agreement, and
+    the eager steps that follow keep the ranks bit-identical; when it succeeds everywhere, both keep their graph."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, fail_rank, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        agreed, kept, strict_raised, losses, _ = res[r]
+        assert agreed == (fail_rank is None) and kept == (fail_rank is None)
+        assert strict_raised == (fail_rank == r)
+        assert all(l == l for l in losses)
+    for a, b in zip(res[0][4], res[1][4]):
+        assert (a == b).all(), "ranks diverged after the fallback"
