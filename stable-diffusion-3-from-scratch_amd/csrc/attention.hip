@@ -1526,11 +1526,13 @@ extern "C" int mmdit_attn_bwd_qk(const void* Q, const void* K, const void* V, co
   hipStream_t s = (hipStream_t)stream;
   const dim3 grid(((S + 255) / 256) * batch * heads);
   constexpr int lds = qk_lds_bytes<8>();        // 70144 B: above the 64 KB default cap of dynamic LDS
-  static const hipError_t raised = [] {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  }();
-  if (raised != hipSuccess) return (int)raised;     // (positive: a HIP error code, as from mmdit_launch_status)
+  static unsigned long long raised = 0;            // one bit per device (the attribute is a per-device property)
+  if (!mmdit_device_once(raised)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return (int)e;             // (positive: a HIP error code, as from mmdit_launch_status)
+    mmdit_device_mark(raised);
+  }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<8, bf16_t, true>), grid, dim3(512), lds, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Ox,
                      (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)nullptr, F);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, bf16_t, true>), grid, dim3(512), lds, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx,

@@ -151,3 +151,10 @@ static inline int mmdit_launch_status() {
   return e == hipSuccess ? 0 : (int)e;
 }
 #define MMDIT_CHECK_ARG(c) do { if (!(c)) return MMDIT_ERR_ARG; } while (0)
+
+// Per-device "done once" cache for host-side launch set-up (hipFuncSetAttribute of > 64 KB dynamic LDS is a per-device property; one
+// process normally drives one GPU, but a second device must not inherit the first one's flag).  Returns true when `done` already
+// holds the current device's bit; mark with mmdit_device_mark.  A benign race only repeats the idempotent call.
+static inline int mmdit_current_device() { int d = 0; (void)hipGetDevice(&d); return d < 0 ? 0 : (d > 63 ? 63 : d); }
+static inline bool mmdit_device_once(const unsigned long long& done) { return (done >> mmdit_current_device()) & 1ull; }
+static inline void mmdit_device_mark(unsigned long long& done) { done |= 1ull << mmdit_current_device(); }

@@ -200,11 +200,11 @@ template <typename TA, typename TB, bool A_KM, bool B_KM, bool SPLIT, typename T
 int launch(const GroupParams& gp, hipStream_t s) {
   constexpr int smem = (SPLIT ? 6 : 4) * TILE_BYTES;  // 2 stages x 2 tiles, or 1 stage x 6 tiles
   auto k = gemm_kernel<TA, TB, A_KM, B_KM, SPLIT, TC, TAUX>;
-  static bool attr_done = false;  // idempotent; a benign race only repeats the call
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device; idempotent, a benign race only repeats the call
+  if (!mmdit_device_once(attr_done)) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    mmdit_device_mark(attr_done);
   }
   hipLaunchKernelGGL(k, dim3(gp.total_tiles), dim3(256), smem, s, gp);
   return mmdit_launch_status();
@@ -252,8 +252,10 @@ int check_problem(const mmdit_gemm_args* a) {
 // Tile-configuration heuristic of the LDS-DMA path.  Bigger tiles halve the L2->CU traffic per FLOP (a 128x128
 // tile needs ~64 B/clk/CU at full MFMA rate, about what the L2 can deliver) but need enough tiles to fill 256 CUs.
 // workspace of the lean weight-gradient kernel's split tail (device memory owned by the caller; first 4 KiB: zero-initialised tickets)
-static void* g_ws = nullptr;
-static long long g_ws_bytes = 0;
+// (one registration per DEVICE: the tickets and slots are device memory, and a ticket left non-zero by a launch on one GPU must not be
+//  seen by another)
+static void* g_ws[64] = {};
+static long long g_ws_bytes[64] = {};
 
 static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k, bool lean_ok) {
   static const char* force = getenv("MMDIT_GEMM_CFG");
@@ -500,11 +502,12 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     gp.qk_on = 1; gp.qk_heads = qkr->heads; gp.qk_s_total = qkr->s_total;
     gp.qkQ = (bf16_t*)qkr->Q; gp.qkK = (bf16_t*)qkr->K; gp.qkV = (bf16_t*)qkr->V;
   }
-  if (kk && g_ws && gp.split_k > 1) {
+  if (kk && gp.split_k > 1) {
+    const int dev = mmdit_current_device();
     const long long tail_tiles = tiles - full_tiles;
-    if (tail_tiles <= 1024 && 4096 + tail_tiles * gp.split_k * 65536LL * 4 <= g_ws_bytes) {
-      gp.ws_count = (int*)g_ws;
-      gp.ws_slots = (float*)((char*)g_ws + 4096);
+    if (g_ws[dev] && tail_tiles <= 1024 && 4096 + tail_tiles * gp.split_k * 65536LL * 4 <= g_ws_bytes[dev]) {
+      gp.ws_count = (int*)g_ws[dev];
+      gp.ws_slots = (float*)((char*)g_ws[dev] + 4096);
     }
   }
   if (zero_mask) {
@@ -543,8 +546,9 @@ extern "C" int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit
 
 extern "C" int mmdit_gemm_set_workspace(void* ptr, long long bytes) {
   MMDIT_CHECK_ARG((ptr == nullptr && bytes == 0) || (ptr != nullptr && bytes >= 4096 + 65536 * 4 && ((uintptr_t)ptr & 15) == 0));
-  g_ws = ptr;
-  g_ws_bytes = bytes;
+  const int dev = mmdit_current_device();      // registered for the CURRENT device (hipSetDevice before the call)
+  g_ws[dev] = ptr;
+  g_ws_bytes[dev] = bytes;
   return 0;
 }
 

@@ -375,11 +375,11 @@ int launch_cfg(const GroupParams& gp, hipStream_t s) {
   constexpr int slot = (WM * MI * 32 + WN * NJ * 32) * 64 + (FP8 == 2 ? 2048 : 0);
   constexpr int smem = RING * slot + (WM * WN * EP32_WAVE_BYTES <= slot ? 0 : WM * WN * EP32_WAVE_BYTES);
   auto k = gemm_dma_kernel<WM, WN, MI, NJ, A_KM, B_KM, TC, TAUX, FP8, SWIGLU>;
-  static bool attr_done = false;  // idempotent; a benign race only repeats the call
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device; idempotent, a benign race only repeats the call
+  if (!mmdit_device_once(attr_done)) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    mmdit_device_mark(attr_done);
   }
   // one resident workgroup per slot (256 CUs x workgroups that fit per CU by LDS)
   const int slots = 256 * (smem <= 80 * 1024 ? 2 : 1);

@@ -209,11 +209,11 @@ template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false>
 int launch_lean(const GroupParams& gp, hipStream_t s) {
   constexpr int smem = RING * (WM * MI * 32 + WN * NJ * 32) * 64;
   auto k = gemm_lean_kernel<WM, WN, MI, NJ, B_KM, SWIGLU>;
-  static bool attr_done = false;  // idempotent; a benign race only repeats the call
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device; idempotent, a benign race only repeats the call
+  if (!mmdit_device_once(attr_done)) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    mmdit_device_mark(attr_done);
   }
   const int grid = gp.total_tiles < 256 ? gp.total_tiles : 256;   // one persistent workgroup per CU
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);
@@ -395,11 +395,11 @@ template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false, bool Q
 int launch_wide(const GroupParams& gp, hipStream_t s) {
   constexpr int smem = 2 * (WM * MI * 32 + WN * NJ * 32) * 128;
   auto k = gemm_wide_kernel<WM, WN, MI, NJ, B_KM, SWIGLU, QK>;
-  static bool attr_done = false;  // idempotent; a benign race only repeats the call
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device; idempotent, a benign race only repeats the call
+  if (!mmdit_device_once(attr_done)) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    mmdit_device_mark(attr_done);
   }
   const int grid = gp.total_tiles < 256 ? gp.total_tiles : 256;   // one persistent workgroup per CU
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);
@@ -712,11 +712,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kk_kernel(GroupParams gp) {
 int launch_kk(const GroupParams& gp, hipStream_t s) {
   constexpr int smem = RING * (256 + 256) * 64;
   auto k = gemm_kk_kernel<2, 4, 4, 2>;
-  static bool attr_done = false;  // idempotent; a benign race only repeats the call
-  if (!attr_done) {
+  static unsigned long long attr_done = 0;  // one bit per device; idempotent, a benign race only repeats the call
+  if (!mmdit_device_once(attr_done)) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    attr_done = true;
+    mmdit_device_mark(attr_done);
   }
   const int work = total_work(gp);
   int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU

@@ -172,19 +172,20 @@ def _variant(arr, n, outs):
 
 
 # Workspace of the weight-gradient launches' split tail (mmdit_gemm_set_workspace): 4 KiB of zeroed tickets + 256 slots of 256 KiB, one per
-# process, allocated at the first K-decomposed launch on a GPU and kept for the life of the process (a captured hipGraph holds its address).
+# DEVICE, allocated at the first K-decomposed launch on that GPU and kept for the life of the process (a captured hipGraph holds its address).
 # MMDIT_GEMM_WS=0: fp32 atomics instead (the round-2 path).
 _GEMM_WS = {}
 _GEMM_WS_ON = os.environ.get("MMDIT_GEMM_WS", "1") != "0" and os.environ.get("MMDIT_WGRAD_STREAM", "0") != "1"   # (one workspace: its launches must be stream-ordered -- not with the weight-gradient side stream)
 
 
 def _ensure_gemm_workspace(device):
-    if not _GEMM_WS_ON or _GEMM_WS:
+    if not _GEMM_WS_ON or device in _GEMM_WS:
         return
     if torch.cuda.is_current_stream_capturing():
-        return          # (never allocate the process-wide workspace inside a capture: the eager warm-up steps do it)
+        return          # (never allocate the workspace inside a capture: the eager warm-up steps do it)
     ws = torch.zeros(4096 + 256 * 65536 * 4, dtype=torch.uint8, device=device)
-    check(_lib.lib().mmdit_gemm_set_workspace(ws.data_ptr(), ws.numel()), "mmdit_gemm_set_workspace")
+    with torch.cuda.device(device):       # the library keys the registration by the CURRENT device
+        check(_lib.lib().mmdit_gemm_set_workspace(ws.data_ptr(), ws.numel()), "mmdit_gemm_set_workspace")
     _GEMM_WS[device] = ws
 
 
