@@ -260,7 +260,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wide_kernel(GroupParams gp)
         const int c = wave * PB + i, hsel = c / (TBN / 16);
         vb[i] = piece_voff<true, TBN>(c % (TBN / 16), lane, q.ldb, ct.tn * TBN, q.N) + (uint32_t)(hsel * 32 * q.ldb * 2);
       } else if constexpr (SWIGLU) {
-        const int c = wave * PB + i, r = 8 * c + (lane >> 3), chunk = (lane & 7) ^ (r & 7);   // tile-local row r -> gate / up row of the packed weight
+        const int c = wave * PB + i, r = 8 * c + (lane >> 3), chunk = (lane & 7) ^ MMDIT_WIDE_SWZ(r);   // tile-local row r -> gate / up row of the packed weight
         const int row = ((r >> 5) & 1) * (q.N >> 1) + ct.tn * 128 + (r >> 6) * 32 + (r & 31);
         vb[i] = (uint32_t)((int64_t)row * q.ldb * 2 + chunk * 16);
       } else {
