@@ -152,6 +152,7 @@ int mmdit_gemm_set_workspace(void* ptr, long long bytes);
  * 2 = 256x256, 3 = 320x256 (lean kernel only), plus 16 if the stream-K decomposition is used, plus 32 for the full-rounds +
  * split-K-tail schedule (the default K decomposition of stream_k launches), plus 128 when the lean hot-path kernel
  * (csrc/gemm_lean.hip: bf16 in / bf16 out, bias / SiLU only; with k-major A: its weight-gradient kernel, fp32 out) takes the launch.
+ * + 256 when the launch goes to the 8-phase kernel (csrc/gemm8p.hip: 256x256 tiles on the de-phased main loop, 16x16x32 MFMA).
  * Negative = the MMDIT_ERR_* the launch would return.
  * Lets profilers / benchmarks attribute timings to the exact kernel symbol. */
 int mmdit_gemm_plan(const mmdit_gemm_args* args, int count);

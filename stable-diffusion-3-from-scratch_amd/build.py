@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdit_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "mmdit_hip.h")
-SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_lean.hip", "rowops.hip", "attention.hip", "vae.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_lean.hip", "gemm8p.hip", "rowops.hip", "attention.hip", "vae.hip", "optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MMDIT_EXTRA_HIPCC_FLAGS", "").split()
 

@@ -521,8 +521,12 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     }
     *zero_mask = mask;
   }
-  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
+  // the 8-phase kernel (gemm8p.hip) takes every 256x256 launch of the lean kernels; MMDIT_GEMM_8P=0: the round-2/3 kernels of gemm_lean.hip
+  static const char* p8_env = getenv("MMDIT_GEMM_8P");
+  const bool p8 = (lean || kk) && cfg == CFG_256x256 && (!p8_env || atoi(p8_env));
+  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
+  if (p8) return launch_gemm8(a0->a_kmajor, a0->b_kmajor, gp, s);
   if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
   if (kk) return launch_lean_wgrad(gp, s);
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, fp8, gp, s);
@@ -558,7 +562,7 @@ extern "C" int mmdit_gemm_zero_mask(const mmdit_gemm_args* args, int count, unsi
   MMDIT_CHECK_ARG(mask);
   *mask = 0;
   const int rc = gemm_grouped_impl(args, count, nullptr, true, mask);
-  return rc < 0 || rc > 255 ? rc : 0;   // (plan codes are small non-negative integers; anything else is a status)
+  return rc < 0 || rc > 511 ? rc : 0;   // (plan codes are small non-negative integers (9 bits); anything else is a status)
 }
 
 extern "C" int mmdit_gemm(const mmdit_gemm_args* a, mmdit_stream_t stream) {

@@ -1,0 +1,586 @@
+// 256 x 256 x 64 bf16 GEMM on the DE-PHASED ("8-phase") main loop -- cdna_hip_programming.md 5 "The 256^2 8-phase template", T2, T3+T4; built and
+// measured as tools/probes/gemm8p.hip first (8192^3 on random operands: 1.51 PFLOP/s against hipBLASLt's 1.46 and 1.33 for the
+// one-barrier-per-K-step kernels of gemm_lean.hip on the same box; 2260 shader cycles per K tile = 96 % of the matrix-pipe floor).
+//
+// Structure.  8 waves = 2 groups (wr = wave >> 2) x 4 column waves (wc = wave & 3).  Group 1 runs ONE s_barrier behind group 0, so between any
+// two consecutive barriers one group issues its LDS fragment reads + LDS-DMA while the other issues MFMAs: on every SIMD the matrix pipe of
+// one wave runs beside the LDS / VMEM issue of the other.  A K tile (64 deep) is four phases, one quadrant of the wave's 128 x 64 outputs each:
+//     P1  read B0 (4 fragments), A0 (8)   C00 += A0 B0          P3  read A1 (8)    C11 += A1 B1
+//     P2  read B1 (4)                     C01 += A0 B1          P4  (B0 kept)      C10 += A1 B0
+// with v_mfma_f32_16x16x32_bf16 (16 per phase): on random operands the 16x16x32 form runs 8 % more FLOPs per joule than 32x32x16 (a quarter of
+// the accumulator traffic per FLOP), and this loop is clock-(power-)bound, not issue-bound.
+// LDS image of a K tile: four half-tiles A0 A1 B0 B1 of 16 KB (128 rows x 64 k); half-tile A[q] holds the 64-row halves q of BOTH wave rows
+// (local row wr * 64 + c  <->  tile row wr * 128 + q * 64 + c), B[q] the 32-column halves q of the four wave columns -- so a wave's outputs are a
+// contiguous 128 x 64 block (epilogues store whole lines) while every half-tile has exactly ONE reading phase per K tile.  Two K tiles are
+// resident (128 KB) + 32 KB of epilogue staging = the whole 160 KB.
+// Every phase issues the two LDS-DMA instructions (per wave) of one half-tile, almost two K tiles ahead:
+//     P1(t): A1(t+1)     P2(t): A0(t+2)     P3(t): B0(t+2)     P4(t): B1(t+2)
+// and the loop has ONE counted wait per K tile, s_waitcnt vmcnt(6) in P4 (three half-tiles stay in flight), never 0.
+// Hazards (the guide's rules for two groups staggered by a barrier): data waited for in phase p is read in phase p+1 or later; a half-tile is
+// restaged >= 1 phase after the phase whose reads were retired (lgkmcnt(0)) BEFORE that phase's first barrier.
+// Layouts: row-major operands as 128-byte rows, 16-byte chunk c of local row r at chunk c ^ ((r >> 1) & 7) (conflict-free ds_read_b128 of
+// 16-row fragments); k-major operands (data / weight gradients) as 64 k-rows of 256 bytes, chunk c of k-row k at c ^ f(k),
+// f(k) = ((k & 3) << 2) ^ (((k >> 3) & 1) << 1) (conflict-free ds_read_b64_tr_b16 of the 4 x 16 blocks a 16x16x32 operand is made of).
+#include "gemm_tile.h"
+
+using namespace gemm;
+
+namespace {
+
+constexpr int HT = 16384;            // bytes of a half-tile
+constexpr int KBUF = 4 * HT;         // one K tile: A0 A1 B0 B1
+constexpr int XA0 = 0, XA1 = HT, XB0 = 2 * HT, XB1 = 3 * HT;
+constexpr int STAGE0 = 2 * KBUF;     // epilogue staging: 8 waves x 4 KiB behind the two K tiles
+constexpr int SMEM8 = STAGE0 + 8 * EP32_WAVE_BYTES;
+
+enum Epi8 { EPI_BF16 = 0, EPI_SWIGLU = 1, EPI_QK = 2, EPI_F32 = 3 };
+
+#define SWZ_R(r) (((r) >> 1) & 7)
+#define SWZ_K(k) ((((k) & 3) << 2) ^ ((((k) >> 3) & 1) << 1))
+
+typedef f32x4 Acc8[2][2][8];         // [qm][qn][i * 2 + j]: C^T fragments of 16 x 16 (lane & 15 = output row, 4 consecutive columns per lane)
+
+// the 4-value group q (0..7) of 32-row block i32 (0..3) of a wave's 128 x 64 outputs: rows i32 * 32 + (q >> 2) * 16 + (lane & 15),
+// columns (q & 3) * 16 + (lane >> 4) * 4 + [0, 4)
+__device__ __forceinline__ f32x4& grp(Acc8& acc, int i32, int q) {
+  const int i16l = q >> 2, j16 = q & 3;
+  return acc[i32 >> 1][j16 >> 1][((i32 & 1) * 2 + i16l) * 2 + (j16 & 1)];
+}
+
+// ---- epilogues (the arithmetic and the read-back / store side are those of gemm_tile.h; only the write side knows the fragment layout) ------
+// bf16 output (+ bias, + SiLU): the wave's 32 x 64 block is converted first, staged as 32 rows x 128 B (chunk c of row r at c ^ (r & 7)) and
+// leaves as 8 rows x 128 B per wave instruction
+__device__ __forceinline__ void epi8_bf16(Acc8& acc, const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, char* stage) {
+  bf16_t* C = (bf16_t*)p.C;
+  const float* bias = p.bias;
+  const int wr = lane & 15, wq = lane >> 4;            // write side: row within the 16-row fragment, 4-column group
+  const int rr = lane >> 3, rc = lane & 7;             // read side: row within the 8-row pass, 16-B chunk (8 columns)
+  const int colw = n0 + wn * 64;
+  float bv[4][4];
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int c = colw + j * 16 + wq * 4;
+      ld4(bias + (c < p.N ? c : 0), bv[j]);
+      if (c >= p.N) bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const f32x4& a = grp(acc, i, q);
+      float v[4] = {a[0], a[1], a[2], a[3]};
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += bv[q & 3][e];
+      }
+      if (gp.act == MMDIT_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = silu_f(v[e]);
+      }
+      const int row = (q >> 2) * 16 + wr, chunk = (q & 3) * 2 + (wq >> 1);
+      *LDS_PTR(u32x2, stage + row * 128 + ((chunk ^ (row & 7)) << 4) + (wq & 1) * 8) = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+    const int col = colw + rc * 8;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+      const int row = m0 + wm * 128 + i * 32 + r;
+      if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+}
+
+// QKV projection: the raw q / k columns + Q / K / V in the joint attention layout (gemm_tile.h epilogue_bf16_qk: same read-back side)
+__device__ __forceinline__ void epi8_qk(Acc8& acc, const Problem& p, const GroupParams& gp, const QkEpi& e, int m0, int n0, int wm, int wn, int lane, char* stage) {
+  bf16_t* C = (bf16_t*)p.C;
+  const int wr = lane & 15, wq = lane >> 4;
+  const int rr = lane >> 3, rc = lane & 7;
+  const int colw = n0 + wn * 64;
+  const int D = gp.qk_heads * 64, part = colw / D, head = (colw - part * D) >> 6;
+  const bool live = colw < p.N;
+  float w8[8], c8[8], s8[8];
+#pragma unroll
+  for (int q = 0; q < 8; q++) w8[q] = 0.f;
+  if (live && part < 2) ld8((part == 0 ? e.wq : e.wk) + rc * 8, w8);
+  bf16_t* obase = part == 0 ? gp.qkQ : part == 1 ? gp.qkK : gp.qkV;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const f32x4& a = grp(acc, i, q);
+      const int row = (q >> 2) * 16 + wr, chunk = (q & 3) * 2 + (wq >> 1);
+      *LDS_PTR(u32x2, stage + row * 128 + ((chunk ^ (row & 7)) << 4) + (wq & 1) * 8) = (u32x2){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int col = colw + rc * 8;
+    const int rowb = m0 + wm * 128 + i * 32;
+    const int b0 = __builtin_amdgcn_readfirstlane(rowb / e.tokens), n0r = rowb - b0 * e.tokens;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+      const int row = rowb + r;
+      if (!live || row >= p.M) continue;
+      int b = b0, n = n0r + r;
+      if (e.tokens >= 32) { if (n >= e.tokens) { n -= e.tokens; b++; } }
+      else { b = row / e.tokens; n = row - b * e.tokens; }
+      bf16_t* dst = obase + (((int64_t)b * gp.qk_heads + head) * gp.qk_s_total + e.tok0 + n) * 64 + rc * 8;
+      if (part == 2) {
+        *(u32x4*)dst = t;
+        continue;
+      }
+      *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
+      float x[8];
+#pragma unroll
+      for (int q = 0; q < 4; q++) { x[2 * q] = __builtin_bit_cast(float, t[q] << 16); x[2 * q + 1] = __builtin_bit_cast(float, t[q] & 0xffff0000u); }
+      if (e.rcos) {
+        ld8(e.rcos + (int64_t)n * 64 + rc * 8, c8);
+        ld8(e.rsin + (int64_t)n * 64 + rc * 8, s8);
+      }
+      float ss = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; q++) ss += x[q] * x[q];
+      ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+      const float rinv = rsqrtf(ss * (1.f / 64.f) + 1.1920929e-07f);
+#pragma unroll
+      for (int q = 0; q < 8; q++) x[q] = x[q] * rinv * w8[q];
+      if (e.rcos) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float a = x[2 * q], bb = x[2 * q + 1];
+          x[2 * q] = a * c8[2 * q] - bb * s8[2 * q];
+          x[2 * q + 1] = bb * c8[2 * q + 1] + a * s8[2 * q + 1];
+        }
+      }
+      st8(dst, x);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// SwiGLU-fused w12 GEMM: the wave's columns 0..31 are gate rows, 32..63 up rows of the SAME 32 hidden indices 128 tn + 32 wn + c (the DMA
+// source mapping interleaves them), so group q (columns (q & 3) * 16 ..) pairs with group q + 2; aux[M, 2h] (if given) gets the bf16
+// pre-activations, C[M, h] = silu(g) * u formed from the ROUNDED values (bit-identical to the GEMM followed by mmdit_swiglu_fwd)
+__device__ __forceinline__ void epi8_swiglu(Acc8& acc, const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage) {
+  bf16_t* Hout = (bf16_t*)p.C;
+  bf16_t* GU = (bf16_t*)p.aux;
+  const float* bias = p.bias;
+  const int h = p.N >> 1;
+  const int wr = lane & 15, wq = lane >> 4;
+  const int hc = tn * 128 + wn * 32;
+  float bgv[2][4], buv[2][4];
+  if (bias) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      ld4(bias + hc + j * 16 + wq * 4, bgv[j]);
+      ld4(bias + h + hc + j * 16 + wq * 4, buv[j]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    u32x2 pa[2][2];
+#pragma unroll
+    for (int il = 0; il < 2; il++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const f32x4& ag = grp(acc, i, il * 4 + j);
+        const f32x4& au = grp(acc, i, il * 4 + 2 + j);
+        float vg[4] = {ag[0], ag[1], ag[2], ag[3]}, vu[4] = {au[0], au[1], au[2], au[3]};
+        if (bias) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) { vg[e] += bgv[j][e]; vu[e] += buv[j][e]; }
+        }
+        const u32x2 pg = {pack_bf2(vg[0], vg[1]), pack_bf2(vg[2], vg[3])}, pu = {pack_bf2(vu[0], vu[1]), pack_bf2(vu[2], vu[3])};
+        const int row = il * 16 + wr;
+        if (GU) {   // staged as 32 rows x 128 B: chunks 0..3 = gate columns, 4..7 = up columns
+          *LDS_PTR(u32x2, stage + row * 128 + (((j * 2 + (wq >> 1)) ^ (row & 7)) << 4) + (wq & 1) * 8) = pg;
+          *LDS_PTR(u32x2, stage + row * 128 + (((4 + j * 2 + (wq >> 1)) ^ (row & 7)) << 4) + (wq & 1) * 8) = pu;
+        }
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const float g0 = __builtin_bit_cast(float, pg[e] << 16), g1 = __builtin_bit_cast(float, pg[e] & 0xffff0000u);
+          const float u0 = __builtin_bit_cast(float, pu[e] << 16), u1 = __builtin_bit_cast(float, pu[e] & 0xffff0000u);
+          a[2 * e] = silu_f(g0) * u0;
+          a[2 * e + 1] = silu_f(g1) * u1;
+        }
+        pa[il][j] = u32x2{pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (GU) {
+      const int rr = lane >> 3, rc = lane & 7;
+      const int col = (rc & 4 ? h : 0) + hc + (rc & 3) * 8;
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = m0 + wm * 128 + i * 32 + r;
+        if (row < p.M) __builtin_nontemporal_store(t, (u32x4*)(GU + (int64_t)row * p.ld_aux + col));   // read again only in backward: streaming store
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // the activation: 32 rows x 64 B (chunk c of row r at c ^ (r & 3))
+#pragma unroll
+    for (int il = 0; il < 2; il++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        const int row = il * 16 + wr;
+        *LDS_PTR(u32x2, stage + row * 64 + (((j * 2 + (wq >> 1)) ^ (row & 3)) << 4) + (wq & 1) * 8) = pa[il][j];
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    {
+      const int rr = lane >> 2, rc = lane & 3;
+#pragma unroll
+      for (int it = 0; it < 2; it++) {
+        const int r = it * 16 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 64 + ((rc ^ (r & 3)) << 4));
+        const int row = m0 + wm * 128 + i * 32 + r;
+        if (row < p.M) *(u32x4*)(Hout + (int64_t)row * p.ldc + hc + rc * 8) = t;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+}
+
+// fp32 output of the weight gradients: plain / accumulating streaming store or atomic add; staged per 32 x 32 block (32 rows x 128 B)
+__device__ __forceinline__ void epi8_f32(Acc8& acc, const Problem& p, int m0, int n0, int wm, int wn, int lane, char* stage, bool atomic_out, bool accumulate) {
+  float* C = (float*)p.C;
+  const int wr = lane & 15, wq = lane >> 4;
+  const int rr = lane >> 3, rc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + rc * 4;
+      const int row0 = m0 + wm * 128 + i * 32 + rr;
+#pragma unroll
+      for (int il = 0; il < 2; il++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const int row = il * 16 + wr;
+          *LDS_PTR(f32x4, stage + row * 128 + (((jj * 4 + wq) ^ (row & 7)) << 4)) = grp(acc, i, il * 4 + j * 2 + jj);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = row0 + it * 8;
+        if (row >= p.M || col >= p.N) continue;
+        float* cp = C + (int64_t)row * p.ldc + col;
+        if (atomic_out) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) atomicAdd(cp + e, t[e]);
+          continue;
+        }
+        if (accumulate) t += *(const f32x4*)cp;
+        __builtin_nontemporal_store(t, (f32x4*)cp);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// a partial tile of the split tail into its workspace slot (row-major [256][256] fp32, device-scope write-through stores)
+__device__ __forceinline__ void epi8_f32_slot(Acc8& acc, float* slot, int wm, int wn, int lane, char* stage) {
+  const int wr = lane & 15, wq = lane >> 4;
+  const int rr = lane >> 3, rc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+      for (int il = 0; il < 2; il++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const int row = il * 16 + wr;
+          *LDS_PTR(f32x4, stage + row * 128 + (((jj * 4 + wq) ^ (row & 7)) << 4)) = grp(acc, i, il * 4 + j * 2 + jj);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        float* dst = slot + (int64_t)(wm * 128 + i * 32 + r) * 256 + wn * 64 + j * 32 + rc * 4;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(t) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+#define BAR8() asm volatile("s_barrier" ::: "memory")
+#define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define VMCNT8(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+
+template <bool A_KM, bool B_KM, int EPI>
+__global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
+  static_assert(EPI == EPI_F32 ? (A_KM && B_KM) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major); bf16 epilogues take a row-major A");
+  static_assert(!(EPI == EPI_SWIGLU || EPI == EPI_QK) || !B_KM, "fused epilogues: row-major weight");
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  const uint32_t ldsw = lds0 + wave * 1024;
+  const int G = (int)gridDim.x;
+
+  int pos = (int)blockIdx.x, end = total_work(gp);
+  if (gp.tail_first >= 0) {   // balanced tail: this workgroup's share of the tail units (gemm_lean.hip gemm_kk_kernel)
+    const int e = xcd_chunk((int)blockIdx.x, gp.full_tiles) - gp.tail_first, E = gp.tail_G - gp.tail_first;
+    const int left = (gp.total_tiles - gp.full_tiles) * gp.split_k - e;
+    end = gp.full_tiles + (e < 0 || left <= 0 ? 0 : (left + E - 1) / E) * gp.tail_G;
+  }
+  end = __builtin_amdgcn_readfirstlane(end);
+
+  // ---- fragment read offsets inside a half-tile (bytes) ---------------------------------------------------------------------------------
+  // row-major: fragment (16 rows x 32 k) = row (lane & 15), 16 B at k chunk 4 ks + (lane >> 4); one ds_read_b128.
+  // k-major:   two ds_read_b64_tr_b16 of 4 k-rows x 16 columns: k-rows 32 ks + 8 (lane >> 4) + ((lane & 15) >> 2) (+ 4), columns c0 + 4 (lane & 3)
+  uint32_t aoff[8], boff[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int r0 = wr * 64 + i * 16;
+      if (A_KM) { const int kr = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2), c = r0 + 4 * (lane & 3); aoff[i * 2 + ks] = kr * 256 + (((c >> 3) ^ SWZ_K(kr)) << 4) + (c & 7) * 2; }
+      else { const int r = r0 + (lane & 15), kp = ks * 4 + (lane >> 4); aoff[i * 2 + ks] = r * 128 + ((kp ^ SWZ_R(r)) << 4); }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int r0 = wc * 32 + j * 16;
+      if (B_KM) { const int kr = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2), c = r0 + 4 * (lane & 3); boff[j * 2 + ks] = kr * 256 + (((c >> 3) ^ SWZ_K(kr)) << 4) + (c & 7) * 2; }
+      else { const int r = r0 + (lane & 15), kp = ks * 4 + (lane >> 4); boff[j * 2 + ks] = r * 128 + ((kp ^ SWZ_R(r)) << 4); }
+    }
+  }
+  auto frag = [&](bool km, const char* p) -> bf16x8 {
+    if (!km) return *LDS_PTR(const bf16x8, p);
+    const s16x4 lo = lds_tr16(p), hi = lds_tr16(p + 4 * 256);
+    return __builtin_bit_cast(bf16x8, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+  };
+
+  Acc8 acc;
+  bf16x8 fa[8], fb0[4], fb1[4];
+  auto readA = [&](int buf, int x) {
+#pragma unroll
+    for (int f = 0; f < 8; f++) fa[f] = frag(A_KM, smem + buf * KBUF + x + aoff[f]);
+  };
+  auto readB = [&](bf16x8 (&fb)[4], int buf, int x) {
+#pragma unroll
+    for (int f = 0; f < 4; f++) fb[f] = frag(B_KM, smem + buf * KBUF + x + boff[f]);
+  };
+  auto mma = [&](f32x4 (&c)[8], const bf16x8 (&fb)[4]) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) c[i * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + ks], fa[i * 2 + ks], c[i * 2 + j], 0, 0, 0);
+  };
+
+  // ---- staging of the current item: per-lane source offsets of the two pieces of each half-tile, wave-uniform bases and K steps -----------
+  uint32_t voffA[2][2], voffB[2][2];       // [half-tile q][piece]
+  uint64_t baseA = 0, baseB = 0;           // operand base + the item's first K tile
+  uint64_t stepA = 0, stepB = 0;           // bytes per K tile
+  int nkt = 0;                             // K tiles of the current item
+  auto item_setup = [&](const Item& it) {
+    const Problem& q = gp.p[it.pi];
+    const int m0 = it.tm * 256, n0 = it.tn * 256;
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        if (A_KM) {
+          const int kr = (i * 8 + wave) * 4 + (lane >> 4), gc = (lane & 15) ^ SWZ_K(kr), lr0 = gc * 8;
+          const int gm = m0 + (lr0 >> 6) * 128 + h * 64 + (lr0 & 63);
+          voffA[h][i] = (uint32_t)((int64_t)kr * q.lda * 2 + (int64_t)min(gm, q.M - 8) * 2);
+        } else {
+          const int lr = i * 64 + wave * 8 + (lane >> 3), chunk = (lane & 7) ^ SWZ_R(lr);
+          const int gm = m0 + i * 128 + h * 64 + wave * 8 + (lane >> 3);
+          voffA[h][i] = (uint32_t)((int64_t)min(gm, q.M - 1) * q.lda * 2 + chunk * 16);
+        }
+        if (B_KM) {
+          const int kr = (i * 8 + wave) * 4 + (lane >> 4), gc = (lane & 15) ^ SWZ_K(kr), lr0 = gc * 8;
+          const int gn = n0 + (lr0 >> 5) * 64 + h * 32 + (lr0 & 31);
+          voffB[h][i] = (uint32_t)((int64_t)kr * q.ldb * 2 + (int64_t)min(gn, q.N - 8) * 2);
+        } else {
+          const int lr = i * 64 + wave * 8 + (lane >> 3), chunk = (lane & 7) ^ SWZ_R(lr);
+          int gn;
+          if (EPI == EPI_SWIGLU) gn = h * (q.N >> 1) + it.tn * 128 + (lr >> 5) * 32 + (lr & 31);   // gate (h = 0) / up (h = 1) rows of the packed weight
+          else gn = min(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31), q.N - 1);
+          voffB[h][i] = (uint32_t)((int64_t)gn * q.ldb * 2 + chunk * 16);
+        }
+      }
+    const int kt0 = it.h0 >> 1;
+    nkt = (it.h1 - it.h0) >> 1;
+    stepA = A_KM ? (uint64_t)64 * q.lda * 2 : 128;
+    stepB = B_KM ? (uint64_t)64 * q.ldb * 2 : 128;
+    baseA = (uint64_t)(uintptr_t)q.A + kt0 * stepA;
+    baseB = (uint64_t)(uintptr_t)q.B + kt0 * stepB;
+  };
+  // half-tile x of K tile t of the item -> buffer buf (past the item's last K tile the last one is requested again: never read)
+  auto stageA = [&](int h, int t, int buf) {
+    const char* src = (const char*)(uintptr_t)(baseA + (uint64_t)min(t, nkt - 1) * stepA);
+    const uint32_t dst = ldsw + buf * KBUF + (h ? XA1 : XA0);
+    glds16(voffA[h][0], src, dst);
+    glds16(voffA[h][1], src, dst + 8192);
+  };
+  auto stageB = [&](int h, int t, int buf) {
+    const char* src = (const char*)(uintptr_t)(baseB + (uint64_t)min(t, nkt - 1) * stepB);
+    const uint32_t dst = ldsw + buf * KBUF + (h ? XB1 : XB0);
+    glds16(voffB[h][0], src, dst);
+    glds16(voffB[h][1], src, dst + 8192);
+  };
+
+#define KTILE8(t, cur)                                                                                       \
+  {                                                                                                          \
+    /* P1 */                                                                                                 \
+    readB(fb0, cur, XB0); __builtin_amdgcn_sched_barrier(0); readA(cur, XA0);                                 \
+    stageA(1, (t) + 1, (cur) ^ 1);                                                                           \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mma(acc[0][0], fb0);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    /* P2 */                                                                                                 \
+    readB(fb1, cur, XB1);                                                                                    \
+    stageA(0, (t) + 2, cur);                                                                                 \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mma(acc[0][1], fb1);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    /* P3 */                                                                                                 \
+    readA(cur, XA1);                                                                                         \
+    stageB(0, (t) + 2, cur);                                                                                 \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mma(acc[1][1], fb1);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    /* P4 */                                                                                                 \
+    stageB(1, (t) + 2, cur);                                                                                 \
+    VMCNT8(6);                                                                                               \
+    BAR8(); __builtin_amdgcn_sched_barrier(0);                                                               \
+    mma(acc[1][0], fb0);                                                                                     \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+  }
+
+  char* stage = smem + STAGE0 + wave * EP32_WAVE_BYTES;
+  int* s_ticket = (int*)smem;      // (the operand buffers are idle while an epilogue runs)
+
+  Item item = item_at(gp, pos, end);
+  while (item.valid) {
+    item_setup(item);
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+      for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[a][b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (nkt > 0) {
+      // prologue: K tile 0 whole, three half-tiles of K tile 1
+      stageA(0, 0, 0); stageB(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0);
+      stageA(0, 1, 1); stageB(0, 1, 1); stageB(1, 1, 1);
+      VMCNT8(6);
+      BAR8();
+      if (wr == 1) BAR8();         // group 1 runs one barrier behind from here on
+      int t = 0;
+#pragma unroll 1
+      for (; t + 1 < nkt; t += 2) {
+        KTILE8(t, 0)
+        KTILE8(t + 1, 1)
+      }
+      if (t < nkt) KTILE8(t, 0)
+      VMCNT8(0);                   // the trailing (unused) requests have landed
+      if (wr == 0) BAR8();         // rejoin
+      BAR8();                      // every wave's requests have landed and every wave has left the operand buffers
+    }
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------------
+    const Problem& q = gp.p[item.pi];
+    const int m0 = item.tm * 256, n0 = item.tn * 256;
+    if constexpr (EPI == EPI_BF16) epi8_bf16(acc, q, gp, m0, n0, wr, wc, lane, stage);
+    else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu(acc, q, m0, item.tn, wr, wc, lane, stage);
+    else if constexpr (EPI == EPI_QK) epi8_qk(acc, q, gp, gp.qk[item.pi & 1], m0, n0, wr, wc, lane, stage);
+    else {
+      if (item.atomic && gp.ws_slots) {
+        // partial tile of the split tail through the workspace (gemm_lean.hip gemm_kk_kernel: slot store, ticket, the last slice sums)
+        constexpr int TE = 256 * 256, NW = 8;
+        const int tt = item.tile - gp.full_tiles, S = gp.split_k;
+        float* slots = gp.ws_slots + (int64_t)tt * S * TE;
+        epi8_f32_slot(acc, slots + (int64_t)item.sk * TE, wr, wc, lane, stage);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *s_ticket = atomicAdd(gp.ws_count + tt, 1);
+        __syncthreads();
+        if (*s_ticket == S - 1) {
+          float* C = (float*)q.C;
+          constexpr int NCH = TE / 4 / (64 * NW);
+#pragma unroll 1
+          for (int b0 = 0; b0 < NCH; b0 += 4) {
+            f32x4 tsum[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) tsum[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+            for (int s0 = 0; s0 < S; s0 += 4) {
+              f32x4 v[4][4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                const int idx = tid + (b0 + u) * (64 * NW), r = idx / 64, c = (idx % 64) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                  const float* src = slots + (int64_t)min(s0 + k, S - 1) * TE + (int64_t)r * 256 + c;
+                  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u][k]) : "v"(src) : "memory");
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory");
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                  if (s0 + k < S) tsum[u] += v[u][k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int idx = tid + (b0 + u) * (64 * NW), r = idx / 64, c = (idx % 64) * 4;
+              if (m0 + r < q.M && n0 + c < q.N) {
+                float* cp = C + (int64_t)(m0 + r) * q.ldc + n0 + c;
+                if (gp.accumulate) tsum[u] += *(const f32x4*)cp;
+                __builtin_nontemporal_store(tsum[u], (f32x4*)cp);
+              }
+            }
+          }
+          if (tid == 0) gp.ws_count[tt] = 0;
+        }
+        __syncthreads();
+      } else {
+        epi8_f32(acc, q, m0, n0, wr, wc, lane, stage, item.atomic, gp.accumulate != 0);
+      }
+    }
+    item = item_at(gp, item.pos + G, end);
+    if (EPI == EPI_F32) __syncthreads();      // (s_ticket lives in the operand area the next prologue overwrites)
+  }
+}
+
+template <bool A_KM, bool B_KM, int EPI>
+int launch8(const GroupParams& gp, hipStream_t s) {
+  auto k = gemm8_kernel<A_KM, B_KM, EPI>;
+  static unsigned long long attr_done = 0;   // one bit per device
+  if (!mmdit_device_once(attr_done)) {
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8);
+    if (e != hipSuccess) return (int)e;
+    mmdit_device_mark(attr_done);
+  }
+  const int work = total_work(gp);
+  const int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), SMEM8, s, gp);
+  return mmdit_launch_status();
+}
+
+}  // namespace
+
+// 256 x 256 tiles only.  a_km && b_km: fp32 weight gradients (the K-decomposed schedule of gemm.hip); otherwise bf16 output with the
+// bias / SiLU, SwiGLU (gp.act) or QKV (gp.qk_on) epilogue.  gemm.hip has checked the rest.
+int gemm::launch_gemm8(bool a_km, bool b_km, const GroupParams& gp, hipStream_t s) {
+  if (a_km) return b_km ? launch8<true, true, EPI_F32>(gp, s) : MMDIT_ERR_ARG;
+  if (gp.qk_on) return b_km ? MMDIT_ERR_ARG : launch8<false, false, EPI_QK>(gp, s);
+  if (gp.act == MMDIT_ACT_SWIGLU) return b_km ? MMDIT_ERR_ARG : launch8<false, false, EPI_SWIGLU>(gp, s);
+  return b_km ? launch8<false, true, EPI_BF16>(gp, s) : launch8<false, false, EPI_BF16>(gp, s);
+}

@@ -163,6 +163,9 @@ def _variant(arr, n, outs):
     if plan == 64:
         ab = "t,t" if a.precision == PREC_BF16 else "f,f"
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
+    if plan & 256:      # the 8-phase kernel (csrc/gemm8p.hip): <a_kmajor, b_kmajor, epilogue>
+        epi = "f32" if a.a_kmajor else "swiglu" if a.act == ACT_SWIGLU else "bf16"
+        return f"gemm8_kernel<{km},{epi}>" + ("+ktail" if plan & 32 else "")
     if plan & 128 and a.a_kmajor:
         return "gemm_kk_kernel<2,4,4,2>" + ("+ktail" if plan & 32 else "")
     if plan & 128:

@@ -81,6 +81,14 @@ def main():
         A, Bm = rnd(n, n), rnd(n, n)
         t = bench(lambda: ops.gemm(A, Bm, out_dtype=torch.bfloat16), max(3, args.reps // 4))
         print(f"{'square NT bf16':<34}{n:>7}{n:>7}{n:>7}{t * 1e6:>10.1f}{2.0 * n ** 3 / t / 1e12:>10.1f}")
+    # the same square problem in the data-gradient (B k-major) and weight-gradient (both k-major, fp32 out) layouts
+    n = 8192
+    A, Bm = rnd(n, n), rnd(n, n)
+    t = bench(lambda: ops.gemm(A, Bm, b_kmajor=True, out_dtype=torch.bfloat16), max(3, args.reps // 4))
+    print(f"{'square NN (dgrad layout) bf16':<34}{n:>7}{n:>7}{n:>7}{t * 1e6:>10.1f}{2.0 * n ** 3 / t / 1e12:>10.1f}")
+    out32 = torch.empty((n, n), dtype=torch.float32, device=dev)
+    t = bench(lambda: ops.gemm(A, Bm, a_kmajor=True, b_kmajor=True, out=out32), max(3, args.reps // 4))
+    print(f"{'square TN (wgrad layout) f32':<34}{n:>7}{n:>7}{n:>7}{t * 1e6:>10.1f}{2.0 * n ** 3 / t / 1e12:>10.1f}")
 
 
 if __name__ == "__main__":
