@@ -523,10 +523,13 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   }
   // the 8-phase kernel (gemm8p.hip) takes every 256x256 launch of the lean kernels; MMDIT_GEMM_8P=0: the round-2/3 kernels of gemm_lean.hip
   static const char* p8_env = getenv("MMDIT_GEMM_8P");
-  const bool p8 = (lean || kk) && cfg == CFG_256x256 && (!p8_env || atoi(p8_env));
+  static const int p8_mode = p8_env ? atoi(p8_env) : 1;      // 1: every lean launch; 2: only the 256x256 ones
+  // (the QKV launch with the QK-norm / RoPE epilogue stays on the wide kernel at 320 rows: with that epilogue's registers the 320-row 8-phase
+  //  variant measured slower, 1.73 vs 1.59 ms per step)
+  const bool p8 = p8_mode > 0 && ((kk && cfg == CFG_256x256) || (lean && (cfg == CFG_256x256 || (cfg == CFG_320x256 && p8_mode == 1 && !qkr))));
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
-  if (p8) return launch_gemm8(a0->a_kmajor, a0->b_kmajor, gp, s);
+  if (p8) return launch_gemm8(cfg, a0->a_kmajor, a0->b_kmajor, gp, s);
   if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
   if (kk) return launch_lean_wgrad(gp, s);
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, fp8, gp, s);

@@ -27,30 +27,42 @@ using namespace gemm;
 
 namespace {
 
-constexpr int HT = 16384;            // bytes of a half-tile
-constexpr int KBUF = 4 * HT;         // one K tile: A0 A1 B0 B1
-constexpr int XA0 = 0, XA1 = HT, XB0 = 2 * HT, XB1 = 3 * HT;
-constexpr int STAGE0 = 2 * KBUF;     // epilogue staging: 8 waves x 4 KiB behind the two K tiles
-constexpr int SMEM8 = STAGE0 + 8 * EP32_WAVE_BYTES;
+// tile MT x 256 (MT = 256 or 320).  A half-tile holds the q-th quadrant rows (QR = MT / 4 of them) of BOTH wave rows: 2 QR rows x 128 B.
+template <int MT> struct Geo {
+  static constexpr int QR = MT / 4, FI = QR / 16;          // rows of a wave's quadrant; its 16-row fragments
+  static constexpr int HTA = 2 * QR * 128, HTB = 16384;    // bytes of an A / B half-tile
+  static constexpr int KBUF = 2 * HTA + 2 * HTB;           // one K tile: A0 A1 B0 B1
+  static constexpr int XA0 = 0, XA1 = HTA, XB0 = 2 * HTA, XB1 = 2 * HTA + HTB;
+  static constexpr int PA = 2 * QR / 8;                    // 1-KiB DMA pieces of an A half-tile (16 / 20): waves 0..PA-17 issue 3, the others 2
+  static constexpr int PAW = (PA + 7) / 8;
+  // epilogue staging: 8 waves x 4 KiB -- behind the two K tiles (256: 128 + 32 = the whole 160 KB), inside the idle operand buffers (320: 144 KB)
+  static constexpr int STAGE0 = MT == 256 ? 2 * KBUF : 0;
+  static constexpr int SMEM = MT == 256 ? 2 * KBUF + 8 * EP32_WAVE_BYTES : 2 * KBUF;
+  static constexpr int NB32 = MT / 64;                     // 32-row blocks of a wave's rows (4 / 5)
+};
 
 enum Epi8 { EPI_BF16 = 0, EPI_SWIGLU = 1, EPI_QK = 2, EPI_F32 = 3 };
 
 #define SWZ_R(r) (((r) >> 1) & 7)
 #define SWZ_K(k) ((((k) & 3) << 2) ^ ((((k) >> 3) & 1) << 1))
 
-typedef f32x4 Acc8[2][2][8];         // [qm][qn][i * 2 + j]: C^T fragments of 16 x 16 (lane & 15 = output row, 4 consecutive columns per lane)
+// accumulators: acc[qm][qn][i * 2 + j], i < FI, j < 2: C^T fragments of 16 x 16 (lane & 15 = output row, 4 consecutive columns per lane)
+template <int MT> struct AccT { f32x4 a[2][2][2 * Geo<MT>::FI]; };
 
-// the 4-value group q (0..7) of 32-row block i32 (0..3) of a wave's 128 x 64 outputs: rows i32 * 32 + (q >> 2) * 16 + (lane & 15),
-// columns (q & 3) * 16 + (lane >> 4) * 4 + [0, 4)
-__device__ __forceinline__ f32x4& grp(Acc8& acc, int i32, int q) {
-  const int i16l = q >> 2, j16 = q & 3;
-  return acc[i32 >> 1][j16 >> 1][((i32 & 1) * 2 + i16l) * 2 + (j16 & 1)];
+// the 4-value group q (0..7) of 32-row block i32 of a wave's (MT / 2) x 64 outputs: rows i32 * 32 + (q >> 2) * 16 + (lane & 15),
+// columns (q & 3) * 16 + (lane >> 4) * 4 + [0, 4).  (MT = 320: block 2 straddles the two row quadrants of 80.)
+template <int MT>
+__device__ __forceinline__ f32x4& grp(AccT<MT>& acc, int i32, int q) {
+  constexpr int FI = Geo<MT>::FI;
+  const int f16 = i32 * 2 + (q >> 2), j16 = q & 3;
+  return acc.a[f16 / FI][j16 >> 1][(f16 % FI) * 2 + (j16 & 1)];
 }
 
 // ---- epilogues (the arithmetic and the read-back / store side are those of gemm_tile.h; only the write side knows the fragment layout) ------
 // bf16 output (+ bias, + SiLU): the wave's 32 x 64 block is converted first, staged as 32 rows x 128 B (chunk c of row r at c ^ (r & 7)) and
 // leaves as 8 rows x 128 B per wave instruction
-__device__ __forceinline__ void epi8_bf16(Acc8& acc, const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, char* stage) {
+template <int MT>
+__device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, char* stage) {
   bf16_t* C = (bf16_t*)p.C;
   const float* bias = p.bias;
   const int wr = lane & 15, wq = lane >> 4;            // write side: row within the 16-row fragment, 4-column group
@@ -66,7 +78,7 @@ __device__ __forceinline__ void epi8_bf16(Acc8& acc, const Problem& p, const Gro
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < Geo<MT>::NB32; i++) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const f32x4& a = grp(acc, i, q);
@@ -88,7 +100,7 @@ __device__ __forceinline__ void epi8_bf16(Acc8& acc, const Problem& p, const Gro
     for (int it = 0; it < 4; it++) {
       const int r = it * 8 + rr;
       const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
-      const int row = m0 + wm * 128 + i * 32 + r;
+      const int row = m0 + wm * (MT / 2) + i * 32 + r;
       if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
@@ -96,7 +108,8 @@ __device__ __forceinline__ void epi8_bf16(Acc8& acc, const Problem& p, const Gro
 }
 
 // QKV projection: the raw q / k columns + Q / K / V in the joint attention layout (gemm_tile.h epilogue_bf16_qk: same read-back side)
-__device__ __forceinline__ void epi8_qk(Acc8& acc, const Problem& p, const GroupParams& gp, const QkEpi& e, int m0, int n0, int wm, int wn, int lane, char* stage) {
+template <int MT>
+__device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const GroupParams& gp, const QkEpi& e, int m0, int n0, int wm, int wn, int lane, char* stage) {
   bf16_t* C = (bf16_t*)p.C;
   const int wr = lane & 15, wq = lane >> 4;
   const int rr = lane >> 3, rc = lane & 7;
@@ -109,7 +122,7 @@ __device__ __forceinline__ void epi8_qk(Acc8& acc, const Problem& p, const Group
   if (live && part < 2) ld8((part == 0 ? e.wq : e.wk) + rc * 8, w8);
   bf16_t* obase = part == 0 ? gp.qkQ : part == 1 ? gp.qkK : gp.qkV;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < Geo<MT>::NB32; i++) {
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const f32x4& a = grp(acc, i, q);
@@ -118,7 +131,7 @@ __device__ __forceinline__ void epi8_qk(Acc8& acc, const Problem& p, const Group
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const int col = colw + rc * 8;
-    const int rowb = m0 + wm * 128 + i * 32;
+    const int rowb = m0 + wm * (MT / 2) + i * 32;
     const int b0 = __builtin_amdgcn_readfirstlane(rowb / e.tokens), n0r = rowb - b0 * e.tokens;
 #pragma unroll
     for (int it = 0; it < 4; it++) {
@@ -166,7 +179,8 @@ __device__ __forceinline__ void epi8_qk(Acc8& acc, const Problem& p, const Group
 // SwiGLU-fused w12 GEMM: the wave's columns 0..31 are gate rows, 32..63 up rows of the SAME 32 hidden indices 128 tn + 32 wn + c (the DMA
 // source mapping interleaves them), so group q (columns (q & 3) * 16 ..) pairs with group q + 2; aux[M, 2h] (if given) gets the bf16
 // pre-activations, C[M, h] = silu(g) * u formed from the ROUNDED values (bit-identical to the GEMM followed by mmdit_swiglu_fwd)
-__device__ __forceinline__ void epi8_swiglu(Acc8& acc, const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage) {
+template <int MT>
+__device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage) {
   bf16_t* Hout = (bf16_t*)p.C;
   bf16_t* GU = (bf16_t*)p.aux;
   const float* bias = p.bias;
@@ -182,7 +196,7 @@ __device__ __forceinline__ void epi8_swiglu(Acc8& acc, const Problem& p, int m0,
     }
   }
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < Geo<MT>::NB32; i++) {
     u32x2 pa[2][2];
 #pragma unroll
     for (int il = 0; il < 2; il++)
@@ -219,7 +233,7 @@ __device__ __forceinline__ void epi8_swiglu(Acc8& acc, const Problem& p, int m0,
       for (int it = 0; it < 4; it++) {
         const int r = it * 8 + rr;
         const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
-        const int row = m0 + wm * 128 + i * 32 + r;
+        const int row = m0 + wm * (MT / 2) + i * 32 + r;
         if (row < p.M) __builtin_nontemporal_store(t, (u32x4*)(GU + (int64_t)row * p.ld_aux + col));   // read again only in backward: streaming store
       }
     }
@@ -239,7 +253,7 @@ __device__ __forceinline__ void epi8_swiglu(Acc8& acc, const Problem& p, int m0,
       for (int it = 0; it < 2; it++) {
         const int r = it * 16 + rr;
         const u32x4 t = *LDS_PTR(const u32x4, stage + r * 64 + ((rc ^ (r & 3)) << 4));
-        const int row = m0 + wm * 128 + i * 32 + r;
+        const int row = m0 + wm * (MT / 2) + i * 32 + r;
         if (row < p.M) *(u32x4*)(Hout + (int64_t)row * p.ldc + hc + rc * 8) = t;
       }
     }
@@ -248,16 +262,17 @@ __device__ __forceinline__ void epi8_swiglu(Acc8& acc, const Problem& p, int m0,
 }
 
 // fp32 output of the weight gradients: plain / accumulating streaming store or atomic add; staged per 32 x 32 block (32 rows x 128 B)
-__device__ __forceinline__ void epi8_f32(Acc8& acc, const Problem& p, int m0, int n0, int wm, int wn, int lane, char* stage, bool atomic_out, bool accumulate) {
+template <int MT>
+__device__ __forceinline__ void epi8_f32(AccT<MT>& acc, const Problem& p, int m0, int n0, int wm, int wn, int lane, char* stage, bool atomic_out, bool accumulate) {
   float* C = (float*)p.C;
   const int wr = lane & 15, wq = lane >> 4;
   const int rr = lane >> 3, rc = lane & 7;
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < Geo<MT>::NB32; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
       const int col = n0 + wn * 64 + j * 32 + rc * 4;
-      const int row0 = m0 + wm * 128 + i * 32 + rr;
+      const int row0 = m0 + wm * (MT / 2) + i * 32 + rr;
 #pragma unroll
       for (int il = 0; il < 2; il++)
 #pragma unroll
@@ -286,11 +301,12 @@ __device__ __forceinline__ void epi8_f32(Acc8& acc, const Problem& p, int m0, in
 }
 
 // a partial tile of the split tail into its workspace slot (row-major [256][256] fp32, device-scope write-through stores)
-__device__ __forceinline__ void epi8_f32_slot(Acc8& acc, float* slot, int wm, int wn, int lane, char* stage) {
+template <int MT>
+__device__ __forceinline__ void epi8_f32_slot(AccT<MT>& acc, float* slot, int wm, int wn, int lane, char* stage) {
   const int wr = lane & 15, wq = lane >> 4;
   const int rr = lane >> 3, rc = lane & 7;
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < Geo<MT>::NB32; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
 #pragma unroll
@@ -305,7 +321,7 @@ __device__ __forceinline__ void epi8_f32_slot(Acc8& acc, float* slot, int wm, in
       for (int it = 0; it < 4; it++) {
         const int r = it * 8 + rr;
         const f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
-        float* dst = slot + (int64_t)(wm * 128 + i * 32 + r) * 256 + wn * 64 + j * 32 + rc * 4;
+        float* dst = slot + (int64_t)(wm * (MT / 2) + i * 32 + r) * 256 + wn * 64 + j * 32 + rc * 4;
         asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(t) : "memory");
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -316,16 +332,20 @@ __device__ __forceinline__ void epi8_f32_slot(Acc8& acc, float* slot, int wm, in
 #define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define VMCNT8(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <bool A_KM, bool B_KM, int EPI>
+template <int MT, bool A_KM, bool B_KM, int EPI>
 __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
-  static_assert(EPI == EPI_F32 ? (A_KM && B_KM) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major); bf16 epilogues take a row-major A");
+  static_assert(MT == 256 || MT == 320, "tile rows");
+  static_assert(EPI == EPI_F32 ? (A_KM && B_KM && MT == 256) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major, 256 rows); bf16 epilogues take a row-major A");
   static_assert(!(EPI == EPI_SWIGLU || EPI == EPI_QK) || !B_KM, "fused epilogues: row-major weight");
+  using GE = Geo<MT>;
+  constexpr int QR = GE::QR, FI = GE::FI, KBUF = GE::KBUF, XA0 = GE::XA0, XA1 = GE::XA1, XB0 = GE::XB0, XB1 = GE::XB1, PAW = GE::PAW;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
   const uint32_t ldsw = lds0 + wave * 1024;
   const int G = (int)gridDim.x;
+  const bool hiw = wave + 8 * (PAW - 1) < GE::PA;      // (wave-uniform) this wave carries PAW A pieces per half-tile, the others PAW - 1
 
   int pos = (int)blockIdx.x, end = total_work(gp);
   if (gp.tail_first >= 0) {   // balanced tail: this workgroup's share of the tail units (gemm_lean.hip gemm_kk_kernel)
@@ -336,22 +356,27 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   end = __builtin_amdgcn_readfirstlane(end);
 
   // ---- fragment read offsets inside a half-tile (bytes) ---------------------------------------------------------------------------------
-  // row-major: fragment (16 rows x 32 k) = row (lane & 15), 16 B at k chunk 4 ks + (lane >> 4); one ds_read_b128.
+  // row-major: fragment (16 rows x 32 k) = row (lane & 15), 16 B at k chunk 4 ks + (lane >> 4): one ds_read_b128.  The chunk permutation only
+  //            involves the row's low four bits, so fragment i of a quadrant is fragment 0 + i * 2048: ONE address register per k step.
   // k-major:   two ds_read_b64_tr_b16 of 4 k-rows x 16 columns: k-rows 32 ks + 8 (lane >> 4) + ((lane & 15) >> 2) (+ 4), columns c0 + 4 (lane & 3)
-  uint32_t aoff[8], boff[4];
+  //            (the permutation mixes the column chunk into the k-row's bits: one address register per fragment).
+  constexpr int NAO = A_KM ? 2 * FI : 2, NBO = B_KM ? 4 : 2;
+  uint32_t aoff[NAO], boff[NBO];
 #pragma unroll
   for (int ks = 0; ks < 2; ks++) {
+    if (A_KM) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int r0 = wr * 64 + i * 16;
-      if (A_KM) { const int kr = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2), c = r0 + 4 * (lane & 3); aoff[i * 2 + ks] = kr * 256 + (((c >> 3) ^ SWZ_K(kr)) << 4) + (c & 7) * 2; }
-      else { const int r = r0 + (lane & 15), kp = ks * 4 + (lane >> 4); aoff[i * 2 + ks] = r * 128 + ((kp ^ SWZ_R(r)) << 4); }
+      for (int i = 0; i < FI; i++) { const int kr = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2), c = wr * QR + i * 16 + 4 * (lane & 3); aoff[i * 2 + ks] = kr * 256 + (((c >> 3) ^ SWZ_K(kr)) << 4) + (c & 7) * 2; }
+    } else {
+      const int r = wr * QR + (lane & 15), kp = ks * 4 + (lane >> 4);
+      aoff[ks] = r * 128 + ((kp ^ SWZ_R(r)) << 4);
     }
+    if (B_KM) {
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int r0 = wc * 32 + j * 16;
-      if (B_KM) { const int kr = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2), c = r0 + 4 * (lane & 3); boff[j * 2 + ks] = kr * 256 + (((c >> 3) ^ SWZ_K(kr)) << 4) + (c & 7) * 2; }
-      else { const int r = r0 + (lane & 15), kp = ks * 4 + (lane >> 4); boff[j * 2 + ks] = r * 128 + ((kp ^ SWZ_R(r)) << 4); }
+      for (int j = 0; j < 2; j++) { const int kr = ks * 32 + 8 * (lane >> 4) + ((lane & 15) >> 2), c = wc * 32 + j * 16 + 4 * (lane & 3); boff[j * 2 + ks] = kr * 256 + (((c >> 3) ^ SWZ_K(kr)) << 4) + (c & 7) * 2; }
+    } else {
+      const int r = wc * 32 + (lane & 15), kp = ks * 4 + (lane >> 4);
+      boff[ks] = r * 128 + ((kp ^ SWZ_R(r)) << 4);
     }
   }
   auto frag = [&](bool km, const char* p) -> bf16x8 {
@@ -360,108 +385,153 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     return __builtin_bit_cast(bf16x8, (s16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
   };
 
-  Acc8 acc;
-  bf16x8 fa[8], fb0[4], fb1[4];
+  AccT<MT> acc;
+  bf16x8 fa[2 * FI], fb0[4], fb1s[4];
+  bf16x8 (&fb1)[4] = MT == 256 ? fb1s : fb0;      // (320 rows: ONE set of B fragments, see REREAD below)
+#define FB1 fb1
   auto readA = [&](int buf, int x) {
 #pragma unroll
-    for (int f = 0; f < 8; f++) fa[f] = frag(A_KM, smem + buf * KBUF + x + aoff[f]);
+    for (int i = 0; i < FI; i++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) fa[i * 2 + ks] = frag(A_KM, smem + buf * KBUF + x + (A_KM ? aoff[A_KM ? i * 2 + ks : 0] : aoff[ks] + i * 2048));
   };
   auto readB = [&](bf16x8 (&fb)[4], int buf, int x) {
 #pragma unroll
-    for (int f = 0; f < 4; f++) fb[f] = frag(B_KM, smem + buf * KBUF + x + boff[f]);
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) fb[j * 2 + ks] = frag(B_KM, smem + buf * KBUF + x + (B_KM ? boff[B_KM ? j * 2 + ks : 0] : boff[ks] + j * 2048));
   };
-  auto mma = [&](f32x4 (&c)[8], const bf16x8 (&fb)[4]) {
+  auto mma = [&](f32x4 (&c)[2 * FI], const bf16x8 (&fb)[4]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int i = 0; i < FI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++) c[i * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + ks], fa[i * 2 + ks], c[i * 2 + j], 0, 0, 0);
   };
 
-  // ---- staging of the current item: per-lane source offsets of the two pieces of each half-tile, wave-uniform bases and K steps -----------
-  uint32_t voffA[2][2], voffB[2][2];       // [half-tile q][piece]
-  uint64_t baseA = 0, baseB = 0;           // operand base + the item's first K tile
-  uint64_t stepA = 0, stepB = 0;           // bytes per K tile
-  int nkt = 0;                             // K tiles of the current item
+  // ---- staging of the current item.  The per-lane source offset of a DMA piece is formed when the piece is issued (four VALU operations in a
+  // phase whose vector ALU is otherwise idle) from TWO registers per operand -- holding one offset per (half-tile, piece) would cost 8 / 10
+  // registers this kernel does not have:
+  //   row-major: row0 = the lane's row in piece 0 of half-tile 0, chk = 16 * its chunk; offset = min(row0 + d, R - 1) * ld * 2 + chk, where the
+  //              row delta d of (half-tile, piece) is a compile-time constant (the chunk permutation depends on the piece's parity = the wave's);
+  //   k-major:   col0 = the lane's first column in half-tile 0, kof = k-row * ld * 2; offset = min(col0 + d, R - 8) * 2 + kof + piece * 32 * ld * 2.
+  uint32_t rowA = 0, chkA = 0, rowB = 0, chkB = 0;
+  uint32_t ld2A = 0, ld2B = 0;             // bytes per operand row (wave-uniform)
+  int limA = 0, limB = 0;                  // clamp: R - 1 (row-major) / R - 8 (k-major)
+  // wave-uniform source pointers: curA / curB = the K tile being multiplied; stagings take it + 0 / 1 / 2 K steps (clamped to the item's
+  // last K tile: past it the last one is requested again and never read) -- running pointers, no 64-bit multiplies by variables in the loop
+  uint64_t curA = 0, curB = 0, stepA = 0, stepB = 0;
+  int nkt = 0, krem = 0;                   // K tiles of the current item; K tiles behind the one being multiplied
+  int swig_h = 0;                          // SwiGLU: rows between the gate and the up half of the packed weight
   auto item_setup = [&](const Item& it) {
     const Problem& q = gp.p[it.pi];
-    const int m0 = it.tm * 256, n0 = it.tn * 256;
-#pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        if (A_KM) {
-          const int kr = (i * 8 + wave) * 4 + (lane >> 4), gc = (lane & 15) ^ SWZ_K(kr), lr0 = gc * 8;
-          const int gm = m0 + (lr0 >> 6) * 128 + h * 64 + (lr0 & 63);
-          voffA[h][i] = (uint32_t)((int64_t)kr * q.lda * 2 + (int64_t)min(gm, q.M - 8) * 2);
-        } else {
-          const int lr = i * 64 + wave * 8 + (lane >> 3), chunk = (lane & 7) ^ SWZ_R(lr);
-          const int gm = m0 + i * 128 + h * 64 + wave * 8 + (lane >> 3);
-          voffA[h][i] = (uint32_t)((int64_t)min(gm, q.M - 1) * q.lda * 2 + chunk * 16);
-        }
-        if (B_KM) {
-          const int kr = (i * 8 + wave) * 4 + (lane >> 4), gc = (lane & 15) ^ SWZ_K(kr), lr0 = gc * 8;
-          const int gn = n0 + (lr0 >> 5) * 64 + h * 32 + (lr0 & 31);
-          voffB[h][i] = (uint32_t)((int64_t)kr * q.ldb * 2 + (int64_t)min(gn, q.N - 8) * 2);
-        } else {
-          const int lr = i * 64 + wave * 8 + (lane >> 3), chunk = (lane & 7) ^ SWZ_R(lr);
-          int gn;
-          if (EPI == EPI_SWIGLU) gn = h * (q.N >> 1) + it.tn * 128 + (lr >> 5) * 32 + (lr & 31);   // gate (h = 0) / up (h = 1) rows of the packed weight
-          else gn = min(n0 + (lr >> 5) * 64 + h * 32 + (lr & 31), q.N - 1);
-          voffB[h][i] = (uint32_t)((int64_t)gn * q.ldb * 2 + chunk * 16);
-        }
-      }
+    const int m0 = it.tm * MT, n0 = it.tn * 256;
+    ld2A = (uint32_t)q.lda * 2; ld2B = (uint32_t)q.ldb * 2;
+    if (A_KM) {   // (MT = 256 only) piece i: k-rows (8 i + wave) * 4 + (lane >> 4); LDS chunk (lane & 15) holds global chunk (lane & 15) ^ SWZ_K(k-row)
+      const int kr = wave * 4 + (lane >> 4), lr0 = ((lane & 15) ^ SWZ_K(kr)) * 8;
+      rowA = m0 + (lr0 >> 6) * 128 + (lr0 & 63); chkA = kr * ld2A; limA = q.M - 8;
+    } else {      // piece pc = wave + 8 i: local rows 8 pc + (lane >> 3) of the half-tile = wave row lr / QR, quadrant row lr % QR
+      const int lr = wave * 8 + (lane >> 3);
+      rowA = m0 + lr; chkA = ((lane & 7) ^ SWZ_R(lr)) * 16; limA = q.M - 1;
+    }
+    if (B_KM) {
+      const int kr = wave * 4 + (lane >> 4), lr0 = ((lane & 15) ^ SWZ_K(kr)) * 8;
+      rowB = n0 + (lr0 >> 5) * 64 + (lr0 & 31); chkB = kr * ld2B; limB = q.N - 8;
+    } else {
+      const int lr = wave * 8 + (lane >> 3);      // piece 0: wave columns lr >> 5 (0, 1), column lr & 31; piece 1: wave columns 2, 3
+      chkB = ((lane & 7) ^ SWZ_R(lr)) * 16;
+      if (EPI == EPI_SWIGLU) { rowB = it.tn * 128 + lr; swig_h = q.N >> 1; limB = q.N - 1; }   // gate / up rows of the packed weight
+      else { rowB = n0 + (lr >> 5) * 64 + (lr & 31); limB = q.N - 1; }
+    }
     const int kt0 = it.h0 >> 1;
     nkt = (it.h1 - it.h0) >> 1;
+    krem = nkt - 1;
     stepA = A_KM ? (uint64_t)64 * q.lda * 2 : 128;
     stepB = B_KM ? (uint64_t)64 * q.ldb * 2 : 128;
-    baseA = (uint64_t)(uintptr_t)q.A + kt0 * stepA;
-    baseB = (uint64_t)(uintptr_t)q.B + kt0 * stepB;
+    curA = (uint64_t)(uintptr_t)q.A + kt0 * stepA;
+    curB = (uint64_t)(uintptr_t)q.B + kt0 * stepB;
   };
-  // half-tile x of K tile t of the item -> buffer buf (past the item's last K tile the last one is requested again: never read)
-  auto stageA = [&](int h, int t, int buf) {
-    const char* src = (const char*)(uintptr_t)(baseA + (uint64_t)min(t, nkt - 1) * stepA);
+  // half-tile h of K tile (current + d), d = 0 / 1 / 2 -> buffer buf
+  auto stageA = [&](int h, int d, int buf) {
+    const int dd = min(d, krem);
+    const char* src = (const char*)(uintptr_t)(curA + (uint64_t)(uint32_t)dd * stepA);
     const uint32_t dst = ldsw + buf * KBUF + (h ? XA1 : XA0);
-    glds16(voffA[h][0], src, dst);
-    glds16(voffA[h][1], src, dst + 8192);
+#pragma unroll
+    for (int i = 0; i < PAW; i++) {
+      if (!(i < PAW - 1 || GE::PA % 8 == 0 || hiw)) continue;
+      uint32_t voff;
+      if (A_KM) voff = (uint32_t)min((int)rowA + h * 64, limA) * 2 + chkA + (uint32_t)(i * 32) * ld2A;
+      else {      // local row 8 (wave + 8 i) + ..: wave row (lr / QR), quadrant row lr % QR -> tile row (lr / QR) * 2 QR + h QR + lr % QR
+        const int lr0 = 64 * i;                                 // + wave * 8 + (lane >> 3) < 64: same wave row as long as 64 i + 63 < QR ... handled per case
+        int drow;
+        if (MT == 256) drow = i * 128 + h * 64;                  // QR = 64: piece i is wave row i
+        else drow = 0;                                           // (320: see below)
+        if (MT == 256) voff = (uint32_t)min((int)rowA + drow, limA) * ld2A + chkA;
+        else {
+          // QR = 80: local row lr = 64 i + 8 wave + (lane >> 3) (< 160); tile row = (lr >= 80 ? 160 : 0) + h * 80 + (lr >= 80 ? lr - 80 : lr) = lr + (lr >= 80 ? 80 : 0) + h * 80
+          const int lr = lr0 + (int)rowA;                        // rowA carries m0 + 8 wave + (lane >> 3)
+          const int lrl = lr0 + wave * 8;                        // wave-uniform part: pieces never straddle the wave rows (80 = 10 pieces)
+          voff = (uint32_t)min(lr + (lrl >= 80 ? 80 : 0) + h * 80, limA) * ld2A + chkA;
+        }
+      }
+      glds16(voff, src, dst + i * 8192);
+    }
   };
-  auto stageB = [&](int h, int t, int buf) {
-    const char* src = (const char*)(uintptr_t)(baseB + (uint64_t)min(t, nkt - 1) * stepB);
+  auto stageB = [&](int h, int d, int buf) {
+    const int dd = min(d, krem);
+    const char* src = (const char*)(uintptr_t)(curB + (uint64_t)(uint32_t)dd * stepB);
     const uint32_t dst = ldsw + buf * KBUF + (h ? XB1 : XB0);
-    glds16(voffB[h][0], src, dst);
-    glds16(voffB[h][1], src, dst + 8192);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      uint32_t voff;
+      if (B_KM) voff = (uint32_t)min((int)rowB + h * 32, limB) * 2 + chkB + (uint32_t)(i * 32) * ld2B;
+      else if (EPI == EPI_SWIGLU) voff = (uint32_t)((int)rowB + i * 64 + h * swig_h) * ld2B + chkB;      // hidden index 128 tn + 64 i + ..: gate (h = 0) / up (h = 1)
+      else voff = (uint32_t)min((int)rowB + i * 128 + h * 32, limB) * ld2B + chkB;                       // piece i: wave columns 2 i, 2 i + 1
+      glds16(voff, src, dst + i * 8192);
+    }
+  };
+  auto next_ktile = [&]() { curA += stepA; curB += stepB; krem--; };
+  // Two schedules.  KEEP (256 rows): B0 stays in registers from P1 to P4; stagings P1(t): A1(t+1), P2(t): A0(t+2), P3(t): B0(t+2), P4(t): B1(t+2);
+  // the three youngest half-tiles at the counted wait are A, B, B.  REREAD (320 rows: 160 accumulator + 40 A-fragment registers leave room for ONE
+  // set of B fragments): P4 reads B0 again, so B0 is restaged last -- P1(t): B0(t+1), P2(t): A0(t+2), P3(t): B1(t+2), P4(t): A1(t+2); youngest A, B, A.
+  constexpr bool REREAD = MT != 256;
+  auto wait3 = [&]() {
+    constexpr int NA = REREAD ? 2 : 1, NB = REREAD ? 1 : 2;
+    if (GE::PA % 8 == 0 || hiw) VMCNT8(NA * PAW + NB * 2);
+    else VMCNT8(NA * (PAW - 1) + NB * 2);
   };
 
-#define KTILE8(t, cur)                                                                                       \
+#define KTILE8(cur)                                                                                          \
   {                                                                                                          \
     /* P1 */                                                                                                 \
     readB(fb0, cur, XB0); __builtin_amdgcn_sched_barrier(0); readA(cur, XA0);                                 \
-    stageA(1, (t) + 1, (cur) ^ 1);                                                                           \
+    if (REREAD) stageB(0, 1, (cur) ^ 1); else stageA(1, 1, (cur) ^ 1);                           \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
-    mma(acc[0][0], fb0);                                                                                     \
+    mma(acc.a[0][0], fb0);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P2 */                                                                                                 \
-    readB(fb1, cur, XB1);                                                                                    \
-    stageA(0, (t) + 2, cur);                                                                                 \
+    readB(FB1, cur, XB1);                                                                                    \
+    stageA(0, 2, cur);                                                                                 \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
-    mma(acc[0][1], fb1);                                                                                     \
+    mma(acc.a[0][1], FB1);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P3 */                                                                                                 \
     readA(cur, XA1);                                                                                         \
-    stageB(0, (t) + 2, cur);                                                                                 \
+    if (REREAD) stageB(1, 2, cur); else stageB(0, 2, cur);                                       \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
-    mma(acc[1][1], fb1);                                                                                     \
+    mma(acc.a[1][1], FB1);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P4 */                                                                                                 \
-    stageB(1, (t) + 2, cur);                                                                                 \
-    VMCNT8(6);                                                                                               \
-    BAR8(); __builtin_amdgcn_sched_barrier(0);                                                               \
-    mma(acc[1][0], fb0);                                                                                     \
+    if (REREAD) { readB(fb0, cur, XB0); stageA(1, 2, cur); } else stageB(1, 2, cur);             \
+    wait3();                                                                                                 \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mma(acc.a[1][0], fb0);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    next_ktile();                                                                                            \
   }
 
-  char* stage = smem + STAGE0 + wave * EP32_WAVE_BYTES;
+  char* stage = smem + GE::STAGE0 + wave * EP32_WAVE_BYTES;
   int* s_ticket = (int*)smem;      // (the operand buffers are idle while an epilogue runs)
 
   Item item = item_at(gp, pos, end);
@@ -472,38 +542,39 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 #pragma unroll
       for (int b = 0; b < 2; b++)
 #pragma unroll
-        for (int i = 0; i < 8; i++) acc[a][b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 2 * FI; i++) acc.a[a][b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (nkt > 0) {
-      // prologue: K tile 0 whole, three half-tiles of K tile 1
-      stageA(0, 0, 0); stageB(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0);
-      stageA(0, 1, 1); stageB(0, 1, 1); stageB(1, 1, 1);
-      VMCNT8(6);
+      // prologue: K tile 0 whole, three half-tiles of K tile 1 (in the order the loop continues)
+      if (REREAD) { stageA(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageB(0, 0, 0); stageA(0, 1, 1); stageB(1, 1, 1); stageA(1, 1, 1); }
+      else { stageA(0, 0, 0); stageB(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageA(0, 1, 1); stageB(0, 1, 1); stageB(1, 1, 1); }
+      // (second argument: K tiles ahead of the one being multiplied)
+      wait3();
       BAR8();
       if (wr == 1) BAR8();         // group 1 runs one barrier behind from here on
       int t = 0;
 #pragma unroll 1
       for (; t + 1 < nkt; t += 2) {
-        KTILE8(t, 0)
-        KTILE8(t + 1, 1)
+        KTILE8(0)
+        KTILE8(1)
       }
-      if (t < nkt) KTILE8(t, 0)
+      if (t < nkt) KTILE8(0)
       VMCNT8(0);                   // the trailing (unused) requests have landed
       if (wr == 0) BAR8();         // rejoin
       BAR8();                      // every wave's requests have landed and every wave has left the operand buffers
     }
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------------
     const Problem& q = gp.p[item.pi];
-    const int m0 = item.tm * 256, n0 = item.tn * 256;
-    if constexpr (EPI == EPI_BF16) epi8_bf16(acc, q, gp, m0, n0, wr, wc, lane, stage);
-    else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu(acc, q, m0, item.tn, wr, wc, lane, stage);
-    else if constexpr (EPI == EPI_QK) epi8_qk(acc, q, gp, gp.qk[item.pi & 1], m0, n0, wr, wc, lane, stage);
+    const int m0 = item.tm * MT, n0 = item.tn * 256;
+    if constexpr (EPI == EPI_BF16) epi8_bf16<MT>(acc, q, gp, m0, n0, wr, wc, lane, stage);
+    else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT>(acc, q, m0, item.tn, wr, wc, lane, stage);
+    else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[item.pi & 1], m0, n0, wr, wc, lane, stage);
     else {
       if (item.atomic && gp.ws_slots) {
         // partial tile of the split tail through the workspace (gemm_lean.hip gemm_kk_kernel: slot store, ticket, the last slice sums)
         constexpr int TE = 256 * 256, NW = 8;
         const int tt = item.tile - gp.full_tiles, S = gp.split_k;
         float* slots = gp.ws_slots + (int64_t)tt * S * TE;
-        epi8_f32_slot(acc, slots + (int64_t)item.sk * TE, wr, wc, lane, stage);
+        epi8_f32_slot<MT>(acc, slots + (int64_t)item.sk * TE, wr, wc, lane, stage);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) *s_ticket = atomicAdd(gp.ws_count + tt, 1);
@@ -551,36 +622,44 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         }
         __syncthreads();
       } else {
-        epi8_f32(acc, q, m0, n0, wr, wc, lane, stage, item.atomic, gp.accumulate != 0);
+        epi8_f32<MT>(acc, q, m0, n0, wr, wc, lane, stage, item.atomic, gp.accumulate != 0);
       }
     }
     item = item_at(gp, item.pos + G, end);
-    if (EPI == EPI_F32) __syncthreads();      // (s_ticket lives in the operand area the next prologue overwrites)
+    if (MT != 256) BAR8();         // (the staging lives in the operand buffers the next prologue overwrites)
   }
 }
 
-template <bool A_KM, bool B_KM, int EPI>
+template <int MT, bool A_KM, bool B_KM, int EPI>
 int launch8(const GroupParams& gp, hipStream_t s) {
-  auto k = gemm8_kernel<A_KM, B_KM, EPI>;
+  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI>;
+  constexpr int smem = Geo<MT>::SMEM;
   static unsigned long long attr_done = 0;   // one bit per device
   if (!mmdit_device_once(attr_done)) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8);
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
     mmdit_device_mark(attr_done);
   }
   const int work = total_work(gp);
   const int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), SMEM8, s, gp);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gp);
   return mmdit_launch_status();
+}
+
+template <int MT>
+int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s) {
+  if (gp.qk_on) return b_km ? MMDIT_ERR_ARG : launch8<MT, false, false, EPI_QK>(gp, s);
+  if (gp.act == MMDIT_ACT_SWIGLU) return b_km ? MMDIT_ERR_ARG : launch8<MT, false, false, EPI_SWIGLU>(gp, s);
+  return b_km ? launch8<MT, false, true, EPI_BF16>(gp, s) : launch8<MT, false, false, EPI_BF16>(gp, s);
 }
 
 }  // namespace
 
-// 256 x 256 tiles only.  a_km && b_km: fp32 weight gradients (the K-decomposed schedule of gemm.hip); otherwise bf16 output with the
-// bias / SiLU, SwiGLU (gp.act) or QKV (gp.qk_on) epilogue.  gemm.hip has checked the rest.
-int gemm::launch_gemm8(bool a_km, bool b_km, const GroupParams& gp, hipStream_t s) {
-  if (a_km) return b_km ? launch8<true, true, EPI_F32>(gp, s) : MMDIT_ERR_ARG;
-  if (gp.qk_on) return b_km ? MMDIT_ERR_ARG : launch8<false, false, EPI_QK>(gp, s);
-  if (gp.act == MMDIT_ACT_SWIGLU) return b_km ? MMDIT_ERR_ARG : launch8<false, false, EPI_SWIGLU>(gp, s);
-  return b_km ? launch8<false, true, EPI_BF16>(gp, s) : launch8<false, false, EPI_BF16>(gp, s);
+// MT x 256 tiles (cfg CFG_256x256 or CFG_320x256).  a_km && b_km: fp32 weight gradients (256 rows; the K-decomposed schedule of gemm.hip);
+// otherwise bf16 output with the bias / SiLU, SwiGLU (gp.act) or QKV (gp.qk_on) epilogue.  gemm.hip has checked the rest.
+int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s) {
+  if (a_km) return b_km && cfg == CFG_256x256 ? launch8<256, true, true, EPI_F32>(gp, s) : MMDIT_ERR_ARG;
+  if (cfg == CFG_320x256) return launch8_bf16<320>(b_km, gp, s);
+  if (cfg == CFG_256x256) return launch8_bf16<256>(b_km, gp, s);
+  return MMDIT_ERR_ARG;
 }

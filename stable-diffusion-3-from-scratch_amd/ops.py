@@ -165,7 +165,7 @@ def _variant(arr, n, outs):
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
     if plan & 256:      # the 8-phase kernel (csrc/gemm8p.hip): <a_kmajor, b_kmajor, epilogue>
         epi = "f32" if a.a_kmajor else "swiglu" if a.act == ACT_SWIGLU else "bf16"
-        return f"gemm8_kernel<{km},{epi}>" + ("+ktail" if plan & 32 else "")
+        return f"gemm8_kernel<{320 if plan & 15 == 3 else 256},{km},{epi}>" + ("+ktail" if plan & 32 else "")
     if plan & 128 and a.a_kmajor:
         return "gemm_kk_kernel<2,4,4,2>" + ("+ktail" if plan & 32 else "")
     if plan & 128:
