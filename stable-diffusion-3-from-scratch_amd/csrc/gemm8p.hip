@@ -77,6 +77,17 @@ __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const
       if (c >= p.N) bv[j][0] = bv[j][1] = bv[j][2] = bv[j][3] = 0.f;
     }
   }
+  if (gp.debug & 32) {      // ablation: the global stores alone (no conversion, no staging): 8 rows x 128 B per instruction, as the real epilogue
+#pragma unroll
+    for (int i = 0; i < Geo<MT>::NB32; i++)
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const f32x4& a = grp(acc, i, it);
+        const int row = m0 + wm * (MT / 2) + i * 32 + it * 8 + rr, col = colw + rc * 8;
+        if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = __builtin_bit_cast(u32x4, a);
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < Geo<MT>::NB32; i++) {
 #pragma unroll
@@ -101,6 +112,7 @@ __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const
       const int r = it * 8 + rr;
       const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
       const int row = m0 + wm * (MT / 2) + i * 32 + r;
+      if (gp.debug & 16) { if (t[0] == 0x12345678u) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t; continue; }   // ablation: staging without the global stores
       if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
@@ -534,9 +546,87 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   char* stage = smem + GE::STAGE0 + wave * EP32_WAVE_BYTES;
   int* s_ticket = (int*)smem;      // (the operand buffers are idle while an epilogue runs)
 
-  Item item = item_at(gp, pos, end);
+  // The epilogue of an item.  DEFER (256 rows, bf16 outputs: the staging has its own 32 KB): it runs AFTER the next item's prologue requests
+  // have been issued, i.e. under their latency (~1.4 us per tile of a K = 768 launch); otherwise (320 rows: the staging aliases the operand
+  // buffers; weight gradients: ticket + long reductions) right behind the item's main loop.
+  constexpr bool DEFER = MT == 256 && EPI != EPI_F32;
+  auto run_epilogue = [&](const Item& it) {
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------------
+  const Problem& q = gp.p[it.pi];
+  const int m0 = it.tm * MT, n0 = it.tn * 256;
+  if (gp.debug & 8) { if (acc.a[0][0][0][0] == 12345.f) ((float*)q.C)[0] = 1.f; }      // ablation (MMDIT_GEMM_DEBUG=8): no epilogue
+  else if constexpr (EPI == EPI_BF16) epi8_bf16<MT>(acc, q, gp, m0, n0, wr, wc, lane, stage);
+  else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT>(acc, q, m0, it.tn, wr, wc, lane, stage);
+  else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[it.pi & 1], m0, n0, wr, wc, lane, stage);
+  else {
+    if (it.atomic && gp.ws_slots) {
+      // partial tile of the split tail through the workspace (gemm_lean.hip gemm_kk_kernel: slot store, ticket, the last slice sums)
+      constexpr int TE = 256 * 256, NW = 8;
+      const int tt = it.tile - gp.full_tiles, S = gp.split_k;
+      float* slots = gp.ws_slots + (int64_t)tt * S * TE;
+      epi8_f32_slot<MT>(acc, slots + (int64_t)it.sk * TE, wr, wc, lane, stage);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) *s_ticket = atomicAdd(gp.ws_count + tt, 1);
+      __syncthreads();
+      if (*s_ticket == S - 1) {
+        float* C = (float*)q.C;
+        constexpr int NCH = TE / 4 / (64 * NW);
+#pragma unroll 1
+        for (int b0 = 0; b0 < NCH; b0 += 4) {
+          f32x4 tsum[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) tsum[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+          for (int s0 = 0; s0 < S; s0 += 4) {
+            f32x4 v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+              const int idx = tid + (b0 + u) * (64 * NW), r = idx / 64, c = (idx % 64) * 4;
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const float* src = slots + (int64_t)min(s0 + k, S - 1) * TE + (int64_t)r * 256 + c;
+                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u][k]) : "v"(src) : "memory");
+              }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+              asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory");
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+              for (int k = 0; k < 4; k++)
+                if (s0 + k < S) tsum[u] += v[u][k];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int idx = tid + (b0 + u) * (64 * NW), r = idx / 64, c = (idx % 64) * 4;
+            if (m0 + r < q.M && n0 + c < q.N) {
+              float* cp = C + (int64_t)(m0 + r) * q.ldc + n0 + c;
+              if (gp.accumulate) tsum[u] += *(const f32x4*)cp;
+              __builtin_nontemporal_store(tsum[u], (f32x4*)cp);
+            }
+          }
+        }
+        if (tid == 0) gp.ws_count[tt] = 0;
+      }
+      __syncthreads();
+    } else {
+      epi8_f32<MT>(acc, q, m0, n0, wr, wc, lane, stage, it.atomic, gp.accumulate != 0);
+    }
+  }
+  };
+
+  Item item = item_at(gp, pos, end), prev = item;
+  bool pending = false;
   while (item.valid) {
     item_setup(item);
+    if (nkt > 0) {
+      // prologue: K tile 0 whole, three half-tiles of K tile 1 (in the order the loop continues; second argument: K tiles ahead)
+      if (REREAD) { stageA(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageB(0, 0, 0); stageA(0, 1, 1); stageB(1, 1, 1); stageA(1, 1, 1); }
+      else { stageA(0, 0, 0); stageB(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageA(0, 1, 1); stageB(0, 1, 1); stageB(1, 1, 1); }
+    }
+    if (DEFER && pending) run_epilogue(prev);
 #pragma unroll
     for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -544,11 +634,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 #pragma unroll
         for (int i = 0; i < 2 * FI; i++) acc.a[a][b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (nkt > 0) {
-      // prologue: K tile 0 whole, three half-tiles of K tile 1 (in the order the loop continues)
-      if (REREAD) { stageA(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageB(0, 0, 0); stageA(0, 1, 1); stageB(1, 1, 1); stageA(1, 1, 1); }
-      else { stageA(0, 0, 0); stageB(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageA(0, 1, 1); stageB(0, 1, 1); stageB(1, 1, 1); }
-      // (second argument: K tiles ahead of the one being multiplied)
-      wait3();
+      wait3();                     // (DEFER: the epilogue's stores are younger than every request -- this also waits for all but a few of them)
       BAR8();
       if (wr == 1) BAR8();         // group 1 runs one barrier behind from here on
       int t = 0;
@@ -562,72 +648,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       if (wr == 0) BAR8();         // rejoin
       BAR8();                      // every wave's requests have landed and every wave has left the operand buffers
     }
-    // ---- epilogue ---------------------------------------------------------------------------------------------------------------------
-    const Problem& q = gp.p[item.pi];
-    const int m0 = item.tm * MT, n0 = item.tn * 256;
-    if constexpr (EPI == EPI_BF16) epi8_bf16<MT>(acc, q, gp, m0, n0, wr, wc, lane, stage);
-    else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT>(acc, q, m0, item.tn, wr, wc, lane, stage);
-    else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[item.pi & 1], m0, n0, wr, wc, lane, stage);
+    if (DEFER) { prev = item; pending = true; }
     else {
-      if (item.atomic && gp.ws_slots) {
-        // partial tile of the split tail through the workspace (gemm_lean.hip gemm_kk_kernel: slot store, ticket, the last slice sums)
-        constexpr int TE = 256 * 256, NW = 8;
-        const int tt = item.tile - gp.full_tiles, S = gp.split_k;
-        float* slots = gp.ws_slots + (int64_t)tt * S * TE;
-        epi8_f32_slot<MT>(acc, slots + (int64_t)item.sk * TE, wr, wc, lane, stage);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) *s_ticket = atomicAdd(gp.ws_count + tt, 1);
-        __syncthreads();
-        if (*s_ticket == S - 1) {
-          float* C = (float*)q.C;
-          constexpr int NCH = TE / 4 / (64 * NW);
-#pragma unroll 1
-          for (int b0 = 0; b0 < NCH; b0 += 4) {
-            f32x4 tsum[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) tsum[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-            for (int s0 = 0; s0 < S; s0 += 4) {
-              f32x4 v[4][4];
-#pragma unroll
-              for (int u = 0; u < 4; u++) {
-                const int idx = tid + (b0 + u) * (64 * NW), r = idx / 64, c = (idx % 64) * 4;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                  const float* src = slots + (int64_t)min(s0 + k, S - 1) * TE + (int64_t)r * 256 + c;
-                  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u][k]) : "v"(src) : "memory");
-                }
-              }
-#pragma unroll
-              for (int u = 0; u < 4; u++)
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[u][0]), "+v"(v[u][1]), "+v"(v[u][2]), "+v"(v[u][3])::"memory");
-#pragma unroll
-              for (int u = 0; u < 4; u++)
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                  if (s0 + k < S) tsum[u] += v[u][k];
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-              const int idx = tid + (b0 + u) * (64 * NW), r = idx / 64, c = (idx % 64) * 4;
-              if (m0 + r < q.M && n0 + c < q.N) {
-                float* cp = C + (int64_t)(m0 + r) * q.ldc + n0 + c;
-                if (gp.accumulate) tsum[u] += *(const f32x4*)cp;
-                __builtin_nontemporal_store(tsum[u], (f32x4*)cp);
-              }
-            }
-          }
-          if (tid == 0) gp.ws_count[tt] = 0;
-        }
-        __syncthreads();
-      } else {
-        epi8_f32<MT>(acc, q, m0, n0, wr, wc, lane, stage, item.atomic, gp.accumulate != 0);
-      }
+      run_epilogue(item);
+      if (MT != 256) BAR8();       // (the staging lives in the operand buffers the next prologue overwrites)
     }
     item = item_at(gp, item.pos + G, end);
-    if (MT != 256) BAR8();         // (the staging lives in the operand buffers the next prologue overwrites)
   }
+  if (DEFER && pending) run_epilogue(prev);
 }
 
 template <int MT, bool A_KM, bool B_KM, int EPI>

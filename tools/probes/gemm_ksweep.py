@@ -30,7 +30,7 @@ def timed(fn):
 
 
 for kind in ("fwd", "dgrad"):
-    for N in (768, 2304, 3072):
+    for N in (768, 2304, 6144):
         pts = []
         for K in (128, 256, 512, 768, 1536, 3072, 6144):
             A = rnd(M, K)
