@@ -8,6 +8,12 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+def experiment(name: str, default: str) -> str:
+    """A/B experiment switch (the fused-vs-unfused, schedule and layout switches listed in tools/README.md).  They are read ONLY when
+    MMDIT_EXPERIMENTS=1 is set: the product has one path per operation, the switches exist for same-box A/B measurements."""
+    return os.environ.get(name, default) if os.environ.get("MMDIT_EXPERIMENTS") == "1" else default
+
+
 LIB_PATH = os.environ.get("MMDIT_LIB") or os.path.join(_HERE, "libmmdit_hip.so")   # MMDIT_LIB: A/B a scratch build
 HEADER_PATH = os.path.join(_HERE, "..", "include", "mmdit_hip.h")
 

@@ -631,440 +631,9 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// forward, persistent: the LDS-DMA kernel above as a loop over work items (q-tile, batch-head).  Ablations of that kernel at
-// S = 410 (tools/probes/attn_ablate.py): 69 us in full, 26 us with an EMPTY tile loop -- 7.6 us to launch 1536 workgroups, 12 us of
-// workgroups waiting for their first K/V tiles and Q rows (three rounds of HBM latency with nothing else resident to hide them),
-// 6.5-11 us of output stores.  Here 2 workgroups per CU stay resident and walk the items; the DMA cursor runs ahead across item
-// boundaries (the first three tiles of the next item land while the last tiles of this one are multiplied), the next item's Q
-// fragments are requested as soon as the last K Q^T of the current one has issued, and the output stores of an item drain under
-// the next item's MFMAs.
-// MEASURED (S = 410, 64 x 12 heads): 71.6 us against 69.7 us for the one-shot kernel on the same box -- the "fixed" costs of the
-// ablation are not additive: with two workgroups per CU they were already hidden behind the other workgroup's tiles.  What is left
-// is the per-wave dependent chain (fragment reads -> K Q^T -> max/exp/sum -> P V), which more residency does not shorten.  Kept
-// selectable (MMDIT_ATTN_DMA=3) as the record of that experiment; not the default.
-// ------------------------------------------------------------------------------------------------
-template <int DBG = 0>
-__global__ __launch_bounds__(512, 4) void attn_fwd_pers_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
-                                                            int BH, int H, int S, int n_img, float scale,
-                                                            bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse) {
-  constexpr int NW = 8;
-  __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  MMDIT_YOUNG_HALF_PRIO();
-  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
-  const int ntile = (S + 32 * NW - 1) / (32 * NW), items = ntile * BH, G = (int)gridDim.x;
-  const int nkv = (S + KT - 1) / KT;
-  // item v = blockIdx + k G -> (q-tile, batch-head): as map_block on the virtual index (G is a multiple of 8, so v keeps the block's
-  // XCD), with the q-tile rotated by the pass k and by the upper half of the grid: the last q-tile of a sequence is partial (S = 410:
-  // 5 of 8 waves busy), and a workgroup -- and the two workgroups of a CU -- should see full and partial tiles in turn
-  const bool rot = BH % 8 == 0 && (G & 15) == 0 && (G >> 4) % ntile == 0;
-  auto item_at = [&](int v, int& tile, int& bh) {
-    if (BH % 8 == 0) {
-      const int xcd = v & 7, j = v >> 3;
-      tile = j % ntile;
-      if (rot) tile = (tile + v / G + (2 * (v % G) >= G ? 1 : 0)) % ntile;
-      bh = (j / ntile) * 8 + xcd;
-    } else {
-      tile = v % ntile;
-      bh = v / ntile;
-    }
-    tile = __builtin_amdgcn_readfirstlane(tile);   // (the division runs on the VALU: tell the compiler the results are uniform)
-    bh = __builtin_amdgcn_readfirstlane(bh);
-  };
-
-  // ---- DMA cursor (wave-uniform): the next K/V tile to request ---------------------------------------------------
-  // this lane's part of a tile: key row 8 * wave + (lane >> 3), 16-byte slot lane & 7
-  const int rl = 8 * wave + (lane >> 3), slot = lane & 7;
-  const int kcol2 = (slot ^ ((rl >> 1) & 7)) * 16, vcol2 = (slot ^ (4 * ((rl >> 1) & 1))) * 16;   // byte column inside the 128-byte row
-  int c_item = (int)blockIdx.x, c_j = 0;
-  const char *cK, *cV;   // wave-uniform bases of the cursor's item (SGPRs; the lane part is a 32-bit offset)
-  auto cursor_item = [&]() {
-    int t, bh;
-    item_at(c_item, t, bh);
-    cK = (const char*)(K + (int64_t)bh * S * HD);
-    cV = (const char*)(V + (int64_t)bh * S * HD);
-  };
-  cursor_item();
-  auto issue_next = [&](int stage) {
-    const uint32_t row = (uint32_t)min(c_j * KT + rl, S - 1) * (HD * 2);
-    attn_glds16s(row + kcol2, cK, lds0 + stage * (2 * KT * 128) + wave * 1024);
-    attn_glds16s(row + vcol2, cV, lds0 + stage * (2 * KT * 128) + KT * 128 + wave * 1024);
-    if (c_j + 1 < nkv) {
-      c_j++;
-    } else if (c_item + G < items) {
-      c_item += G;
-      c_j = 0;
-      cursor_item();
-    }   // else: past the end of the stream the last tile is requested again (into a free stage; never read)
-  };
-#pragma unroll
-  for (int st = 0; st < ANS - 1; st++) issue_next(st);
-
-  bf16x8 qf[4];
-  auto load_q = [&](int v) {   // plain loads: the compiler tracks them (its waits over-count the untracked DMA traffic: safe)
-    int t, bh;
-    item_at(v, t, bh);
-    const int qc = min(t * 32 * NW + wave * 32 + (lane & 31), S - 1);
-    const bf16_t* src = Q + ((int64_t)bh * S + qc) * HD + (lane >> 5) * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(src + ks * 16);
-  };
-  load_q((int)blockIdx.x);
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
-
-  const float c = scale * LOG2E;
-  // per-lane LDS offsets of the fragment reads (see attn_fwd_dma_kernel); the k-step / feature-half only flips address bits 5-6,
-  // so one offset per operand is kept and the others are formed with an XOR
-  uint32_t kofs0, vofs0;
-  {
-    const int l31 = lane & 31, hi5 = lane >> 5, swz = (l31 >> 1) & 7, f = swz >> 1, e = hi5 ^ (swz & 1);
-    kofs0 = l31 * 128 + (f << 5) + (e << 4);
-    const int rr = (lane & 15) >> 2, x = (lane >> 4) & 1, y = lane & 3, bb = (rr >> 1) & 1;
-    vofs0 = KT * 128 + (4 * hi5 + rr) * 128 + (bb << 6) + (x << 5) + ((y >> 1) << 4) + ((y & 1) << 3);
-  }
-  const int n_txt = S - n_img, D = H * HD;
-  int stage = 0, v = (int)blockIdx.x, j = 0, qtile, bh;
-  item_at(v, qtile, bh);
-  f32x16 o[2];
-#pragma unroll
-  for (int db = 0; db < 2; db++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) o[db][r] = 0.f;
-  float m = -INFINITY, l = 0.f;
-#pragma unroll 1
-  for (;;) {   // one K/V tile per iteration, items back to back
-    // Tile j has landed once at most the two younger tiles are outstanding.  (At an item's first tile the queue also holds the
-    // previous item's output stores -- gfx9 counts stores in vmcnt -- all younger than the tiles: the same count over-waits.)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ANS - 2)) : "memory");
-    __builtin_amdgcn_s_barrier();                              // ... for every wave; and everyone has left the previous tile
-    issue_next(stage == 0 ? ANS - 1 : stage - 1);              // refill the stage of the previous tile
-    const bool active = qtile * 32 * NW + wave * 32 < S;       // wave-uniform
-    const bool last = j == nkv - 1, more = v + G < items;
-    const uint32_t tb = (uint32_t)(stage * (2 * KT * 128));
-    const char* kp[4] = {smem + (tb + kofs0), smem + (tb + (kofs0 ^ 32)), smem + (tb + (kofs0 ^ 64)), smem + (tb + (kofs0 ^ 96))};
-    const char* vp[2] = {smem + (tb + vofs0), smem + (tb + (vofs0 ^ 64))};
-    f32x16 s[2];
-    if (active) {
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++) {
-        if (j * KT + kb * 32 >= S) {
-#pragma unroll
-          for (int r = 0; r < 16; r++) s[kb][r] = -INFINITY;
-          continue;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*LDS_PTR(const bf16x8, kp[ks] + kb * 32 * 128), qf[ks], s[kb], 0, 0, 0);
-        if ((j + 1) * KT > S) {
-#pragma unroll
-          for (int r = 0; r < 16; r++)
-            if (j * KT + kb * 32 + acc_row(r, lane) >= S) s[kb][r] = -INFINITY;
-        }
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[kb][r]);
-      mx = fmaxf(mx, partner32(mx, lane)) * c;   // the two lanes of a query (l, l + 32)
-      // the accumulators are rescaled only when some query's running maximum grows (exact: alpha == 1 otherwise)
-      if (!__all(mx <= m)) {
-        const float mn = fmaxf(m, mx);
-        const float alpha = fast_exp2(m - mn);
-        l *= alpha;
-        m = mn;
-#pragma unroll
-        for (int db = 0; db < 2; db++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) o[db][r] *= alpha;
-      }
-      float rs = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) { const float p = fast_exp2(fmaf(s[kb][r], c, -m)); s[kb][r] = p; rs += p; }
-      l += rs + partner32(rs, lane);
-    }
-    // the Q fragments are dead: the next item's travel under the P V MFMAs (one load site for every wave, into the same registers;
-    // after the last item the current rows are simply read again)
-    if (last) load_q(more ? v + G : v);
-    if (active) {
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-        if (j * KT + kb * 32 < S)
-#pragma unroll
-          for (int h8 = 0; h8 < 2; h8++) {
-            const bf16x8 pf = pack_frag(s[kb], h8);
-#pragma unroll
-            for (int db = 0; db < 2; db++) {
-              const char* q0 = vp[db] + (kb * 32 + 16 * h8) * 128;
-              const s16x4 lo = lds_tr16(q0), hi = lds_tr16(q0 + 8 * 128);
-              const s16x8 vr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vr), pf, o[db], 0, 0, 0);
-            }
-          }
-    }
-    const int this_stage = stage;
-    stage = stage + 1 == ANS ? 0 : stage + 1;
-    if (!last) {
-      j++;
-      continue;
-    }
-    // ---- end of an item --------------------------------------------------------------------------------------------
-    // The compiler's wait for the Q loads is forced HERE (queue: the tile requested at the top of this iteration, then Q), ahead of
-    // the output stores, so that it never has to wait for a store or for a tile that was only just requested.
-    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
-    // Epilogue.  The accumulators hold O^T fragments (lane = query, 4 consecutive features per register group); stored directly,
-    // every instruction would touch 32 rows with 8 bytes each.  Each wave stages its block through a private 2 KB of the stage
-    // of the item's LAST tile (idle once every wave has left it: the barrier below; refilled only after the next barrier), one
-    // 32-feature half at a time -- 16-byte chunk c of row r at chunk c ^ ((r >> 2) & 3) -- and writes 16 rows x 64 B per instruction.
-    __builtin_amdgcn_s_barrier();
-    if (active) {
-      const float inv = 1.f / l;
-      const int h = bh % H;
-      const int64_t b = bh / H;
-      char* stg = smem + this_stage * (2 * KT * 128) + wave * 2048;
-      const int wr = lane & 31, wc = lane >> 5, rr = lane >> 2, rc = lane & 3;
-#pragma unroll
-      for (int db = 0; db < 2; db++) {
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          const u32x2 pk = {pack_bf2(o[db][g * 4] * inv, o[db][g * 4 + 1] * inv), pack_bf2(o[db][g * 4 + 2] * inv, o[db][g * 4 + 3] * inv)};
-          *LDS_PTR(u32x2, stg + wr * 64 + ((g ^ ((wr >> 2) & 3)) << 4) + wc * 8) = pk;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
-        u32x4 t[2];
-#pragma unroll
-        for (int it = 0; it < 2; it++) { const int r = it * 16 + rr; t[it] = *LDS_PTR(const u32x4, stg + r * 64 + ((rc ^ ((r >> 2) & 3)) << 4)); }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... before the second half overwrites the block
-#pragma unroll
-        for (int it = 0; it < 2; it++) {
-          const int qq = qtile * 32 * NW + wave * 32 + it * 16 + rr;
-          if (qq < S) {
-            bf16_t* dst = qq < n_img ? Ox + ((b * n_img + qq) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (qq - n_img)) * (int64_t)D + h * HD);
-            *(u32x4*)(dst + db * 32 + rc * 8) = t[it];
-          }
-        }
-      }
-      const int q = qtile * 32 * NW + wave * 32 + (lane & 31);
-      if (q < S && lane < 32) lse[(int64_t)bh * S + q] = m * LN2 + logf(l);
-    }
-    if (!more) break;
-    v += G;
-    j = 0;
-    item_at(v, qtile, bh);
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) o[db][r] = 0.f;
-    m = -INFINITY;
-    l = 0.f;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (unused) DMA pieces must land before the LDS is released
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward, 64 queries per wave (fast mode): 4 waves per workgroup (one per SIMD) = 256 queries, two workgroups per CU.
-// The 32-query-per-wave kernels above spend their time in dependent chains (PMC: waves 25 % issuing, 42 % parked at waits /
-// barriers, 33 % issue-stalled; MFMA 20 % busy): every MFMA of a wave waits for the previous one on the same accumulator and for
-// an LDS fragment read issued just before it.  Here a wave owns TWO 32-query blocks: each K / V^T fragment read from LDS feeds two
-// MFMAs (half the LDS reads per FLOP), four accumulators are in flight per phase (s[qb][kb], then o[qb][db]) so consecutive
-// MFMAs are independent, and the two waves that share a SIMD belong to different workgroups (independent barriers), so one is
-// in its MFMA phase while the other runs its softmax.  K/V tiles: the LDS-DMA ring of attn_fwd_dma_kernel (swizzles as there).
-// ------------------------------------------------------------------------------------------------
-// TRACE (tools/probes/attn_trace.hip): lane 0 of every wave of the first 2048 workgroups records s_memtime at the phase boundaries
-template <bool TRACE>
-__global__ __launch_bounds__(256, 2) void attn_fwd_w64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
-                                                           int BH, int H, int S, int n_img, float scale,
-                                                           bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse, unsigned long long* __restrict__ trace) {
-  int tpos = 0;
-  auto stamp = [&]() {
-    if constexpr (TRACE) {
-      if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0 && tpos < 40) trace[((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 40 + tpos] = __builtin_readcyclecounter();
-      tpos++;
-    }
-  };
-  stamp();
-  constexpr int NW = 4, QW = 64;     // waves, queries per wave
-  __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  MMDIT_YOUNG_HALF_PRIO();
-  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
-  int qtile, bh;
-  map_block((S + QW * NW - 1) / (QW * NW), BH, qtile, bh);
-  const int h = bh % H;
-  const int64_t b = bh / H;
-  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
-  const bf16_t* Kb = K + (int64_t)bh * S * HD;
-  const bf16_t* Vb = V + (int64_t)bh * S * HD;
-  const int q0 = qtile * QW * NW + wave * QW;                 // first query of this wave
-  const int nqb = q0 >= S ? 0 : (q0 + 32 >= S ? 1 : 2);       // (wave-uniform) 32-query blocks of this wave that hold real queries
-
-  bf16x8 qf[2][4];
-#pragma unroll
-  for (int qb = 0; qb < 2; qb++) {
-    const int qc = min(q0 + qb * 32 + (lane & 31), S - 1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) qf[qb][ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the Q loads are the only compiler-visible loads: retire them before the DMA stream starts
-  stamp();
-
-  const int nkv = (S + KT - 1) / KT;
-  // this lane's part of a tile: every wave moves two 1-KiB pieces (8 key rows each) of K and two of V
-  uint32_t krow[2];
-  int kcol[2], vcol[2];
-#pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int rl = 8 * (wave * 2 + i) + (lane >> 3), slot = lane & 7;
-    krow[i] = rl;
-    kcol[i] = (slot ^ ((rl >> 1) & 7)) * 8;
-    vcol[i] = (slot ^ (4 * ((rl >> 1) & 1))) * 8;
-  }
-  auto issue = [&](int j, int stage) {
-    const int t0 = min(j, nkv - 1) * KT;
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int row = min(t0 + (int)krow[i], S - 1);
-      attn_glds16(Kb + (int64_t)row * HD + kcol[i], lds0 + stage * (2 * KT * 128) + (wave * 2 + i) * 1024);
-      attn_glds16(Vb + (int64_t)row * HD + vcol[i], lds0 + stage * (2 * KT * 128) + KT * 128 + (wave * 2 + i) * 1024);
-    }
-  };
-#pragma unroll
-  for (int st = 0; st < ANS - 1; st++) issue(st, st);
-
-  f32x16 o[2][2];
-#pragma unroll
-  for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-    for (int db = 0; db < 2; db++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) o[qb][db][r] = 0.f;
-  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
-  const float c = scale * LOG2E;
-  uint32_t kofs[4], vofs[2];   // per-lane LDS offsets of the fragment reads (see attn_fwd_dma_kernel)
-  {
-    const int l31 = lane & 31, hi5 = lane >> 5, swz = (l31 >> 1) & 7, f = swz >> 1, e = hi5 ^ (swz & 1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) kofs[ks] = l31 * 128 + ((ks ^ f) << 5) + (e << 4);
-    const int rr = (lane & 15) >> 2, x = (lane >> 4) & 1, y = lane & 3, bb = (rr >> 1) & 1;
-#pragma unroll
-    for (int db = 0; db < 2; db++) vofs[db] = KT * 128 + (4 * hi5 + rr) * 128 + ((db ^ bb) << 6) + (x << 5) + ((y >> 1) << 4) + ((y & 1) << 3);
-  }
-  int stage = 0;
-  for (int j = 0; j < nkv; j++) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (ANS - 2)) : "memory");   // tile j has landed (ANS-2 younger tiles, 4 pieces each, may be in flight)
-    stamp();
-    __builtin_amdgcn_s_barrier();
-    stamp();
-    issue(j + ANS - 1, stage == 0 ? ANS - 1 : stage - 1);
-    const char* tile = smem + stage * (2 * KT * 128);
-    stage = stage + 1 == ANS ? 0 : stage + 1;
-    if (nqb == 0) continue;
-    const int nkb = j * KT + 32 >= S ? 1 : 2;                   // (wave-uniform) key blocks of this tile with real keys
-    const bool ragged = (j + 1) * KT > S;
-    // ---- S^T = K Q^T: four independent accumulators, every K fragment feeds both query blocks
-    f32x16 s[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++)
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) s[qb][kb][r] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < 4; ks++) {
-      const bf16x8 k0 = *LDS_PTR(const bf16x8, tile + kofs[ks]);
-      s[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[0][ks], s[0][0], 0, 0, 0);
-      s[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[1][ks], s[1][0], 0, 0, 0);
-      if (nkb == 2) {
-        const bf16x8 k1 = *LDS_PTR(const bf16x8, tile + kofs[ks] + 32 * 128);
-        s[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[0][ks], s[0][1], 0, 0, 0);
-        s[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[1][ks], s[1][1], 0, 0, 0);
-      }
-    }
-    if constexpr (TRACE) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[1][0][0]), "v"(s[0][1][0]), "v"(s[1][1][0])); }
-    stamp();
-    // ---- online softmax per query block (the row statistics are lane-local up to the l / l+32 pair)
-#pragma unroll
-    for (int qb = 0; qb < 2; qb++) {
-      if (ragged || nkb == 1) {
-#pragma unroll
-        for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-          for (int r = 0; r < 16; r++)
-            if (j * KT + kb * 32 + acc_row(r, lane) >= S) s[qb][kb][r] = -INFINITY;
-      }
-      float mx = -INFINITY;
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[qb][kb][r]);
-      mx = fmaxf(mx, partner32(mx, lane)) * c;
-      if (!__all(mx <= m[qb])) {     // rescale only when some running maximum grows (exact: alpha == 1 otherwise)
-        const float mn = fmaxf(m[qb], mx);
-        const float alpha = fast_exp2(m[qb] - mn);
-        l[qb] *= alpha;
-        m[qb] = mn;
-#pragma unroll
-        for (int db = 0; db < 2; db++)
-#pragma unroll
-          for (int r = 0; r < 16; r++) o[qb][db][r] *= alpha;
-      }
-      float rs = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; kb++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) { const float pz = fast_exp2(fmaf(s[qb][kb][r], c, -m[qb])); s[qb][kb][r] = pz; rs += pz; }
-      l[qb] += rs + partner32(rs, lane);
-    }
-    if constexpr (TRACE) { asm volatile("" :: "v"(s[0][0][0]), "v"(s[1][0][0]), "v"(s[0][1][0]), "v"(s[1][1][0])); }
-    stamp();
-    // ---- O^T += V^T P^T: every V^T fragment feeds both query blocks
-#pragma unroll
-    for (int kb = 0; kb < 2; kb++) {
-      if (kb < nkb) {
-#pragma unroll
-        for (int h8 = 0; h8 < 2; h8++) {
-          const bf16x8 p0 = pack_frag(s[0][kb], h8), p1 = pack_frag(s[1][kb], h8);
-#pragma unroll
-          for (int db = 0; db < 2; db++) {
-            const char* a0 = tile + vofs[db] + (kb * 32 + 16 * h8) * 128;
-            const s16x4 lo = lds_tr16(a0), hi = lds_tr16(a0 + 8 * 128);
-            const s16x8 vr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            const bf16x8 vf = __builtin_bit_cast(bf16x8, vr);
-            o[0][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, p0, o[0][db], 0, 0, 0);
-            o[1][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, p1, o[1][db], 0, 0, 0);
-          }
-        }
-      }
-    }
-  }
-  if constexpr (TRACE) { asm volatile("" :: "v"(o[0][0][0]), "v"(o[1][0][0]), "v"(o[0][1][0]), "v"(o[1][1][0])); }
-  stamp();
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is released
-  const int n_txt = S - n_img, D = H * HD;
-#pragma unroll
-  for (int qb = 0; qb < 2; qb++) {
-    const int q = q0 + qb * 32 + (lane & 31);
-    if (q < S) {
-      const float inv = 1.f / l[qb];
-      bf16_t* dst = q < n_img ? Ox + ((b * n_img + q) * (int64_t)D + h * HD) : Oc + ((b * n_txt + (q - n_img)) * (int64_t)D + h * HD);
-#pragma unroll
-      for (int db = 0; db < 2; db++)
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          float v4[4] = {o[qb][db][g * 4] * inv, o[qb][db][g * 4 + 1] * inv, o[qb][db][g * 4 + 2] * inv, o[qb][db][g * 4 + 3] * inv};
-          st4(dst + db * 32 + 8 * g + 4 * (lane >> 5), v4);
-        }
-      if (lane < 32) lse[(int64_t)bh * S + q] = m[qb] * LN2 + logf(l[qb]);
-    }
-  }
-  if constexpr (TRACE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  stamp();
-}
+// (Two forward variants of round 2 -- a persistent one, 2 workgroups per CU walking the work items, 71.6 vs 69.7 us, and one with 64 queries
+//  per wave on 4 waves, 80 vs 74 us -- were measured slower and are not part of the library any more; their text is in the history of this
+//  file, commit cd8583f.)
 
 // ------------------------------------------------------------------------------------------------
 // backward dQ: query-stationary, loops over KV tiles.  dQ^T[hd][q] += K^T[hd][key] dS^T[key][q]
@@ -1425,11 +994,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 // backward 372 -> 271 us).  7-wave workgroups would pad S = 410 less (448 instead of 512 rows) but measured slower (forward 96 vs
 // 70 us: 448 threads copy a 512-chunk tile in two unbalanced passes).  MMDIT_ATTN_NW = 2 | 4 | 6 | 7 | 8 overrides for A/B runs.
 int attn_waves(int S) {
+  (void)S;
+#ifdef MMDIT_PROBES
   static const char* e = getenv("MMDIT_ATTN_NW");
   if (e) return atoi(e);
-  int best = 8, best_rows = 1 << 30;
-  (void)best_rows;
-  return best;
+#endif
+  return 8;
 }
 
 }  // namespace
@@ -1442,40 +1012,24 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
   const int nw = attn_waves(S);
 #define MMDIT_FWD(NW, OR) hipLaunchKernelGGL((attn_fwd_kernel<NW, OR>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                                              (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse)
-  static const char* dma_env = getenv("MMDIT_ATTN_DMA");
-  static const bool use_dma = !dma_env || atoi(dma_env) != 0;
-  if (mode == 1) MMDIT_FWD(2, true);
+  if (mode == 1) MMDIT_FWD(2, true);                 // the reference's rounding points (parity mode)
   else if (mode != 0) return MMDIT_ERR_ARG;
-  else if (use_dma && !getenv("MMDIT_ATTN_NW") && dma_env && atoi(dma_env) == 2)   // MMDIT_ATTN_DMA=2: the 64-queries-per-wave variant (measured 80 vs 74 us at S = 410: not the default)
-    hipLaunchKernelGGL(attn_fwd_w64_kernel<false>, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
-                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, nullptr);
-  else if (use_dma && !getenv("MMDIT_ATTN_NW") && dma_env && atoi(dma_env) == 3) {   // MMDIT_ATTN_DMA=3: the persistent variant (measured 71.6 vs 69.7 us: not the default)
-    const int items = ((S + 255) / 256) * batch * heads;
-    hipLaunchKernelGGL(attn_fwd_pers_kernel<0>, dim3(items < 512 ? items : 512), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
-                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
-  } else if (use_dma && !getenv("MMDIT_ATTN_NW"))
+#ifdef MMDIT_PROBES                                   // experiments: the register-staged kernel at a forced workgroup width (MMDIT_ATTN_DMA=0 / MMDIT_ATTN_NW)
+  else if ((getenv("MMDIT_ATTN_DMA") && atoi(getenv("MMDIT_ATTN_DMA")) == 0) || getenv("MMDIT_ATTN_NW")) {
+    if (nw == 8) MMDIT_FWD(8, false);
+    else if (nw == 7) MMDIT_FWD(7, false);
+    else if (nw == 6) MMDIT_FWD(6, false);
+    else if (nw == 4) MMDIT_FWD(4, false);
+    else MMDIT_FWD(2, false);
+  }
+#endif
+  else
     hipLaunchKernelGGL(attn_fwd_dma_kernel<0>, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
                        batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
-  else if (nw == 8) MMDIT_FWD(8, false);
-  else if (nw == 7) MMDIT_FWD(7, false);
-  else if (nw == 6) MMDIT_FWD(6, false);
-  else if (nw == 4) MMDIT_FWD(4, false);
-  else MMDIT_FWD(2, false);
 #undef MMDIT_FWD
   return mmdit_launch_status();
 }
 
-#ifdef MMDIT_PROBES   // probe entry points are not part of the product library: bash tools/build_variant.sh probes -DMMDIT_PROBES, then MMDIT_LIB=tools/scratch/probes/libmmdit_hip.so
-// measurement aid (tools/probes/attn_trace.py; not declared in include/mmdit_hip.h): the 64-queries-per-wave forward with per-phase
-// s_memtime stamps, trace = 2048 workgroups x 4 waves x 40 slots of 8 bytes
-extern "C" int mmdit_probe_attn_fwd_trace(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
-                                          void* Ox, void* Oc, float* lse, void* trace, mmdit_stream_t stream) {
-  hipLaunchKernelGGL(attn_fwd_w64_kernel<true>, dim3(((S + 255) / 256) * batch * heads), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K,
-                     (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse, (unsigned long long*)trace);
-  return mmdit_launch_status();
-}
-
-#endif
 
 extern "C" int mmdit_attn_fwd_mx(const void* Q, const void* K, const void* V, int batch, int heads, int S, int n_img, float scale,
                                  void* Ox_fp8, void* Oc_fp8, void* scales_x, void* scales_c, mmdit_stream_t stream) {
@@ -1553,16 +1107,14 @@ extern "C" int mmdit_attn_bwd(const void* Q, const void* K, const void* V, const
 #define MMDIT_DQ(NW, TG) hipLaunchKernelGGL((attn_bwd_dq_kernel<NW, TG>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(NW * 64), 0, s, (const bf16_t*)Q, (const bf16_t*)K, \
                                             (const bf16_t*)V, (const bf16_t*)Ox, (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (TG*)dQ)
   if (dq_dtype == MMDIT_BF16) {
-    if (nw == 8) MMDIT_DQ(8, bf16_t);
-    else if (nw == 7) MMDIT_DQ(7, bf16_t);
-    else if (nw == 6) MMDIT_DQ(6, bf16_t);
-    else if (nw == 4) MMDIT_DQ(4, bf16_t);
-    else MMDIT_DQ(2, bf16_t);
-    if (nw == 8) MMDIT_DKV(8, bf16_t);
-    else if (nw == 7) MMDIT_DKV(7, bf16_t);
-    else if (nw == 6) MMDIT_DKV(6, bf16_t);
-    else if (nw == 4) MMDIT_DKV(4, bf16_t);
-    else MMDIT_DKV(2, bf16_t);
+#ifdef MMDIT_PROBES      // experiments: other workgroup widths (MMDIT_ATTN_NW)
+    if (nw == 7) { MMDIT_DQ(7, bf16_t); MMDIT_DKV(7, bf16_t); }
+    else if (nw == 6) { MMDIT_DQ(6, bf16_t); MMDIT_DKV(6, bf16_t); }
+    else if (nw == 4) { MMDIT_DQ(4, bf16_t); MMDIT_DKV(4, bf16_t); }
+    else if (nw == 2) { MMDIT_DQ(2, bf16_t); MMDIT_DKV(2, bf16_t); }
+    else
+#endif
+    { MMDIT_DQ(8, bf16_t); MMDIT_DKV(8, bf16_t); }
   } else if (dq_dtype == MMDIT_F32) {
     MMDIT_DQ(2, float);
     MMDIT_DKV(2, float);

@@ -152,6 +152,18 @@ static inline int mmdit_launch_status() {
 }
 #define MMDIT_CHECK_ARG(c) do { if (!(c)) return MMDIT_ERR_ARG; } while (0)
 
+// Experiment switches (tile configuration, schedule and ablation overrides of the GEMM / row kernels: the MMDIT_GEMM_* / MMDIT_QK_* variables of
+// tools/README.md) exist only in -DMMDIT_PROBES builds (tools/build_variant.sh); the product library has ONE path per launch.
+#include <stdlib.h>
+static inline const char* mmdit_exp_env(const char* name) {
+#ifdef MMDIT_PROBES
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // Per-device "done once" cache for host-side launch set-up (hipFuncSetAttribute of > 64 KB dynamic LDS is a per-device property; one
 // process normally drives one GPU, but a second device must not inherit the first one's flag).  Returns true when `done` already
 // holds the current device's bit; mark with mmdit_device_mark.  A benign race only repeats the idempotent call.

@@ -258,9 +258,9 @@ static void* g_ws[64] = {};
 static long long g_ws_bytes[64] = {};
 
 static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k, bool lean_ok) {
-  static const char* force = getenv("MMDIT_GEMM_CFG");
+  static const char* force = mmdit_exp_env("MMDIT_GEMM_CFG");
   if (force) return atoi(force) == CFG_320x256 && !lean_ok ? CFG_256x256 : atoi(force);
-  static const char* force_epi = getenv("MMDIT_GEMM_CFG_EPI");   // experiments: tile configuration of the gated-residual (fp32 C) launches only
+  static const char* force_epi = mmdit_exp_env("MMDIT_GEMM_CFG_EPI");   // experiments: tile configuration of the gated-residual (fp32 C) launches only
   if (force_epi && args[0].gate) return atoi(force_epi);
   if (stream_k) return CFG_256x256;   // no quantisation with stream-K: take the fewest bytes per FLOP
   // Wave quantisation decides (measured, tools/gemm_bench.py): a "round" of 128x128 tiles (2 workgroups per CU)
@@ -301,8 +301,8 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   int aux_dt = -1;
   // LDS-DMA fast path: bf16 operands, every K a multiple of the 64-wide K-tile (MMDIT_GEMM_NO_DMA=1 forces
   // the register-staged kernel, for A/B measurements)
-  static const bool no_dma = getenv("MMDIT_GEMM_NO_DMA") != nullptr;
-  static const char* raster_env = getenv("MMDIT_GEMM_RASTER");
+  static const bool no_dma = mmdit_exp_env("MMDIT_GEMM_NO_DMA") != nullptr;
+  static const char* raster_env = mmdit_exp_env("MMDIT_GEMM_RASTER");
   // fp8 (e4m3) operands: DMA kernel only, row-major x row-major, K a multiple of the 128-wide fp8 K-tile, per-tensor scales
   const bool fp8 = a0->a_dtype == MMDIT_FP8 || a0->b_dtype == MMDIT_FP8;
   bool dma = !no_dma && a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16;
@@ -361,11 +361,11 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   }
   int bm = BM, bn = BN, cfg = CFG_128x128;
   // stream-K for the weight gradients (k-major A): fp32 C must be pre-zeroed by the caller (a0->stream_k)
-  static const bool no_sk = getenv("MMDIT_GEMM_NO_STREAMK") != nullptr;
+  static const bool no_sk = mmdit_exp_env("MMDIT_GEMM_NO_STREAMK") != nullptr;
   const bool stream_k = dma && !no_sk && a0->stream_k && a0->c_dtype == MMDIT_F32 && split_k == 1 && a0->act == MMDIT_ACT_NONE && !a0->accumulate;
   // lean hot-path kernel (gemm_lean.hip): bf16 row-major A, bf16 output, bias / SiLU epilogue only.  MMDIT_GEMM_LEAN=0: never;
   // 2: only where it offers the 320x256 tile; 1 (default): also for 256x256 launches
-  static const char* lean_env = getenv("MMDIT_GEMM_LEAN");
+  static const char* lean_env = mmdit_exp_env("MMDIT_GEMM_LEAN");
   static const int lean_mode = lean_env ? atoi(lean_env) : 1;
   bool lean_ok = dma && lean_mode > 0 && !fp8 && !conv && !stream_k && split_k == 1 && !a0->a_kmajor && a0->c_dtype == MMDIT_BF16 &&
                  (a0->act == MMDIT_ACT_NONE || a0->act == MMDIT_ACT_SILU || swiglu) && !a0->accumulate;
@@ -382,7 +382,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   int tiles = 0, units = 0;
   // K-decomposed launches take the problems longest-K first: the tiles of the first round are then ordered long -> short and the
   // balanced tail below can hand the split leftovers to the workgroups that finish their first tile early
-  static const char* kdec_env = getenv("MMDIT_GEMM_KDEC");
+  static const char* kdec_env = mmdit_exp_env("MMDIT_GEMM_KDEC");
   static const bool kdec_streamk = kdec_env && kdec_env[0] == 's', kdec_plain = kdec_env && kdec_env[0] == 'p';
   int order[MAXG];
   for (int i = 0; i < count; i++) order[i] = i;
@@ -435,7 +435,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
         const double c = (double)((r * S + G - 1) / G) / S + (S > 1 ? 0.0028 * r * S : 0.0);
         if (c < best) { best = c; tail_split = S; }
       }
-      static const char* ts_env = getenv("MMDIT_GEMM_TAIL_S");   // experiments: force the K split of the tail tiles
+      static const char* ts_env = mmdit_exp_env("MMDIT_GEMM_TAIL_S");   // experiments: force the K split of the tail tiles
       const int ts_force = ts_env ? atoi(ts_env) : 0;
       if (ts_force > 0 && ts_force * 2 <= nk_min) { tail_split = ts_force; best = -1.0; }
       // Balanced tail (one full round, problems of different K): in the first round the tiles of the shorter problems finish
@@ -462,13 +462,13 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
       }
     }
   }
-  static const bool no_persist = getenv("MMDIT_GEMM_NO_PERSIST") != nullptr;
+  static const bool no_persist = mmdit_exp_env("MMDIT_GEMM_NO_PERSIST") != nullptr;
   gp.persistent = !no_persist;
   if (aux_dt < 0) aux_dt = a0->c_dtype == MMDIT_FP8 ? MMDIT_BF16 : a0->c_dtype;
   gp.count = count; gp.total_tiles = tiles; gp.act = a0->act; gp.accumulate = a0->accumulate; gp.split_k = tail_split; gp.full_tiles = full_tiles;
-  static const char* debug_env = getenv("MMDIT_GEMM_DEBUG");   // ablation bits (tools/gemm_ablate.py): 2 = operand stream only (no LDS reads / MFMA), 8 = no epilogue, 64 = no bf16 fast epilogue
+  static const char* debug_env = mmdit_exp_env("MMDIT_GEMM_DEBUG");   // ablation bits (tools/gemm_ablate.py): 2 = operand stream only (no LDS reads / MFMA), 8 = no epilogue, 64 = no bf16 fast epilogue
   gp.debug = debug_env ? atoi(debug_env) : 0;
-  static const char* epi_env = getenv("MMDIT_GEMM_EPI");
+  static const char* epi_env = mmdit_exp_env("MMDIT_GEMM_EPI");
   gp.epi_direct = epi_env ? (atoi(epi_env) == 0) : 0;
   gp.raster = raster_env ? atoi(raster_env) : 8;   // n-tiles per rasterization group (see locate_tile)
   if (split_k > 1) {
@@ -478,7 +478,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   }
   // lean weight-gradient kernel (gemm_lean.hip, gemm_kk_kernel): both operands k-major, fp32 C, 256x256 tiles, the round + tail (or
   // caller-split) schedule, nothing but store / accumulate / atomic add in the epilogue.  MMDIT_GEMM_KK=0: the general kernel.
-  static const char* kk_env = getenv("MMDIT_GEMM_KK");
+  static const char* kk_env = mmdit_exp_env("MMDIT_GEMM_KK");
   bool kk = dma && (!kk_env || atoi(kk_env)) && !fp8 && !conv && !gp.stream_k && cfg == CFG_256x256 && a0->a_kmajor && a0->b_kmajor &&
             a0->c_dtype == MMDIT_F32 && a0->act == MMDIT_ACT_NONE;
   for (int i = 0; i < count && kk; i++) {
@@ -522,7 +522,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     *zero_mask = mask;
   }
   // the 8-phase kernel (gemm8p.hip) takes every 256x256 launch of the lean kernels; MMDIT_GEMM_8P=0: the round-2/3 kernels of gemm_lean.hip
-  static const char* p8_env = getenv("MMDIT_GEMM_8P");
+  static const char* p8_env = mmdit_exp_env("MMDIT_GEMM_8P");
   static const int p8_mode = p8_env ? atoi(p8_env) : 1;      // 1: every lean launch; 2: only the 256x256 ones
   // (the QKV launch with the QK-norm / RoPE epilogue stays on the wide kernel at 320 rows: with that epilogue's registers the 320-row 8-phase
   //  variant measured slower, 1.73 vs 1.59 ms per step)

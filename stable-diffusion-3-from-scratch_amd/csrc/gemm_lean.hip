@@ -37,6 +37,7 @@ __device__ __forceinline__ TileRef tile_at(const GroupParams& gp, int pos) {
 
 __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+#ifdef MMDIT_PROBES      // the ring-of-halves kernel of round 2: superseded by the wide-slot kernel below and by gemm8p.hip; A/B builds only
 template <int WM, int WN, int MI, int NJ, bool B_KM, bool SWIGLU = false>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_lean_kernel(GroupParams gp) {
   static_assert(!SWIGLU || (!B_KM && WN == 4 && NJ == 2), "SwiGLU epilogue: row-major packed weight, 256-column tile");
@@ -220,6 +221,8 @@ int launch_lean(const GroupParams& gp, hipStream_t s) {
   return mmdit_launch_status();
 }
 
+
+#endif   // MMDIT_PROBES
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Wide-slot variant of the lean kernel: same tiles / waves / epilogues, but a ring slot is a whole 64-wide K step and the ring is
@@ -406,6 +409,7 @@ int launch_wide(const GroupParams& gp, hipStream_t s) {
   return mmdit_launch_status();
 }
 
+#ifdef MMDIT_PROBES      // the weight-gradient kernel of round 3: superseded by gemm8_kernel<256, true, true, f32> (gemm8p.hip); A/B builds only
 // ------------------------------------------------------------------------------------------------------------------------------
 // Lean weight-gradient kernel: C[M,N] (fp32) = A^T B with BOTH operands k-major (A [K,M], B [K,N] row-major: dW = dY^T X), the
 // K-decomposed schedule of gemm.hip (whole-K tiles in rounds + a split tail whose partial tiles are added atomically into a
@@ -722,25 +726,34 @@ int launch_kk(const GroupParams& gp, hipStream_t s) {
   int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
   // experiments (MMDIT_WGRAD_STREAM=1): leave CUs to the kernels of the main stream; only without the balanced tail (MMDIT_GEMM_KDEC=plain),
   // whose unit -> workgroup map is built for 256 workgroups
-  static const char* g_env = getenv("MMDIT_GEMM_KK_GRID");
+  static const char* g_env = mmdit_exp_env("MMDIT_GEMM_KK_GRID");
   if (g_env && gp.tail_first < 0 && atoi(g_env) > 0 && atoi(g_env) < grid) grid = atoi(g_env);
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gp);
   return mmdit_launch_status();
 }
 
+#endif   // MMDIT_PROBES
+
 }  // namespace
 
-// C fp32 = A^T B, both operands k-major, 256x256 tiles, no bias / gate / residual / aux / activation (gemm.hip has checked that)
-int gemm::launch_lean_wgrad(const GroupParams& gp, hipStream_t s) { return launch_kk(gp, s); }
+// The product library launches ONE kernel of this file: the wide-slot kernel at 320 x 256 with the QKV epilogue (QK-RMSNorm + RoPE + joint-layout
+// store) -- every other launch of the lean family goes to the 8-phase kernels of gemm8p.hip.  -DMMDIT_PROBES builds (tools/build_variant.sh) keep the
+// kernels of rounds 2-3 selectable for same-box A/B runs (MMDIT_GEMM_8P=0 / 2, MMDIT_GEMM_WIDE=0, MMDIT_GEMM_KK=0).
+int gemm::launch_lean_wgrad(const GroupParams& gp, hipStream_t s) {
+#ifdef MMDIT_PROBES
+  return launch_kk(gp, s);
+#else
+  (void)gp; (void)s;
+  return MMDIT_ERR_SHAPE;
+#endif
+}
 
 int gemm::launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t s) {
-  // wide-slot variant (128-byte DMA rows, double buffer): default; MMDIT_GEMM_WIDE=0 selects the 4-slot ring of 32-wide halves.
-  // Measured on the MMDiT-B shapes (tools/gemm_bench.py): out-proj 37.6 -> 34.7 us, w3 113 -> 106 / 123 -> 117 us, qkv 117.5 -> 114 us,
-  // w12 dgrad 228 -> 222 us, 8192^3 1218 -> 1247 TF; the step 31.36 -> 31.19 ms.
+  if (gp.qk_on && cfg == CFG_320x256 && !b_km && gp.act == MMDIT_ACT_NONE) return launch_wide<2, 4, 5, 2, false, false, true>(gp, s);
+#ifdef MMDIT_PROBES
   static const char* wide_env = getenv("MMDIT_GEMM_WIDE");
-  if (gp.qk_on) {   // QKV projection with the QK-norm + RoPE + joint-layout store in the epilogue: wide-slot kernel only
+  if (gp.qk_on) {
     if (b_km || gp.act != MMDIT_ACT_NONE || (wide_env && !atoi(wide_env))) return MMDIT_ERR_SHAPE;
-    if (cfg == CFG_320x256) return launch_wide<2, 4, 5, 2, false, false, true>(gp, s);
     if (cfg == CFG_256x256) return launch_wide<2, 4, 4, 2, false, false, true>(gp, s);
     return MMDIT_ERR_SHAPE;
   }
@@ -755,7 +768,7 @@ int gemm::launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t
     if (cfg == CFG_256x256) return b_km ? launch_wide<2, 4, 4, 2, true>(gp, s) : launch_wide<2, 4, 4, 2, false>(gp, s);
     return MMDIT_ERR_ARG;
   }
-  if (gp.act == MMDIT_ACT_SWIGLU) {   // packed w12 GEMM with the activation in the epilogue (gemm.hip has checked the rest)
+  if (gp.act == MMDIT_ACT_SWIGLU) {
     if (b_km) return MMDIT_ERR_ARG;
     if (cfg == CFG_320x256) return launch_lean<2, 4, 5, 2, false, true>(gp, s);
     if (cfg == CFG_256x256) return launch_lean<2, 4, 4, 2, false, true>(gp, s);
@@ -763,5 +776,6 @@ int gemm::launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t
   }
   if (cfg == CFG_320x256) return b_km ? launch_lean<2, 4, 5, 2, true>(gp, s) : launch_lean<2, 4, 5, 2, false>(gp, s);
   if (cfg == CFG_256x256) return b_km ? launch_lean<2, 4, 4, 2, true>(gp, s) : launch_lean<2, 4, 4, 2, false>(gp, s);
-  return MMDIT_ERR_ARG;
+#endif
+  return MMDIT_ERR_SHAPE;
 }

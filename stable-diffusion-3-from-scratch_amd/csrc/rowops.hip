@@ -1159,14 +1159,14 @@ extern "C" int mmdit_qk_norm_rope_fwd(const void* qkv, int qkv_dtype, const floa
 // global atomics on the same two cache lines, so fewer, fatter workgroups), `lanes` rows in flight per iteration pair, a multiple of the
 // tokens per sample when RoPE applies (same token for all rows of a lane: factors loaded once).
 static int qk_bwd_rl(int heads, int min_rows) {
-  static const int env = [] { const char* e = getenv("MMDIT_QK_RL"); return e ? atoi(e) : 0; }();
+  static const int env = [] { const char* e = mmdit_exp_env("MMDIT_QK_RL"); return e ? atoi(e) : 0; }();
   int rl = 1024 / (24 * heads);
   if (env > 0 && env < rl) rl = env;
   if (rl < 1 || min_rows < 2048) rl = 1;
   return rl;
 }
 static int qk_bwd_grid(int rows, int tokens, bool rope, int& rl) {
-  static const int lanes_max = [] { const char* e = getenv("MMDIT_QK_LANES"); return e ? atoi(e) : 768; }();
+  static const int lanes_max = [] { const char* e = mmdit_exp_env("MMDIT_QK_LANES"); return e ? atoi(e) : 768; }();
   if (rl == 1) {
     int g = rows < 512 ? rows : 512;
     if (rope && tokens <= 1024 && rows >= tokens) g = (g / tokens > 0 ? g / tokens : 1) * tokens;

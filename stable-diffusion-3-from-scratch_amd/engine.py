@@ -25,7 +25,7 @@ from types import SimpleNamespace as NS
 
 import torch
 
-from . import ops
+from . import _lib, ops
 from ._lib import ACT_SILU, PREC_BF16, PREC_SPLIT
 
 F32 = torch.float32
@@ -129,10 +129,9 @@ def _dgrad(m, dY, W, out_dtype, **kw):
 # 37.41 ms/step before and 1909 vs 1922 img/s after the 320x256-tile kernel -- no gain: the persistent 256x256 wgrad kernel owns
 # every CU (128 KB LDS, 2 x 243 VGPRs per SIMD), so main-stream kernels queue behind it instead of overlapping with it (the row
 # kernels showed 17 -> 116 us in the profile).  Default: one stream (clean per-kernel durations, graph-capturable step).
-import os as _os
-_WG_MODE = _os.environ.get("MMDIT_WGRAD_MODE", "streamk")
-_WG_OVERLAP = _os.environ.get("MMDIT_WGRAD_STREAM", "0") == "1"
-_FUSE_SWIGLU = _os.environ.get("MMDIT_FUSE_SWIGLU", "1") != "0"   # SwiGLU activation in the up-projection GEMM's epilogue (A/B switch)
+_WG_MODE = _lib.experiment("MMDIT_WGRAD_MODE", "streamk")
+_WG_OVERLAP = _lib.experiment("MMDIT_WGRAD_STREAM", "0") == "1"
+_FUSE_SWIGLU = _lib.experiment("MMDIT_FUSE_SWIGLU", "1") != "0"   # SwiGLU activation in the up-projection GEMM's epilogue (A/B switch)
 _wg_streams = {}
 
 
@@ -431,12 +430,12 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     return X2, C2, sv
 
 
-_LN_PAIR = _os.environ.get("MMDIT_LN_PAIR", "1") != "0"      # image + text rows of the adaLN / QK-norm+RoPE / MLP-activation-backward kernels in one launch (A/B switch)
-_MX_FUSE = _os.environ.get("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
-_BATCH_WMOD = _os.environ.get("MMDIT_BATCH_WMOD", "1") != "0"   # single-rank backward: the modulation-matrix weight gradients of all blocks in one grouped launch (A/B switch)
-_QKV_FUSE = _os.environ.get("MMDIT_QKV_FUSE", "1") != "0"        # QK-norm + RoPE + joint-layout store inside the QKV GEMM epilogue (A/B switch)
-_QK_FUSE = _os.environ.get("MMDIT_ATTN_QK_FUSE", "1") != "0"     # QK-norm + RoPE backward inside the attention backward kernels (A/B switch)
-_FUSE_GATE = _os.environ.get("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
+_LN_PAIR = _lib.experiment("MMDIT_LN_PAIR", "1") != "0"      # image + text rows of the adaLN / QK-norm+RoPE / MLP-activation-backward kernels in one launch (A/B switch)
+_MX_FUSE = _lib.experiment("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
+_BATCH_WMOD = _lib.experiment("MMDIT_BATCH_WMOD", "1") != "0"   # single-rank backward: the modulation-matrix weight gradients of all blocks in one grouped launch (A/B switch)
+_QKV_FUSE = _lib.experiment("MMDIT_QKV_FUSE", "1") != "0"        # QK-norm + RoPE + joint-layout store inside the QKV GEMM epilogue (A/B switch)
+_QK_FUSE = _lib.experiment("MMDIT_ATTN_QK_FUSE", "1") != "0"     # QK-norm + RoPE backward inside the attention backward kernels (A/B switch)
+_FUSE_GATE = _lib.experiment("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
 
 
 def _qk_bwd_two_pass(m, w, sv, g, dOx, dOc, dims, rope, dev):

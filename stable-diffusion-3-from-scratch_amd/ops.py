@@ -16,7 +16,7 @@ _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 # bench.py sets this to a list to time every GEMM launch with HIP events on the launch stream
 # (entries: (kernel variant, algorithmic FLOPs, start event, end event)); None = no instrumentation.
 PROFILE = None
-_ZERO_ALL = os.environ.get("MMDIT_ZERO_ALL", "0") == "1"     # A/B: zero-fill every K-decomposed GEMM output (from the pass's zero pool)
+_ZERO_ALL = _lib.experiment("MMDIT_ZERO_ALL", "0") == "1"     # A/B: zero-fill every K-decomposed GEMM output (from the pass's zero pool)
 
 
 class _ZeroPool:
@@ -169,7 +169,7 @@ def _variant(arr, n, outs):
     if plan & 128 and a.a_kmajor:
         return "gemm_kk_kernel<2,4,4,2>" + ("+ktail" if plan & 32 else "")
     if plan & 128:
-        kern = "gemm_lean_kernel" if os.environ.get("MMDIT_GEMM_WIDE", "1") == "0" else "gemm_wide_kernel"
+        kern = "gemm_lean_kernel" if _lib.experiment("MMDIT_GEMM_WIDE", "1") == "0" else "gemm_wide_kernel"
         return f"{kern}<{_CFG[plan & 15]},{int(bool(a.b_kmajor))}>" + ("+swiglu" if a.act == ACT_SWIGLU else "")
     return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "") + ("+swiglu" if a.act == ACT_SWIGLU else "")
 
@@ -178,7 +178,7 @@ def _variant(arr, n, outs):
 # DEVICE, allocated at the first K-decomposed launch on that GPU and kept for the life of the process (a captured hipGraph holds its address).
 # MMDIT_GEMM_WS=0: fp32 atomics instead (the round-2 path).
 _GEMM_WS = {}
-_GEMM_WS_ON = os.environ.get("MMDIT_GEMM_WS", "1") != "0" and os.environ.get("MMDIT_WGRAD_STREAM", "0") != "1"   # (one workspace: its launches must be stream-ordered -- not with the weight-gradient side stream)
+_GEMM_WS_ON = _lib.experiment("MMDIT_GEMM_WS", "1") != "0" and _lib.experiment("MMDIT_WGRAD_STREAM", "0") != "1"   # (one workspace: its launches must be stream-ordered -- not with the weight-gradient side stream)
 
 
 def _ensure_gemm_workspace(device):

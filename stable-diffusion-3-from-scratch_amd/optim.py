@@ -27,7 +27,7 @@ class ClipAdamW(torch.optim.AdamW):
         self.table_builds = 0   # pointer-table uploads so far
         self._steps_flat, self._step_views = None, None
         # the update kernel also rewrites the bf16 GEMM-operand copies (packing.shadow_targets); MMDIT_ADAMW_SHADOWS=0: A/B switch
-        self.write_shadows = os.environ.get("MMDIT_ADAMW_SHADOWS", "1") != "0"
+        self.write_shadows = _lib.experiment("MMDIT_ADAMW_SHADOWS", "1") != "0"
         # learning rates as DEVICE doubles, one per param group (the update launch reads them: a launch captured into a hipGraph
         # must not bake the scheduler's current value in); refreshed by one tiny fill only when a group's lr changed
         self._lr_dev, self._lr_host = None, None

@@ -14,7 +14,7 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
-from . import ops
+from . import _lib, ops
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -23,8 +23,7 @@ def _pad8(n):
     return (n + 7) // 8 * 8
 
 
-import os as _os
-_H_BF16 = _os.environ.get("MMDIT_VAE_H_BF16", "1") != "0"     # A/B switch: conv1 outputs of the ResNet blocks in bf16
+_H_BF16 = _lib.experiment("MMDIT_VAE_H_BF16", "1") != "0"     # A/B switch: conv1 outputs of the ResNet blocks in bf16
 _CIN_PAD = 64     # conv_in operand channels (the implicit-GEMM K = 9 * C must be a multiple of the 64-wide K tile)
 
 

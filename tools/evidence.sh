@@ -28,6 +28,21 @@ bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
   echo "== tools/probes/guard_step.py b"; python tools/probes/guard_step.py b 2>&1 | grep guard
   echo "== tools/probes/parity_budget.py"; python tools/probes/parity_budget.py 2>&1 | grep "HIP\|reference"
 ) > gpurun_out/${R}_probe_outputs.txt 2>&1
+# round 4: the 8-phase structure probe (32x32x16 and 16x16x32 builds, structure A/B + ablations + cycle stamps) next to the library yardstick,
+# the K sweep of the shipped kernels, PMC of the attention kernels
+( cd tools/probes
+  [ -x gemm8p ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o gemm8p gemm8p.hip 2>/dev/null
+  [ -x gemm8p_mf16 ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -DMF16=1 -o gemm8p_mf16 gemm8p.hip 2>/dev/null
+  [ -x gemm8p_nostagger ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -DMF16=1 -DSTAGGER=0 -o gemm8p_nostagger gemm8p.hip 2>/dev/null
+  echo "== tools/probes/gemm8p 8192 (v_mfma_f32_32x32x16_bf16)"; ./gemm8p 8192 10
+  echo "== tools/probes/gemm8p_mf16 8192 (v_mfma_f32_16x16x32_bf16: the shipped form)"; ./gemm8p_mf16 8192 10
+  echo "== tools/probes/gemm8p_nostagger 8192 (16x16x32, both wave groups in the same phase)"; ./gemm8p_nostagger 8192 10 | head -4
+  cd ../..
+  echo "== tools/probes/blaslt_ref.py (hipBLASLt, same box)"; python tools/probes/blaslt_ref.py 2>&1 | grep square
+  echo "== tools/gemm_bench.py (the shipped kernels through the C ABI)"; python tools/gemm_bench.py 2>&1 | grep "square\|block wgrads"
+  echo "== tools/probes/gemm_ksweep.py"; python tools/probes/gemm_ksweep.py 20 2>&1 | grep -v amdgpu
+) > gpurun_out/${R}_gemm8p_probe.txt 2>&1
+bash tools/pmc_attn.sh > gpurun_out/${R}_pmc_attention.txt 2>&1
 # MMDiT-L training step (config 4's model, batch 16) and the 28-step mxfp8 sampler (config 5): kernel tables
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_l -o run -- python3 tools/probes/l_config.py 16 > gpurun_out/${R}_l_prof.log 2>&1
