@@ -228,6 +228,16 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().mmdit_abi_version() == _lib.ABI_VERSION == 5 and _lib.lib().mmdit_struct_size(0) == ctypes.sizeof(_lib.GemmArgs) and _lib.lib().mmdit_build_arch() == b"gfx950"
 
 
+def test_8_phase_gemm_kernels_have_no_scratch_access_in_their_k_loop():
+    """The 8-phase GEMM kernels sit at the 256-VGPR edge; a spill reload inside the K loop drains the LDS-DMA queue (vmcnt(0)) and costs 20 % of
+    the kernel (tools/check_spills.py: compiles csrc/gemm8p.hip for gfx950 and scans the ISA of every instantiation)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_spills.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_product_path_fails_loudly_without_gpu():
     import sd3_amd  # noqa: F401
     from sd3_amd import ops

@@ -1,0 +1,56 @@
+"""Build-time guard for the 8-phase GEMM kernels (csrc/gemm8p.hip): they live at the 256-VGPR edge, and a scratch access INSIDE the K loop is a
+catastrophe there -- a scratch_load is a VMEM load, the compiler follows it with s_waitcnt vmcnt(0), and that drains the LDS-DMA queue the loop
+keeps two K tiles deep (measured: the 320-row forward kernel 1.58 -> 1.91 ms per step from TWO such reloads).  Compiles the file with -save-temps
+and fails if any gemm8 kernel has a scratch instruction between its K-loop header and the loop's backward branch.
+    python tools/check_spills.py [extra hipcc flags]           (needs hipcc; ~10 s; run by tests/test_oracle_cpu.py)"""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "stable-diffusion-3-from-scratch_amd", "csrc", "gemm8p.hip")
+
+
+def main():
+    with tempfile.TemporaryDirectory() as td:
+        subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps"] + sys.argv[1:] + ["-c", SRC, "-o", os.path.join(td, "o.o")],
+                       cwd=td, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        asm = open(os.path.join(td, "gemm8p-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
+    bad, kernels = [], 0
+    i = 0
+    while i < len(asm):
+        m = re.match(r"^(_ZN12_GLOBAL__N_1\d+gemm8\w*_kernel\w+):", asm[i])
+        if not m:
+            i += 1
+            continue
+        name, j = m.group(1), i + 1
+        while j < len(asm) and "s_endpgm" not in asm[j]:
+            j += 1
+        body = asm[i:j]
+        kernels += 1
+        # the K loop: the innermost loop (Depth=2) of the item loop; from its header label to the conditional branch back to that label
+        for k, line in enumerate(body):
+            if "Inner Loop Header: Depth=2" in line:
+                label = None
+                for b in range(k, max(k - 3, 0), -1):
+                    mm = re.match(r"^(\.LBB\d+_\d+):", body[b])
+                    if mm:
+                        label = mm.group(1)
+                        break
+                if label is None:
+                    continue
+                end = next((e for e in range(len(body) - 1, k, -1) if re.search(r"s_c?branch\w* " + re.escape(label) + r"\b", body[e])), None)
+                if end is None:
+                    continue
+                n = sum("scratch_" in l for l in body[k:end])
+                if n and any("v_mfma" in l for l in body[k:end]):
+                    bad.append((name, n))
+        i = j
+    print(f"{kernels} gemm8 kernels checked; in-loop scratch instructions: {bad if bad else 'none'}")
+    return 1 if bad or not kernels else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
