@@ -51,6 +51,8 @@ def pmc_traffic(kernel):
         qk = "+qk" in kernel
         cands = [name[:-1] + ((",1,0>" if sw else ",0,1>" if qk else ",0,0>") if lean else (",0,1>" if sw else ",0,0>")),
                  name[:-1] + ((",1>" if sw else ",0>") if lean else ""), name, name.split("<")[0]]
+        if name.startswith("gemm8_kernel"):     # tools/pmc_summary.py names the 8-phase kernel's instantiations exactly as ops._variant does
+            cands = [name]
         for key in cands:
             if key in d:
                 return d[key]["hbm_bytes_per_launch"], d[key]["mfma_util"], os.path.relpath(f, ROOT)
