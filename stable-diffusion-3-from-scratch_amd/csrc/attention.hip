@@ -404,6 +404,11 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const bf16_t* __restr
 //   V (ds_read_b64_tr_b16 fragments):    16-B piece p of key row r lives at slot p ^ (4 * ((r >> 1) & 1))
 // Rows beyond S are clamped to the last valid row (their scores are masked / their probabilities are zero).
 // One s_waitcnt vmcnt + one s_barrier per tile; every wave issues exactly two pieces per tile (8 waves = 8 + 8 KiB).
+// Round 4: nothing is issued past the last tile (the ring used to reload clamped copies: 3 of 7 + 3 tile copies at S = 410), the Q loads
+// go out first and share the first tile's counted wait, the first MFMA of a score block takes a constant-zero C, scale-and-shift and row
+// sums are packed fp32 pairs: 70 -> 67.5 us.  Workgroup geometry, same box (tools/probes/attn_fwd_geo.sh, waves x ring stages):
+// 8x4 70.2, 8x3 69.6, 4x4 104, 4x3 101, 4x2 101 us -- four independent 4-wave workgroups per CU de-phase MFMA and VALU work but copy every
+// K/V tile twice as often, and the LDS-DMA stream (64 KiB per tile step and CU) becomes the limit.
 // ------------------------------------------------------------------------------------------------
 constexpr int ANS = 4;   // ring stages
 
@@ -443,13 +448,14 @@ __device__ __forceinline__ bf16x8 tr_frag_sw(const char* tile, int rb, int h8, i
 // MXO (fp8 inference): the output leaves as MX e4m3 -- codes in place of the bf16 rows (same (B, tokens, H * 64) geometry, one byte per
 // feature) plus E8M0 block scales in the GEMM's layout (mx_scale_index; a head's 64 features are two 32-blocks) -- so the out-projection
 // GEMM needs no quantise pass; bit-identical to the bf16 output followed by mmdit_mxfp8_quantize.
-template <int DBG = 0, bool MXO = false>
-__global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+template <int DBG = 0, bool MXO = false, int NW = 8, int NS = ANS>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_dma_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                            int BH, int H, int S, int n_img, float scale,
                                                            bf16_t* __restrict__ Ox, bf16_t* __restrict__ Oc, float* __restrict__ lse,
                                                            unsigned char* __restrict__ scx = nullptr, unsigned char* __restrict__ scc = nullptr) {
-  constexpr int NW = 8;
-  __shared__ __attribute__((aligned(16))) char smem[ANS * 2 * KT * 128];
+  constexpr int PPW = 8 / NW;   // 1 KiB pieces (8 key rows) of each operand tile this wave copies
+  static_assert(NW * PPW == 8 && NS >= 2 && NW * 4096 <= NS * 2 * KT * 128, "tile pieces / epilogue staging");
+  __shared__ __attribute__((aligned(16))) char smem[NS * 2 * KT * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   MMDIT_YOUNG_HALF_PRIO();
   const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
@@ -466,22 +472,27 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
 
   if (DBG & 64) return;   // launch floor
   const int nkv = (S + KT - 1) / KT;
-  // this lane's part of a tile: key row 8 * wave + (lane >> 3), 16-byte slot lane & 7
-  const int rl = 8 * wave + (lane >> 3), slot = lane & 7;
-  const int kcol = (slot ^ ((rl >> 1) & 7)) * 8, vcol = (slot ^ (4 * ((rl >> 1) & 1))) * 8;
+  // this lane's part of a tile: piece p = PPW * wave + i holds key rows 8 p .. 8 p + 7; row 8 p + (lane >> 3), 16-byte slot lane & 7
+  const int slot = lane & 7;
   auto issue = [&](int j, int stage) {
-    const int row = min(min(j, nkv - 1) * KT + rl, S - 1);
-    attn_glds16(Kb + (int64_t)row * HD + kcol, lds0 + stage * (2 * KT * 128) + wave * 1024);
-    attn_glds16(Vb + (int64_t)row * HD + vcol, lds0 + stage * (2 * KT * 128) + KT * 128 + wave * 1024);
-  };
 #pragma unroll
-  for (int st = 0; st < ANS - 1; st++) issue(st, st);
-  // the Q fragments are requested BEHIND the first K/V tiles, so the two latencies overlap; the explicit wait that follows covers
-  // both (these are the only compiler-visible loads of the kernel: nothing else may make the compiler drain the DMA queue)
+    for (int i = 0; i < PPW; i++) {
+      const int pc = wave * PPW + i, rl = 8 * pc + (lane >> 3);
+      const int kcol = (slot ^ ((rl >> 1) & 7)) * 8, vcol = (slot ^ (4 * ((rl >> 1) & 1))) * 8;
+      const int row = min(j * KT + rl, S - 1);
+      attn_glds16(Kb + (int64_t)row * HD + kcol, lds0 + stage * (2 * KT * 128) + pc * 1024);
+      attn_glds16(Vb + (int64_t)row * HD + vcol, lds0 + stage * (2 * KT * 128) + KT * 128 + pc * 1024);
+    }
+  };
+  // The Q fragments are requested FIRST and the ring's first NS - 1 tiles behind them; nothing waits here: the first tile's counted wait
+  // in the loop covers the Q loads too (they are older).  The Q loads are asm so that the compiler does not put a vmcnt(0) of its own
+  // in front of their first use (it cannot see the DMA queue); the empty asm after the loop's wait carries the dependence.
   bf16x8 qf[4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ks++) qf[ks] = *(const bf16x8*)(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  for (int ks = 0; ks < 4; ks++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[ks]) : "v"(Qb + (int64_t)qc * HD + ks * 16 + (lane >> 5) * 8) : "memory");
+#pragma unroll
+  for (int st = 0; st < NS - 1; st++)
+    if (st < nkv) issue(st, st);
 
   f32x16 o[2];
 #pragma unroll
@@ -507,29 +518,34 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
   int stage = 0;
   for (int j = 0; j < nkv; j++) {
     if (!(DBG & 16) || j == 0) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (ANS - 2)) : "memory");   // tile j has landed (ANS-2 younger tiles may be in flight)
+    // tile j has landed; the min(NS - 2, nkv - 1 - j) younger tiles may be in flight (nothing is issued past the last tile)
+    const int ahead = nkv - 1 - j;
+    if (NS >= 3 && ahead >= NS - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW * (NS - 2)) : "memory");
+    else if (NS >= 4 && ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
     __builtin_amdgcn_s_barrier();                                          // ... for every wave; and everyone has left tile j-1
-    issue(j + ANS - 1, stage == 0 ? ANS - 1 : stage - 1);                  // refill the stage of tile j-1
+    if (j + NS - 1 < nkv) issue(j + NS - 1, stage == 0 ? NS - 1 : stage - 1);   // refill the stage of tile j-1
     }
     const char* tile = smem + stage * (2 * KT * 128);
-    stage = stage + 1 == ANS ? 0 : stage + 1;
+    stage = stage + 1 == NS ? 0 : stage + 1;
     if (!active) continue;
     const char* kp[4] = {tile + kofs[0], tile + kofs[1], tile + kofs[2], tile + kofs[3]};
     const char* vp[2] = {tile + vofs[0], tile + vofs[1]};
     f32x16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; kb++) {
-      if (j * KT + kb * 32 >= S) {
+      // (a fully padded second block of the last tile is multiplied too -- its rows are copies of the last key -- and masked below: a
+      //  skip would cost every tile 16 speculative v_mov of -inf)
+      if (DBG & 4) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) s[kb][r] = -INFINITY;
-        continue;
-      }
+        for (int r = 0; r < 16; r++) s[kb][r] = (float)qf[r & 3][0];
+      } else {
+        // the first MFMA of the chain takes the constant 0 as its C operand: no 16 v_mov per block to clear the accumulator
+        constexpr f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 16; r++) s[kb][r] = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++) {
-        if (DBG & 4) { s[kb][ks] += (float)qf[ks][0]; continue; }
-        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((DBG & 8) ? qf[(ks + 1) & 3] : *LDS_PTR(const bf16x8, kp[ks] + kb * 32 * 128), qf[ks], s[kb], 0, 0, 0);
+        for (int ks = 0; ks < 4; ks++)
+          s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((DBG & 8) ? qf[(ks + 1) & 3] : *LDS_PTR(const bf16x8, kp[ks] + kb * 32 * 128), qf[ks], ks == 0 ? zero16 : s[kb], 0, 0, 0);
       }
       if ((j + 1) * KT > S) {
 #pragma unroll
@@ -555,11 +571,22 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
 #pragma unroll
         for (int r = 0; r < 16; r++) o[db][r] *= alpha;
     }
-    float rs = 0.f;
+    // p = 2^(s c - m): the scale-and-shift and the row sums as packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot);
+    // the 32 v_exp_f32 stay scalar -- they are the VALU floor of a tile
+    f32x2 rs2 = {0.f, 0.f};
+    const f32x2 c2 = {c, c}, nm2 = {-m, -m};
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int r = 0; r < 16; r++) { const float p = (DBG & 1) ? fmaf(s[kb][r], c, 1.f) : fast_exp2(fmaf(s[kb][r], c, -m)); s[kb][r] = p; if (!(DBG & 32)) rs += p; }
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {s[kb][r], s[kb][r + 1]};
+        const f32x2 t = (DBG & 1) ? sv : __builtin_elementwise_fma(sv, c2, nm2);
+        const f32x2 pv = {(DBG & 1) ? t[0] : fast_exp2(t[0]), (DBG & 1) ? t[1] : fast_exp2(t[1])};
+        s[kb][r] = pv[0];
+        s[kb][r + 1] = pv[1];
+        if (!(DBG & 32)) rs2 += pv;
+      }
+    const float rs = rs2[0] + rs2[1];
     l += rs + partner32(rs, lane);
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
@@ -578,8 +605,7 @@ __global__ __launch_bounds__(512) void attn_fwd_dma_kernel(const bf16_t* __restr
           }
         }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing (clamped, unused) pieces must land before the LDS is reused
-  __builtin_amdgcn_s_barrier();                      // ... everybody's, and every wave has left the last tile
+  __builtin_amdgcn_s_barrier();                      // every wave has left the last tile (no DMA is in flight: the last wait was vmcnt(0))
   if (DBG & 128) { if (o[0][0] + o[1][3] + l == 12345.f) lse[0] = 1.f; return; }
   // Epilogue: the accumulators hold O^T fragments (lane = query, 4 consecutive features per register group): stored directly, every
   // instruction would touch 32 different rows with 8 bytes each (16 instructions per wave, store-issue-bound: the empty-loop
@@ -1023,9 +1049,21 @@ extern "C" int mmdit_attn_fwd(const void* Q, const void* K, const void* V, int b
     else MMDIT_FWD(2, false);
   }
 #endif
-  else
-    hipLaunchKernelGGL(attn_fwd_dma_kernel<0>, dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V,
-                       batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse);
+#define MMDIT_FWD_DMA(NW, NS) hipLaunchKernelGGL((attn_fwd_dma_kernel<0, false, NW, NS>), dim3(((S + 32 * NW - 1) / (32 * NW)) * batch * heads), dim3(64 * NW), 0, s, (const bf16_t*)Q, \
+                                                (const bf16_t*)K, (const bf16_t*)V, batch * heads, heads, S, n_img, scale, (bf16_t*)Ox, (bf16_t*)Oc, lse)
+#ifdef MMDIT_PROBES                                   // experiments: waves per workgroup / ring depth of the DMA kernel (MMDIT_ATTN_FWD_GEO = 84 | 83 | 43 | 42 | 44)
+  else if (mmdit_exp_env("MMDIT_ATTN_FWD_GEO") && atoi(mmdit_exp_env("MMDIT_ATTN_FWD_GEO")) != 84) {
+    switch (atoi(mmdit_exp_env("MMDIT_ATTN_FWD_GEO"))) {
+      case 83: MMDIT_FWD_DMA(8, 3); break;
+      case 44: MMDIT_FWD_DMA(4, 4); break;
+      case 43: MMDIT_FWD_DMA(4, 3); break;
+      case 42: MMDIT_FWD_DMA(4, 2); break;
+      default: return MMDIT_ERR_ARG;
+    }
+  }
+#endif
+  else MMDIT_FWD_DMA(8, 4);
+#undef MMDIT_FWD_DMA
 #undef MMDIT_FWD
   return mmdit_launch_status();
 }
