@@ -282,10 +282,11 @@ def main():
                     "avg_launch_us": round(dom[1][2] / dom[1][0] * 1e6, 2), "launches_per_step": dom[1][0] // 3,
                     "all_gemm": {"achieved": round(tot_f / tot_t / 1e12, 1), "frac": round(tot_f / tot_t / PEAK_BF16, 4),
                                  "ms_per_step": round(tot_t / 3 * 1e3, 3), "gflop_per_step": round(tot_f / 3 / 1e9, 1),
-                                 # launches whose epilogue also runs a former row kernel ("+qk": QK-norm + RoPE + joint-layout store) are priced
-                                 # with their GEMM FLOPs only; the same figure over the plain GEMM launches:
-                                 "frac_without_fused_row_work": round(sum(v[1] for k, v in stats.items() if "+qk" not in k) /
-                                                                      max(1e-12, sum(v[2] for k, v in stats.items() if "+qk" not in k)) / PEAK_BF16, 4)},
+                                 # launches whose epilogue also runs a former row kernel ("+qk": QK-norm + RoPE + joint-layout store; "swiglu_bwd":
+                                 # the SwiGLU backward, an HBM-bound pass of 644 MB per launch) are priced with their GEMM FLOPs only; the same
+                                 # figure over the plain GEMM launches:
+                                 "frac_without_fused_row_work": round(sum(v[1] for k, v in stats.items() if "+qk" not in k and "swiglu_bwd" not in k) /
+                                                                      max(1e-12, sum(v[2] for k, v in stats.items() if "+qk" not in k and "swiglu_bwd" not in k)) / PEAK_BF16, 4)},
                     "by_kernel": {k: {"tflops": round(v[1] / v[2] / 1e12, 1), "ms_per_step": round(v[2] / 3 * 1e3, 3), "launches_per_step": v[0] // 3} for k, v in sorted(stats.items())}}
     if world > 1:
         dist.barrier()

@@ -41,6 +41,14 @@ extern "C" {
                                  * Row-major bf16 operands with K % 64 == 0 or e4m3 operands with K % 128 == 0, h % 128 == 0 (else
                                  * MMDIT_ERR_SHAPE: run the GEMM and mmdit_swiglu_fwd separately); no gate / residual / split. */
 
+#define MMDIT_ACT_SWIGLU_BWD 3  /* data gradient of the SwiGLU down-projection fused with the activation backward (MLP.py:32 backward / xformers
+                                 * SwiGLU w3, then silu(g) * u): A = dY [M, K] row-major bf16, B = w3 [K, N] (b_kmajor = 1, N = h), aux [M, 2h] (bf16,
+                                 * INPUT) = the [g | u] kept by MMDIT_ACT_SWIGLU, C [M, 2h] (bf16, ldc >= 2h) = d[g | u] computed from the
+                                 * bf16-rounded dh = A B (== mmdit_gemm followed by mmdit_swiglu_bwd, bit for bit, without the dh round trip);
+                                 * dbias (optional, fp32 [2h], PRE-ZEROED or accumulating) += column sums of d[g | u].  h % 8 == 0, K % 64 == 0;
+                                 * MMDIT_ERR_SHAPE when the planner would not give the launch to the 8-phase 256 x 256 kernel (run the two
+                                 * passes instead); no bias / gate / residual / split. */
+
 #define MMDIT_PREC_BF16 0       /* single-pass bf16 MFMA operands, fp32 accumulate */
 #define MMDIT_PREC_SPLIT 1      /* 3-term split-bf16, 6-pass MFMA: fp32-exact products (parity mode) */
 
@@ -51,7 +59,7 @@ typedef void* mmdit_stream_t;   /* hipStream_t */
  * (MMDIT_LIB=...) with another layout fails loudly instead of reading past a struct.  mmdit_struct_size(which): sizeof of
  * 0 mmdit_gemm_args, 1 mmdit_ln_fwd_problem, 2 mmdit_ln_bwd_problem, 3 mmdit_qk_problem, 4 mmdit_mlp_bwd_problem,
  * 5 mmdit_adamw_tensor, 6 mmdit_cast_tensor, 7 mmdit_qk_epilogue; -1 for an unknown id. */
-#define MMDIT_ABI_VERSION 5
+#define MMDIT_ABI_VERSION 6
 int mmdit_abi_version(void);
 int mmdit_struct_size(int which);
 const char* mmdit_build_arch(void);
@@ -112,6 +120,8 @@ typedef struct {
    * (C: (M, N/2) bytes, ldc in bytes) + E8M0 block scales (layout / size as scale_mode 1 for an (M, N/2) operand), so that the
    * down-projection GEMM reads it without a quantise pass; aux must be NULL (inference). */
   void* c_scales;
+  /* MMDIT_ACT_SWIGLU_BWD: bias gradient of the packed up-projection (column sums of C), added atomically; NULL: not wanted */
+  float* dbias;
 } mmdit_gemm_args;
 int mmdit_gemm(const mmdit_gemm_args* args, mmdit_stream_t stream);
 /* Grouped launch: count (1..12) independent problems of the SAME kernel variant (dtypes, layouts,

@@ -18,7 +18,7 @@ LIB_PATH = os.environ.get("MMDIT_LIB") or os.path.join(_HERE, "libmmdit_hip.so")
 HEADER_PATH = os.path.join(_HERE, "..", "include", "mmdit_hip.h")
 
 F32, BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_SWIGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_SWIGLU, ACT_SWIGLU_BWD = 0, 1, 2, 3
 PREC_BF16, PREC_SPLIT = 0, 1
 FP8 = 2   # dtype code of OCP e4m3 GEMM operands (stored in torch.uint8 / float8_e4m3fn tensors)
 
@@ -42,6 +42,7 @@ class GemmArgs(ctypes.Structure):
         ("stream_k", _i),
         ("conv_mode", _i), ("conv_H", _i), ("conv_W", _i), ("conv_C", _i),
         ("scale_a", _vp), ("scale_b", _vp), ("scale_mode", _i), ("c_scales", _vp),
+        ("dbias", _vp),
     ]
 
 
@@ -134,7 +135,7 @@ _SIGNATURES = {
     "mmdit_cast_multi": ([_vp, _vp, _vp, _i, _vp], _i),
 }
 ADAMW_CHUNK = 65536   # MMDIT_ADAMW_CHUNK
-ABI_VERSION = 5       # MMDIT_ABI_VERSION of include/mmdit_hip.h this binding mirrors
+ABI_VERSION = 6       # MMDIT_ABI_VERSION of include/mmdit_hip.h this binding mirrors
 # struct ids of mmdit_struct_size() -> ctypes mirrors (None: laid out with numpy record dtypes in optim.py / ops.py: 48 / 24 bytes)
 _STRUCTS = [("mmdit_gemm_args", GemmArgs), ("mmdit_ln_fwd_problem", LnFwdProblem), ("mmdit_ln_bwd_problem", LnBwdProblem),
             ("mmdit_qk_problem", QkProblem), ("mmdit_mlp_bwd_problem", MlpBwdProblem), ("mmdit_adamw_tensor", None), ("mmdit_cast_tensor", None), ("mmdit_qk_epilogue", QkEpilogue)]

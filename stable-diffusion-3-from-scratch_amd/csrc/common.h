@@ -99,6 +99,14 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + expf
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 #endif
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
+// backward of h = silu(g) * u for one element: dg = d u s (1 + g (1 - s)), du = d g s, s = sigmoid(g).  ONE spelling (explicit fma) for the row
+// kernel (rowops.hip mlp_act_bwd_body) and the GEMM epilogue (gemm8p.hip epi8_swiglu_bwd): the two paths must produce the same bits, and the
+// compiler's choice to contract 1 + g (1 - s) depends on the surrounding code
+__device__ __forceinline__ void swiglu_bwd_f(float d, float g, float u, float& dg, float& du) {
+  const float s = sigmoid_f(g);
+  dg = d * u * s * __builtin_fmaf(g, 1.f - s, 1.f);
+  du = d * g * s;
+}
 
 // ---- MX (OCP microscaling) e4m3 helpers ------------------------------------------------------------------------------------
 // E8M0 exponent of a 32-block with absolute maximum amax: the smallest power of two with amax / 2^ex <= 448 (floor(log2 amax) - 8

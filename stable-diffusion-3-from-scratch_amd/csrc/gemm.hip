@@ -238,7 +238,7 @@ int check_problem(const mmdit_gemm_args* a) {
   MMDIT_CHECK_ARG((a->lda * esa) % 16 == 0 && (a->ldb * esb) % 16 == 0 && a->ldc % 4 == 0);
   if (a->a_kmajor) { MMDIT_CHECK_ARG(a->M % 8 == 0 && a->lda >= a->M); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->lda >= a->K); }
   if (a->b_kmajor) { MMDIT_CHECK_ARG(a->N % 8 == 0 && a->ldb >= a->N); } else { MMDIT_CHECK_ARG(a->K % 8 == 0 && a->ldb >= a->K); }
-  MMDIT_CHECK_ARG(a->ldc >= (a->act == MMDIT_ACT_SWIGLU ? a->N / 2 : a->N));
+  MMDIT_CHECK_ARG(a->ldc >= (a->act == MMDIT_ACT_SWIGLU ? a->N / 2 : a->act == MMDIT_ACT_SWIGLU_BWD ? 2 * a->N : a->N));
   if (a->bias) MMDIT_CHECK_ARG(aligned16(a->bias));
   if (a->gate) MMDIT_CHECK_ARG(a->residual && a->rows_per_batch > 0 && aligned16(a->gate) && a->ld_gate % 4 == 0);
   if (a->residual) MMDIT_CHECK_ARG(aligned16(a->residual) && a->ld_res % 4 == 0);
@@ -359,6 +359,18 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
       if (a->aux) MMDIT_CHECK_ARG(a->ld_aux >= a->N && a->ld_aux % 8 == 0 && aligned16(a->aux));
     }
   }
+  const bool swiglu_bwd = a0->act == MMDIT_ACT_SWIGLU_BWD;
+  if (swiglu_bwd) {
+    // C[M, 2N] = d[g | u] from dh = A B (N = h hidden columns) and aux[M, 2N] = [g | u]: the 8-phase kernel's 256 x 256 launch only
+    if (!dma) return MMDIT_ERR_SHAPE;
+    for (int i = 0; i < count; i++) {
+      const mmdit_gemm_args* a = &args[i];
+      MMDIT_CHECK_ARG(a->c_dtype == MMDIT_BF16 && !a->a_kmajor && a->b_kmajor && a->aux && a->aux_dtype == MMDIT_BF16 && !a->bias && !a->gate && !a->residual &&
+                      !a->accumulate && split_k == 1 && !a->stream_k && !a->conv_mode && !fp8);
+      MMDIT_CHECK_ARG(a->N % 8 == 0 && a->ldc >= 2 * a->N && a->ldc % 8 == 0 && aligned16(a->C) && a->ld_aux >= 2 * a->N && a->ld_aux % 8 == 0 && aligned16(a->aux));
+      if (a->dbias) MMDIT_CHECK_ARG(((uintptr_t)a->dbias & 3) == 0);
+    }
+  }
   int bm = BM, bn = BN, cfg = CFG_128x128;
   // stream-K for the weight gradients (k-major A): fp32 C must be pre-zeroed by the caller (a0->stream_k)
   static const bool no_sk = mmdit_exp_env("MMDIT_GEMM_NO_STREAMK") != nullptr;
@@ -368,14 +380,15 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   static const char* lean_env = mmdit_exp_env("MMDIT_GEMM_LEAN");
   static const int lean_mode = lean_env ? atoi(lean_env) : 1;
   bool lean_ok = dma && lean_mode > 0 && !fp8 && !conv && !stream_k && split_k == 1 && !a0->a_kmajor && a0->c_dtype == MMDIT_BF16 &&
-                 (a0->act == MMDIT_ACT_NONE || a0->act == MMDIT_ACT_SILU || swiglu) && !a0->accumulate;
+                 (a0->act == MMDIT_ACT_NONE || a0->act == MMDIT_ACT_SILU || swiglu || swiglu_bwd) && !a0->accumulate;
   for (int i = 0; i < count && lean_ok; i++) {
     const mmdit_gemm_args* a = &args[i];
-    lean_ok = (!a->aux || swiglu) && !a->gate && !a->residual && a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) && (!a->b_kmajor || a->N >= 8);
+    lean_ok = (!a->aux || swiglu || swiglu_bwd) && !a->gate && !a->residual && a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) && (!a->b_kmajor || a->N >= 8);
   }
   if (dma) {
     cfg = pick_dma_cfg(args, count, split_k, stream_k, lean_ok);
     if (swiglu && cfg != CFG_320x256) cfg = CFG_256x256;   // the activation pairs gate / up columns inside a 256-column tile
+    if (swiglu_bwd) cfg = CFG_256x256;                     // (the fused backward epilogue exists at 256 rows)
     dma_cfg_tile(cfg, bm, bn);
   }
   const bool lean = lean_ok && (cfg == CFG_320x256 || (cfg == CFG_256x256 && lean_mode == 1));
@@ -404,6 +417,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     p.tile_start = tiles;
     p.nk = a->K / bk;
     p.scale_a = (const float*)a->scale_a; p.scale_b = (const float*)a->scale_b; p.c_scales = (unsigned char*)a->c_scales;
+    p.dbias = a->dbias;
     p.unit_start = units;
     tiles += p.tiles_n * p.tiles_m;
     units += p.tiles_n * p.tiles_m * p.nk;
@@ -527,6 +541,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   // (the QKV launch with the QK-norm / RoPE epilogue stays on the wide kernel at 320 rows: with that epilogue's registers the 320-row 8-phase
   //  variant measured slower, 1.73 vs 1.59 ms per step)
   const bool p8 = p8_mode > 0 && ((kk && cfg == CFG_256x256) || (lean && (cfg == CFG_256x256 || (cfg == CFG_320x256 && p8_mode == 1 && !qkr))));
+  if (swiglu_bwd && !p8) return MMDIT_ERR_SHAPE;
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
   if (p8) return launch_gemm8(cfg, a0->a_kmajor, a0->b_kmajor, gp, s);

@@ -41,7 +41,7 @@ template <int MT> struct Geo {
   static constexpr int NB32 = MT / 64;                     // 32-row blocks of a wave's rows (4 / 5)
 };
 
-enum Epi8 { EPI_BF16 = 0, EPI_SWIGLU = 1, EPI_QK = 2, EPI_F32 = 3 };
+enum Epi8 { EPI_BF16 = 0, EPI_SWIGLU = 1, EPI_QK = 2, EPI_F32 = 3, EPI_SWIGLU_BWD = 4 };
 
 #define SWZ_R(r) (((r) >> 1) & 7)
 #define SWZ_K(k) ((((k) & 3) << 2) ^ ((((k) >> 3) & 1) << 1))
@@ -141,6 +141,91 @@ __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const
       if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+}
+
+// SwiGLU backward in the epilogue of the down-projection's data gradient (MMDIT_ACT_SWIGLU_BWD; MLP.py:32 backward / xformers SwiGLU): the tile
+// is dh = dY W3 for the hidden columns [n0, n0 + 256).  It is staged as bf16 exactly as epi8_bf16 would store it; every lane then takes 8
+// consecutive columns of a row, loads the saved pre-activations g, u of those columns (aux = [g | u], 2 N columns) and writes d[g | u] to C:
+// the arithmetic of rowops.hip mlp_act_bwd_body on the ROUNDED dh, i.e. the bits of the GEMM followed by mmdit_swiglu_bwd without the dh round
+// trip (322 of that pass's 806 MB at MMDiT-B) and without its launch.  Bias gradient (column sums of d[g | u]): one atomic per column and wave.
+template <int MT>
+__device__ __forceinline__ void epi8_swiglu_bwd(AccT<MT>& acc, const Problem& p, int m0, int n0, int wm, int wn, int lane, char* stage) {
+  constexpr int NB = Geo<MT>::NB32;
+  const bf16_t* GU = (const bf16_t*)p.aux;
+  bf16_t* D = (bf16_t*)p.C;
+  const int wr = lane & 15, wq = lane >> 4;            // write side: row within the 16-row fragment, 4-column group
+  const int rr = lane >> 3, rc = lane & 7;             // read side: row within the 8-row pass, 16-B chunk (8 columns)
+  const int col = n0 + wn * 64 + rc * 8;
+  const bool cok = col < p.N;
+  const int row0 = m0 + wm * (MT / 2) + rr;
+  // The pre-activation rows of the next 32-row block are requested before the current block is converted (double buffer: 2 x 8 quads).
+  // (Requesting all four blocks up front -- 32 KB per wave in flight, the retired blocks parked in packed form -- measured SLOWER, 246 vs 225 us
+  //  per launch at MMDiT-B: 30 spilled registers, and the epilogue phases are HBM-bound anyway: 256 CUs x 512 KB per round.)
+  u32x4 gq[2][4], uq[2][4];
+  auto request = [&](int i, int b) {
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = row0 + i * 32 + it * 8;
+      gq[b][it] = uq[b][it] = (u32x4){0u, 0u, 0u, 0u};
+      if (row < p.M && cok) {                          // (saved pre-activations at their last use: streaming loads)
+        const bf16_t* src = GU + (int64_t)row * p.ld_aux + col;
+        gq[b][it] = __builtin_nontemporal_load((const u32x4*)src);
+        uq[b][it] = __builtin_nontemporal_load((const u32x4*)(src + p.N));
+      }
+    }
+  };
+  float sg[8], su[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) sg[e] = su[e] = 0.f;
+  request(0, 0);
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    if (i + 1 < NB) request(i + 1, (i + 1) & 1);
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const f32x4& a = grp(acc, i, q);
+      const int row = (q >> 2) * 16 + wr, chunk = (q & 3) * 2 + (wq >> 1);
+      *LDS_PTR(u32x2, stage + row * 128 + ((chunk ^ (row & 7)) << 4) + (wq & 1) * 8) = (u32x2){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private region: program order is enough
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+      const int row = row0 + i * 32 + it * 8;
+      const u32x4 gw = gq[i & 1][it], uw = uq[i & 1][it];
+      float og[8], ou[8];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const float d = __builtin_bit_cast(float, h ? t[e] & 0xffff0000u : t[e] << 16);
+          const float g = __builtin_bit_cast(float, h ? gw[e] & 0xffff0000u : gw[e] << 16);
+          const float u = __builtin_bit_cast(float, h ? uw[e] & 0xffff0000u : uw[e] << 16);
+          swiglu_bwd_f(d, g, u, og[2 * e + h], ou[2 * e + h]);
+        }
+      }
+      if (row < p.M && cok) {
+#pragma unroll
+        for (int e = 0; e < 8; e++) { sg[e] += og[e]; su[e] += ou[e]; }
+        bf16_t* dst = D + (int64_t)row * p.ldc + col;
+        st8(dst, og);
+        st8(dst + p.N, ou);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
+  }
+  if (p.dbias) {      // the 8 lanes with the same chunk (rr = 0..7) hold partial sums of the same 8 columns
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { sg[e] += __shfl_xor(sg[e], o, 64); su[e] += __shfl_xor(su[e], o, 64); }
+    }
+    if (rr == 0 && cok) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { atomicAdd(p.dbias + col + e, sg[e]); atomicAdd(p.dbias + p.N + col + e, su[e]); }
+    }
   }
 }
 
@@ -374,6 +459,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   static_assert(MT == 256 || MT == 320, "tile rows");
   static_assert(EPI == EPI_F32 ? (A_KM && B_KM && MT == 256) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major, 256 rows); bf16 epilogues take a row-major A");
   static_assert(!(EPI == EPI_SWIGLU || EPI == EPI_QK) || !B_KM, "fused epilogues: row-major weight");
+  static_assert(EPI != EPI_SWIGLU_BWD || (B_KM && MT == 256), "SwiGLU backward epilogue: the data-gradient layout, 256-row tiles");
   using GE = Geo<MT>;
   constexpr int QR = GE::QR, FI = GE::FI, KBUF = GE::KBUF, XA0 = GE::XA0, XA1 = GE::XA1, XB0 = GE::XB0, XB1 = GE::XB1, PAW = GE::PAW;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -585,6 +671,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   if constexpr (EPI == EPI_BF16) epi8_bf16<MT>(acc, q, gp, m0, n0, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT>(acc, q, m0, it.tn, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[it.pi & 1], m0, n0, wr, wc, lane, stage);
+  else if constexpr (EPI == EPI_SWIGLU_BWD) epi8_swiglu_bwd<MT>(acc, q, m0, n0, wr, wc, lane, stage);
   else {
     if (it.atomic && gp.ws_slots) {
       // partial tile of the split tail through the workspace (gemm_lean.hip gemm_kk_kernel: slot store, ticket, the last slice sums)
@@ -708,6 +795,10 @@ int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s) {
     else return MMDIT_ERR_SHAPE;
   }
   if (gp.act == MMDIT_ACT_SWIGLU) return b_km ? MMDIT_ERR_ARG : launch8<MT, false, false, EPI_SWIGLU>(gp, s);
+  if (gp.act == MMDIT_ACT_SWIGLU_BWD) {
+    if constexpr (MT == 256) return b_km ? launch8<MT, false, true, EPI_SWIGLU_BWD>(gp, s) : MMDIT_ERR_ARG;
+    else return MMDIT_ERR_SHAPE;
+  }
   return b_km ? launch8<MT, false, true, EPI_BF16>(gp, s) : launch8<MT, false, false, EPI_BF16>(gp, s);
 }
 

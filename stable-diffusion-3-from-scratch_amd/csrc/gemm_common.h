@@ -21,6 +21,7 @@ struct Problem {
   int conv_mode, cHo, cWo, cHp, cWp, cC;
   const float* scale_a; const float* scale_b;   // fp8 operands: per-tensor dequantisation scales (device scalars), C = sa*sb*(A_q B_q^T); MX mode: E8M0 bytes (mx_scale_index)
   unsigned char* c_scales;                      // SwiGLU epilogue with an MX e4m3 output: E8M0 scales of C (C then holds e4m3 codes)
+  float* dbias;                                 // SwiGLU-backward epilogue: column sums of C are added here (nullptr: not wanted)
 };
 // QKV projection with the per-head QK RMSNorm + axial RoPE + joint-layout store in its epilogue (gemm_lean.hip, mmdit_gemm_qkv_norm_rope)
 struct QkEpi {

@@ -714,9 +714,7 @@ __device__ __forceinline__ void mlp_act_bwd_body(int by, const T* __restrict__ d
         } else {
 #pragma unroll
           for (int e = 0; e < 8; e++) {
-            float sig = sigmoid_f(g[k][e]);
-            og[e] = d[k][e] * u[k][e] * sig * (1.f + g[k][e] * (1.f - sig));
-            ou[e] = d[k][e] * g[k][e] * sig;
+            swiglu_bwd_f(d[k][e], g[k][e], u[k][e], og[e], ou[e]);
             sg[e] += og[e]; su[e] += ou[e];
           }
           st8(dgu + r * ldi + c, og);

@@ -435,6 +435,7 @@ _MX_FUSE = _lib.experiment("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passe
 _BATCH_WMOD = _lib.experiment("MMDIT_BATCH_WMOD", "1") != "0"   # single-rank backward: the modulation-matrix weight gradients of all blocks in one grouped launch (A/B switch)
 _QKV_FUSE = _lib.experiment("MMDIT_QKV_FUSE", "1") != "0"        # QK-norm + RoPE + joint-layout store inside the QKV GEMM epilogue (A/B switch)
 _QK_FUSE = _lib.experiment("MMDIT_ATTN_QK_FUSE", "1") != "0"     # QK-norm + RoPE backward inside the attention backward kernels (A/B switch)
+_FUSE_SWIGLU_BWD = _lib.experiment("MMDIT_FUSE_SWIGLU_BWD", "1") != "0"   # SwiGLU backward in the epilogue of the down-projection's data gradient (A/B switch)
 _FUSE_GATE = _lib.experiment("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)
 
 
@@ -508,10 +509,22 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None,
         dacc_c = dacc[1] if dacc is not None else ops.gate_residual_bwd(dC2, sv.acc_mc, ms.gate2c, Mt, dms.gate2c, bpart[:, d:], m.T)
         probs.append(dict(A=dacc_c, B=w.mlp_c.Wdown, b_kmajor=True, out_dtype=m.T))
     ops.colsum(bpart, bdown)   # finish both bias gradients: sum the per-batch partial rows
-    dh = _group(m, probs)
+    # SwiGLU: the activation backward runs in the epilogue of this data-gradient GEMM (no dh round trip, no row-kernel launch) when the
+    # planner gives the launch to the 8-phase kernel; otherwise GEMM + mlp_act_bwd
+    dgu = None
+    if (_FUSE_SWIGLU_BWD and m.fast and dev.type == "cuda" and m.prec == PREC_BF16 and dacc_x.dtype == BF16 and sv.gu_x.dtype == BF16
+            and not w.mlp_x.gelu and (not both or not w.mlp_c.gelu)):
+        fp = [dict(A=dacc_x, B=w.mlp_x.Wdown, aux=sv.gu_x, dbias=g.mlp_x.bup, precision=m.prec)]
+        if both:
+            fp.append(dict(A=dacc_c, B=w.mlp_c.Wdown, aux=sv.gu_c, dbias=g.mlp_c.bup, precision=m.prec))
+        dgu = ops.gemm_swiglu_bwd(fp)
+    if dgu is None:
+        dh = _group(m, probs)
     defer(g.mlp_x, "Wdown", dacc_x, sv.h_x)
     pair = both and _LN_PAIR and dev.type == "cuda" and w.mlp_x.hidden == w.mlp_c.hidden and w.mlp_x.gelu == w.mlp_c.gelu
-    if pair:     # image + text activation backward in one launch
+    if dgu is not None:
+        dgu_x, dgu_c = dgu[0], (dgu[1] if both else None)
+    elif pair:     # image + text activation backward in one launch
         dgu_x, dgu_c = ops.mlp_act_bwd_pair((dh[0], sv.gu_x, g.mlp_x.bup), (dh[1], sv.gu_c, g.mlp_c.bup), w.mlp_x.hidden, w.mlp_x.gelu)
     else:
         dgu_x = ops.mlp_act_bwd(dh[0], sv.gu_x, w.mlp_x.hidden, g.mlp_x.bup, w.mlp_x.gelu)
@@ -519,7 +532,7 @@ def block_bwd(m, w, sv, dX2, dC2, dy_acc, dims, rope, defer_cond=False, st=None,
     defer(g.mlp_x, "Wup", dgu_x, sv.ln2x)
     if both:
         defer(g.mlp_c, "Wdown", dacc_c, sv.h_c)
-        if not pair:
+        if not pair and dgu is None:
             dgu_c = ops.mlp_act_bwd(dh[1], sv.gu_c, w.mlp_c.hidden, g.mlp_c.bup, w.mlp_c.gelu)
         probs.append(dict(A=dgu_c, B=w.mlp_c.Wup, b_kmajor=True, out_dtype=m.T))
         defer(g.mlp_c, "Wup", dgu_c, sv.ln2c)

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_SILU, ACT_SWIGLU, BF16, F32, FP8, PREC_BF16, PREC_SPLIT, GemmArgs, check
+from ._lib import ACT_NONE, ACT_SILU, ACT_SWIGLU, ACT_SWIGLU_BWD, BF16, F32, FP8, PREC_BF16, PREC_SPLIT, GemmArgs, check
 
 _DT = {torch.float32: F32, torch.bfloat16: BF16, torch.float8_e4m3fn: FP8}
 
@@ -92,7 +92,7 @@ def torch_dtype(code: int):
 
 # ---------------------------------------------------------------------------------------------
 def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=None, bias=None, act=ACT_NONE,
-               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None, scale_a=None, scale_b=None, scale_mode=0, out_scales=None):
+               gate=None, rows_per_batch=0, residual=None, aux=None, accumulate=False, precision=PREC_BF16, split_k=1, stream_k=False, conv=None, scale_a=None, scale_b=None, scale_mode=0, out_scales=None, dbias=None):
     """conv = (mode, H, W, C): A is a zero-bordered NHWC bf16 tensor (batch, H+2, W+2, C) -- implicit-GEMM 3x3 convolution."""
     if conv is not None:
         mode, cH, cW, cC = conv
@@ -116,6 +116,11 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
             raise RuntimeError("gemm(act=ACT_SWIGLU): an MX output needs out (float8_e4m3fn) AND out_scales")
         if out is None:
             out = torch.empty((M, N // 2), dtype=torch.bfloat16, device=A.device)
+    if act == ACT_SWIGLU_BWD:   # dgrad of the SwiGLU down-projection + activation backward: aux (M, 2h) = saved [g | u] (input), out (M, 2h) = d[g | u]
+        if aux is None or aux.dtype != torch.bfloat16 or tuple(aux.shape) != (M, 2 * N) or (out is not None and tuple(out.shape) != (M, 2 * N)):
+            raise RuntimeError("gemm(act=ACT_SWIGLU_BWD): aux is the saved bf16 (M, 2h) pre-activation buffer, out (M, 2h)")
+        if out is None:
+            out = torch.empty((M, 2 * N), dtype=torch.bfloat16, device=A.device)
     if out is None:
         if split_k > 1 or stream_k:
             # K-decomposed launch: partial tiles may be added atomically.  gemm_grouped asks the planner which outputs really
@@ -146,6 +151,7 @@ def _fill_gemm(a, A, B, *, a_kmajor=False, b_kmajor=False, out=None, out_dtype=N
     a.precision = precision
     a.split_k = split_k
     a.stream_k = int(stream_k)
+    a.dbias = _p(dbias)
     return out
 
 
@@ -164,7 +170,7 @@ def _variant(arr, n, outs):
         ab = "t,t" if a.precision == PREC_BF16 else "f,f"
         return f"gemm_kernel<{ab},{km},{int(a.precision == PREC_SPLIT)},{tc},{ta}>"
     if plan & 256:      # the 8-phase kernel (csrc/gemm8p.hip): <a_kmajor, b_kmajor, epilogue>
-        epi = "f32" if a.a_kmajor else "swiglu" if a.act == ACT_SWIGLU else "bf16"
+        epi = "f32" if a.a_kmajor else "swiglu" if a.act == ACT_SWIGLU else "swiglu_bwd" if a.act == ACT_SWIGLU_BWD else "bf16"
         return f"gemm8_kernel<{320 if plan & 15 == 3 else 256},{km},{epi}>" + ("+ktail" if plan & 32 else "")
     if plan & 128 and a.a_kmajor:
         return "gemm_kk_kernel<2,4,4,2>" + ("+ktail" if plan & 32 else "")
@@ -230,6 +236,27 @@ def gemm_grouped(problems):
         PROFILE.append((_variant(arr, n, outs), sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
         return outs
     check(_lib.lib().mmdit_gemm_grouped(arr, n, _s()), "mmdit_gemm_grouped")
+    return outs
+
+
+def gemm_swiglu_bwd(problems):
+    """Data gradient of the SwiGLU down-projection with the activation backward in its epilogue (MMDIT_ACT_SWIGLU_BWD): one launch for
+    the image and the text MLP.  problems: dicts with A = d(out) (M, d) bf16, B = w3 (d, h) [b_kmajor is set here], aux = the saved (M, 2h)
+    [g | u], dbias = fp32 (2h,) accumulating bias gradient or None.  Returns the list of d[g | u] (M, 2h) bf16 -- the bits of gemm() followed
+    by mlp_act_bwd() -- or None when the planner would not run these problems on the 8-phase 256 x 256 kernel (caller: the two passes)."""
+    n = len(problems)
+    arr = (GemmArgs * n)()
+    outs = [_fill_gemm(arr[i], **dict(problems[i], b_kmajor=True, act=ACT_SWIGLU_BWD)) for i in range(n)]
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = _lib.lib().mmdit_gemm_grouped(arr, n, _s())
+    if rc == _lib.ERR_SHAPE:
+        return None
+    check(rc, "mmdit_gemm_grouped(swiglu_bwd)")
+    if PROFILE is not None:
+        e1.record()
+        PROFILE.append((_variant(arr, n, outs), sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
     return outs
 
 

@@ -744,6 +744,33 @@ def test_gemm_swiglu_epilogue_equals_gemm_plus_row_kernel(ops, M, h, K, bias):
         ops.gemm(rnd(64, 64, dtype=torch.bfloat16), rnd(2 * 72, 64, dtype=torch.bfloat16), act=ops.ACT_SWIGLU, aux=torch.empty((64, 144), dtype=torch.bfloat16, device="cuda"))
 
 
+@pytest.mark.parametrize("M,h,K", [(16384, 3072, 768), (3000, 512, 128), (700, 264, 64)])
+def test_gemm_swiglu_bwd_epilogue_equals_gemm_plus_row_kernel(ops, M, h, K):
+    """act=ACT_SWIGLU_BWD (the SwiGLU backward formed in the epilogue of the down-projection's data-gradient GEMM) must be BIT-identical
+    to the plain bf16 GEMM dh = dY W3 followed by mmdit_swiglu_bwd, the bias gradients equal up to the order of the fp32 atomics, and
+    both agree with autograd through silu(g) * u -> F.linear (MLP.py:15-40) within bf16 rounding.  Ragged M and h, grouped launch."""
+    probs, refs = [], []
+    for s in range(2):
+        Mr = M if s == 0 else M // 2 + 5
+        dY, W3 = rnd(Mr, K, seed=80 + s, dtype=torch.bfloat16), rnd(K, h, seed=82 + s, scale=0.05, dtype=torch.bfloat16)   # nn.Linear(h, K).weight
+        gu = rnd(Mr, 2 * h, seed=84 + s, dtype=torch.bfloat16)
+        dh = ops.gemm(dY, W3, b_kmajor=True, out_dtype=torch.bfloat16)
+        db = torch.zeros(2 * h, device="cuda")
+        refs.append((ops.mlp_act_bwd(dh, gu, h, db, False), db))
+        probs.append(dict(A=dY, B=W3, aux=gu, dbias=torch.zeros(2 * h, device="cuda")))
+    outs = ops.gemm_swiglu_bwd(probs)
+    assert outs is not None
+    for p, o, (dgu, db) in zip(probs, outs, refs):
+        assert o.shape == dgu.shape and torch.equal(o, dgu)
+        assert rel(p["dbias"], db) < 1e-5
+        gr = p["aux"].float().requires_grad_(True)
+        g, u = gr.chunk(2, -1)
+        F.linear(F.silu(g) * u, p["B"].float()).backward(p["A"].float())
+        assert rel(o, gr.grad) < 6e-3 and rel(p["dbias"], gr.grad.sum(0)) < 6e-3
+    # a shape the LDS-DMA kernels do not take (K not a multiple of 64): None, the caller keeps the two passes
+    assert ops.gemm_swiglu_bwd([dict(A=rnd(64, 72, dtype=torch.bfloat16), B=rnd(72, 128, dtype=torch.bfloat16), aux=rnd(64, 256, dtype=torch.bfloat16))]) is None
+
+
 def test_gemm_block_wgrads_balanced_tail(ops):
     """All eight weight gradients of one MMDiT-B block at batch 64 (image K = 16384, text K = 9856; 288 tiles of 256x256 on 256
     workgroups): one full round plus a split tail that goes to the workgroups holding the short (text) tiles.  Given in
