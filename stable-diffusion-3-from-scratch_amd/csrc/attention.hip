@@ -1015,6 +1015,313 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
   stamp();                                   // stores done
 }
 
+#ifdef MMDIT_PROBES
+// ------------------------------------------------------------------------------------------------
+// backward dK/dV, DE-PHASED (round 4 experiment, probes build only: MMDIT_ATTN_DKV_DP=1).  Same arithmetic and fragment conventions as
+// attn_bwd_dkv_kernel above, another schedule.  MEASURED SLOWER than that kernel (backward of one block, S = 410, 64 x 12 heads, same box:
+// 264.9 vs 248.5 us; correct: the attention tests pass with it), so it is not the product path.  Ablations of this kernel (same box, backward =
+// dQ kernel ~105 us + this): full 268; without the stagger 272; no exponentials 262; no MFMAs 243; no LDS fragment reads 263; no DMA in the loop
+// 260; no MFMAs + no LDS reads + no exponentials 188 -- the pieces are small and nearly additive, and ~80 us remain without them: the fused
+// QK-norm / RoPE epilogue (HBM-bound row traffic, one workgroup per CU: nothing to overlap with), the launch and first-tile latency of six
+// rounds of workgroups, barriers and the non-transcendental VALU work.  De-phasing attacks MFMA / VALU serialisation, which is not where this
+// kernel's time is.  There a tile's phases -- S / dP MFMAs, softmax-backward VALU work, dV / dK MFMAs, each behind LDS fragment reads -- run
+// one after the other, because two workgroup barriers per tile put all eight waves into the same phase (cycle stamps, round 3: 5700 cycles
+// per tile against 2048 of matrix-pipe time).  Here:
+//  * the unit is a BLOCK of 32 queries (two per 64-query tile) with a V phase (the arithmetic of block b: P, dS packed to bf16 fragments) and
+//    an M phase (the dV / dK MFMAs of block b, then the S / dP MFMAs of block b + 1): 16 MFMAs against 16 exponentials + ~50 packed VALU slots;
+//  * the waves form two groups (wave >> 2: the two waves of every SIMD are in different groups) and group 1 runs ONE barrier behind group 0:
+//    between any two consecutive barriers one group is in a V phase and the other in an M phase, so on every SIMD the matrix pipe of one wave
+//    runs beside the VALU work of the other (the 8-phase GEMM's trick, csrc/gemm8p.hip);
+//  * Q / dO tiles (+ their lse / delta rows) go global -> LDS by LDS-DMA into a 4-stage ring (swizzle sw2 on the source address: the layout
+//    tile_r2s_sw writes), two tiles ahead, with counted vmcnt waits; no staging registers, no ds_write.
+// Hazards (barrier intervals: group 0 has V(b) in interval 2b and M(b) in 2b + 1, group 1 one later).  Tile j is read from M(2j - 1) (S / dP of
+// its first block) to M(2j + 1) (dV / dK of its second), i.e. until interval 4j + 4: its stage is refilled (tile j + 4) in M(2j + 2), interval
+// 4j + 5 / 4j + 6.  The LDS reads of an M phase are requested at the end of the V phase before it, so tile j is first read at the end of
+// V(2j - 1) (interval 4j - 2 / 4j - 1); the wait for it sits at the end of V(2j - 2) of every wave (interval <= 4j - 3).
+// ------------------------------------------------------------------------------------------------
+constexpr int DKV_ST = 4;                            // ring stages (a power of two)
+constexpr int DKV_STB = 2 * KT * 128 + 2 * KT * 4;   // 16896 B: Q tile, dO tile, lse row, delta row
+template <bool FUSE> constexpr int dkv_lds_bytes() { return FUSE && qk_lds_bytes<8>() > DKV_ST * DKV_STB ? qk_lds_bytes<8>() : DKV_ST * DKV_STB; }
+
+__device__ __forceinline__ void attn_glds4(const void* gptr, uint32_t lds_dst_) {    // 4 bytes per lane: 256 B per instruction
+  const uint32_t lds_dst = __builtin_amdgcn_readfirstlane(lds_dst_);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_dst) : "memory", "m0");
+}
+
+template <typename TG, bool FUSE>
+__global__ __launch_bounds__(512) void attn_bwd_dkv_dp_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                              const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV, QkFuse F = QkFuse()) {
+  constexpr int NW = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];      // dkv_lds_bytes<FUSE>(): the ring; afterwards the fused epilogue's tiles
+#ifdef MMDIT_DKV_GRP_LSB     // experiment: which waves share a SIMD?
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave & 1;
+#else
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2;
+#endif
+  MMDIT_YOUNG_HALF_PRIO();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)LDS_PTR(char, smem);
+  int ktile, bh;
+  map_block((S + 32 * NW - 1) / (32 * NW), BH, ktile, bh);
+  const int h = bh % H;
+  const int64_t b = bh / H;
+  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
+  const bf16_t* Kb = K + (int64_t)bh * S * HD;
+  const bf16_t* Vb = V + (int64_t)bh * S * HD;
+  const int key = ktile * 32 * NW + wave * 32 + (lane & 31);
+  const bool active = ktile * 32 * NW + wave * 32 < S;   // wave-uniform: a wave whose 32 keys are all padding only helps with the tile copies
+  const int keyc = min(key, S - 1);
+  const int n_txt = S - n_img, D = H * HD;
+  const int nq = (S + KT - 1) / KT, nblk = (S + 31) / 32;
+
+  // K / V fragments of this lane's key: requested first (asm: the compiler must not put a vmcnt(0) of its own in front of their first use --
+  // it cannot see the DMA queue); the first tile's counted wait covers them, the empty asm behind it carries the dependence
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(kf[ks]) : "v"(Kb + (int64_t)keyc * HD + ks * 16 + (lane >> 5) * 8) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(vf[ks]) : "v"(Vb + (int64_t)keyc * HD + ks * 16 + (lane >> 5) * 8) : "memory");
+  }
+  // this lane's 16 bytes of a Q / dO tile: row 8 * wave + (lane >> 3), LDS slot lane & 7 holds chunk slot ^ sw2(row); rows past the end re-read
+  // the last query (masked in the ragged block).  Wave 0 also copies the tile's 64 lse and delta values (4 bytes per lane).
+  const int rl = 8 * wave + (lane >> 3), dcol = ((lane & 7) ^ sw2(rl)) * 8;
+  auto issue = [&](int t) {
+    const uint32_t base = lds0 + (t & (DKV_ST - 1)) * DKV_STB;
+    const int row = min(t * KT + rl, S - 1);
+    attn_glds16(Qb + (int64_t)row * HD + dcol, base + wave * 1024);
+    attn_glds16(tok_ptr(dOx, dOc, b, row, n_img, n_txt, D, h) + dcol, base + KT * 128 + wave * 1024);
+    if (wave == 0) {
+      const int64_t r1 = (int64_t)bh * S + min(t * KT + lane, S - 1);
+      attn_glds4(lse + r1, base + 2 * KT * 128);
+      attn_glds4(delta + r1, base + 2 * KT * 128 + KT * 4);
+    }
+  };
+  auto wait_tiles = [&](int n) {      // all but the n youngest tiles of this wave's requests have landed (n = 0, 1, 2)
+    if (wave == 0) {
+      if (n >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else if (n == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      if (n >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else if (n == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+#pragma unroll
+  for (int t = 0; t < DKV_ST - 1; t++)
+    if (t < nq) issue(t);
+
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int db = 0; db < 2; db++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+  // per-lane LDS offsets of the fragment reads (tile / block / k-step parts are immediates: sw2 only involves row bits 1..3)
+  uint32_t rowoff[4], troff[2][2];
+  {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) rowoff[ks] = l31 * 128 + (((ks * 2 + hi) ^ sw2(l31)) << 4);
+    const int row0 = 4 * hi + ((lane & 15) >> 2);
+#pragma unroll
+    for (int cb = 0; cb < 2; cb++) {
+      const int cbyte = (cb * 32 + 16 * ((lane >> 4) & 1) + (lane & 3) * 4) * 2;
+      troff[cb][0] = row0 * 128 + ((((cbyte >> 4) ^ sw2(row0)) << 4) | (cbyte & 15));
+      troff[cb][1] = (row0 + 8) * 128 + ((((cbyte >> 4) ^ sw2(row0 + 8)) << 4) | (cbyte & 15));
+    }
+  }
+  const float c = scale * LOG2E;
+  f32x16 s, dp;
+  bf16x8 pf[2], dsf[2];
+  constexpr f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto tile_of = [&](int bq) { return smem + ((bq >> 1) & (DKV_ST - 1)) * DKV_STB; };
+  // fragment registers of an M phase: ALL LDS reads of the phase are requested before its first MFMA (the compiler's own order -- read two,
+  // wait, multiply -- left ~600 cycles of LDS latency per phase exposed, during which the SIMD's matrix pipe idled: the other wave is in
+  // its V phase)
+  bf16x8 fq[4], fo[4];       // row fragments of Q / dO (block bq + 1)
+  s16x4 tq4[2][2][2], to4[2][2][2];   // transposed fragments of Q / dO (block bq): [h8][db][low | high half]
+  auto read_rows = [&](int bq) {
+#ifdef MMDIT_DKV_NOLDS           // ablation: no LDS fragment reads (wrong results)
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { fq[ks] = kf[ks]; fo[ks] = vf[ks]; }
+    return;
+#endif
+    const char* tq = tile_of(bq) + (bq & 1) * 32 * 128;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      fq[ks] = *LDS_PTR(const bf16x8, tq + rowoff[ks]);
+      fo[ks] = *LDS_PTR(const bf16x8, tq + KT * 128 + rowoff[ks]);
+    }
+  };
+  auto read_tr = [&](int bq) {
+#ifdef MMDIT_DKV_NOLDS
+#pragma unroll
+    for (int h8 = 0; h8 < 2; h8++)
+#pragma unroll
+      for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int w = 0; w < 2; w++) { to4[h8][db][w] = (s16x4){1, 2, 3, (short)bq}; tq4[h8][db][w] = (s16x4){4, 3, 2, (short)bq}; }
+    return;
+#endif
+    const char* tq = tile_of(bq) + (bq & 1) * 32 * 128;
+#pragma unroll
+    for (int h8 = 0; h8 < 2; h8++)
+#pragma unroll
+      for (int db = 0; db < 2; db++)
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+          to4[h8][db][w] = lds_tr16(tq + h8 * 16 * 128 + KT * 128 + troff[db][w]);
+          tq4[h8][db][w] = lds_tr16(tq + h8 * 16 * 128 + troff[db][w]);
+        }
+  };
+  auto mfma_sdp = [&]() {        // S = Q K^T, dP = dO V^T of the block whose row fragments were read (rows = queries, lane = key)
+#ifdef MMDIT_DKV_NOMFMA          // ablation: no MFMAs (wrong results)
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) { s[ks] = (float)fq[ks][0]; dp[ks] = (float)fo[ks][0]; }
+    return;
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fq[ks], kf[ks], ks == 0 ? zero16 : s, 0, 0, 0);
+      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fo[ks], vf[ks], ks == 0 ? zero16 : dp, 0, 0, 0);
+    }
+  };
+  auto softmax_bwd = [&](int bq) {     // P = exp2(S c - lse), dS = P (dP - delta): packed fp32 pairs; -> bf16 fragments
+    const char* tl = tile_of(bq) + 2 * KT * 128;
+    const int qb = bq & 1, hi = lane >> 5;
+    f32x16 ds;
+    f32x4 lq[4], dq4[4];       // all eight (broadcast) reads first: one exposed LDS latency per phase instead of one per group
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const int r0 = qb * 32 + 8 * g + 4 * hi;
+      lq[g] = *LDS_PTR(const f32x4, tl + r0 * 4);
+      dq4[g] = *LDS_PTR(const f32x4, tl + KT * 4 + r0 * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      const f32x4 l4 = lq[g], d4 = dq4[g];
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        const int r = g * 4 + e;
+        const f32x2 sv = {s[r], s[r + 1]}, dpv = {dp[r], dp[r + 1]};
+        const f32x2 nl = (f32x2){l4[e], l4[e + 1]} * (f32x2){-LOG2E, -LOG2E};
+        const f32x2 t = __builtin_elementwise_fma(sv, (f32x2){c, c}, nl);
+#ifdef MMDIT_DKV_NOEXP          // ablation: no exponentials (wrong results)
+        const f32x2 pv = t;
+#else
+        const f32x2 pv = {fast_exp2(t[0]), fast_exp2(t[1])};
+#endif
+        const f32x2 dsv = pv * (dpv - (f32x2){d4[e], d4[e + 1]});
+        s[r] = pv[0]; s[r + 1] = pv[1];
+        ds[r] = dsv[0]; ds[r + 1] = dsv[1];
+      }
+    }
+    // Padding QUERIES exist in the last block only (their tile rows are copies of the last query): P and dS are zeroed there in a
+    // wave-uniform branch.  A lane whose key is padding works on the clamped last key and its dK / dV column is never stored.
+    if ((bq + 1) * 32 > S) {
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          if (bq * 32 + 8 * g + 4 * hi + e >= S) { s[g * 4 + e] = 0.f; ds[g * 4 + e] = 0.f; }
+    }
+#pragma unroll
+    for (int h8 = 0; h8 < 2; h8++) { pf[h8] = pack_frag(s, h8); dsf[h8] = pack_frag(ds, h8); }
+  };
+  auto mfma_dkv = [&]() {        // dV^T += dO^T P, dK^T += Q^T dS of the block whose transposed fragments were read
+#ifdef MMDIT_DKV_NOMFMA
+#pragma unroll
+    for (int h8 = 0; h8 < 2; h8++)
+#pragma unroll
+      for (int db = 0; db < 2; db++) { dv[db][h8] += (float)to4[h8][db][0][0] + (float)to4[h8][db][1][0] + (float)pf[h8][0]; dk[db][h8] += (float)tq4[h8][db][0][0] + (float)tq4[h8][db][1][0] + (float)dsf[h8][0]; }
+    return;
+#endif
+#pragma unroll
+    for (int h8 = 0; h8 < 2; h8++)
+#pragma unroll
+      for (int db = 0; db < 2; db++) {
+        const s16x4 olo = to4[h8][db][0], ohi = to4[h8][db][1], qlo = tq4[h8][db][0], qhi = tq4[h8][db][1];
+        const s16x8 of = {olo[0], olo[1], olo[2], olo[3], ohi[0], ohi[1], ohi[2], ohi[3]};
+        const s16x8 qf = {qlo[0], qlo[1], qlo[2], qlo[3], qhi[0], qhi[1], qhi[2], qhi[3]};
+        dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, of), pf[h8], dv[db], 0, 0, 0);
+        dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, qf), dsf[h8], dk[db], 0, 0, 0);
+      }
+  };
+  auto bar = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+
+  wait_tiles(min(2, nq - 1));
+  asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
+  bar();                                   // tile 0 has landed for every wave
+  if (active) { read_rows(0); mfma_sdp(); read_tr(0); }
+#ifndef MMDIT_DKV_NOSTAGGER    // (experiment: both groups in the same phase -- the same code as a lockstep kernel)
+  if (grp == 1) bar();                     // group 1 runs one barrier behind from here on
+#endif
+  for (int bq = 0; bq < nblk; bq++) {
+    // ---- V phase: the arithmetic of block bq; at its end the LDS reads of the M phase are REQUESTED (they complete under the barrier and
+    // the first MFMAs: nothing of the M phase waits for LDS latency with an idle matrix pipe)
+    if (active) softmax_bwd(bq);
+#ifdef MMDIT_DKV_NODMA
+    if (bq == 0) wait_tiles(0);
+#else
+    if (!(bq & 1)) wait_tiles(max(0, min(1, nq - 2 - (bq >> 1))));
+#endif
+    if (false) wait_tiles(0);   // tile (bq >> 1) + 1 (first read at the end of the NEXT V phase) has landed
+    __builtin_amdgcn_s_barrier();
+    // ---- M phase.  ALL LDS fragment traffic lives here, between the MFMAs (the V phase is pure VALU work): the row fragments of block
+    // bq + 1 are requested first and arrive under the dV / dK MFMAs of block bq (whose transposed fragments were requested in the previous
+    // M phase); the transposed fragments of block bq + 1 are requested behind those MFMAs and arrive under the S / dP MFMAs and the V phase.
+    if (active && bq + 1 < nblk) read_rows(bq + 1);
+    const int t2 = (bq >> 1) + DKV_ST - 1;
+#ifndef MMDIT_DKV_NODMA          // (ablation: the loop re-reads the first three tiles)
+    if (!(bq & 1) && t2 < nq) issue(t2);   // refill the stage of tile (bq >> 1) - 1: every wave left it two barriers ago
+#endif
+    if (active) {
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_dkv();
+      __builtin_amdgcn_sched_barrier(0);
+      if (bq + 1 < nblk) { read_tr(bq + 1); __builtin_amdgcn_sched_barrier(0); mfma_sdp(); }
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+#ifndef MMDIT_DKV_NOSTAGGER
+  if (grp == 0) bar();                     // rejoin
+#endif
+  __syncthreads();                         // every wave has left the ring
+  if constexpr (FUSE) {
+    // dK rows -> gradient of the raw k projection (qk_bwd_tile), dV rows into the v part of the same output rows
+    float* sdw = (float*)(smem + NW * QK_WAVE_BYTES);             // [image | text][64]
+    if (tid < 128) sdw[tid] = 0.f;
+    __syncthreads();
+    if (active) {
+      const int k0 = ktile * 32 * NW + wave * 32;
+      const bool img = k0 < n_img;                                   // wave-uniform: n_img % 32 == 0
+      const int tok0 = img ? k0 : k0 - n_img, nvalid = min(32, (img ? n_img : S) - k0);
+      const int64_t pitch = 3 * (int64_t)D, off = (img ? b * n_img + tok0 : b * n_txt + tok0) * pitch + D + h * HD;
+      bf16_t* ob = (img ? F.dqkv_x : F.dqkv_c) + off;
+      float* tile = (float*)(smem + wave * QK_WAVE_BYTES);
+      acc_to_lds(dk, tile, lane);
+      qk_bwd_tile(tile, scale, lane, nvalid, (img ? F.qkv_x : F.qkv_c) + off, ob, pitch, img ? F.wk_x : F.wk_c,
+                  img ? F.rcos + (int64_t)tok0 * 64 : nullptr, img ? F.rsin + (int64_t)tok0 * 64 : nullptr, sdw + (img ? 0 : 64));
+      __builtin_amdgcn_wave_barrier();
+      acc_to_lds(dv, tile, lane);
+      rows_from_tile(tile, lane, nvalid, ob + D, pitch);
+    }
+    __syncthreads();
+    if (tid < 128 && sdw[tid] != 0.f) atomicAdd(F.dw + (tid >> 6) * 128 + 64 + (tid & 63), sdw[tid]);   // [. | wk_x | . | wk_c]
+  } else if (key < S) {
+    TG* pk = dK + ((int64_t)bh * S + key) * HD;
+    TG* pv = dV + ((int64_t)bh * S + key) * HD;
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        float k4[4] = {dk[db][g * 4] * scale, dk[db][g * 4 + 1] * scale, dk[db][g * 4 + 2] * scale, dk[db][g * 4 + 3] * scale};
+        float v4[4] = {dv[db][g * 4], dv[db][g * 4 + 1], dv[db][g * 4 + 2], dv[db][g * 4 + 3]};
+        st4(pk + db * 32 + 8 * g + 4 * (lane >> 5), k4);
+        st4(pv + db * 32 + 8 * g + 4 * (lane >> 5), v4);
+      }
+  }
+}
+#endif   // MMDIT_PROBES
+
 // waves (32 queries / keys each) per workgroup: all waves of a workgroup share one stream of 64-row K/V (or Q/dO) tiles, so
 // 8 waves cut the tile copies and barriers per (batch, head) from 7x to 2x (measured at S = 410: forward 115 -> 70 us,
 // backward 372 -> 271 us).  7-wave workgroups would pad S = 410 less (448 instead of 512 rows) but measured slower (forward 96 vs
@@ -1122,11 +1429,21 @@ extern "C" int mmdit_attn_bwd_qk(const void* Q, const void* K, const void* V, co
   if (!mmdit_device_once(raised)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<8, bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+#ifdef MMDIT_PROBES
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_dp_kernel<bf16_t, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds_bytes<true>());
+#endif
     if (e != hipSuccess) return (int)e;             // (positive: a HIP error code, as from mmdit_launch_status)
     mmdit_device_mark(raised);
   }
   hipLaunchKernelGGL((attn_bwd_dq_kernel<8, bf16_t, true>), grid, dim3(512), lds, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Ox,
                      (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)nullptr, F);
+#ifdef MMDIT_PROBES      // experiment: the de-phased dK/dV kernel (MMDIT_ATTN_DKV_DP=1; needs a text output gradient when there are text tokens)
+  if (mmdit_exp_env("MMDIT_ATTN_DKV_DP") && atoi(mmdit_exp_env("MMDIT_ATTN_DKV_DP")) == 1 && (dOc || n_img == S)) {
+    hipLaunchKernelGGL((attn_bwd_dkv_dp_kernel<bf16_t, true>), grid, dim3(512), dkv_lds_bytes<true>(), s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx,
+                       (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)nullptr, (bf16_t*)nullptr, F);
+    return mmdit_launch_status();
+  }
+#endif
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, bf16_t, true>), grid, dim3(512), lds, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx,
                      (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)nullptr, (bf16_t*)nullptr, F);
   return mmdit_launch_status();
