@@ -20,3 +20,32 @@ class ImageLatentSource:
             raise RuntimeError("image sides must be multiples of 16 (8x VAE downsampling, 2x2 patches)")
         latents = self.vae.forward_VAE_and_sample(images, generator=self.generator)      # (B,16,H/8,W/8), normalised
         return latents.to(torch.bfloat16), text, pooled                                  # the trainer's wire format (model_trainer.py:353-355)
+
+    @classmethod
+    def synthetic(cls, batch, res, class_dim, device, text_len=154, text_dim=2304, seed=0):
+        """Fresh U(-1,1) images (batch, 3, res, res) and random text embeddings from a device generator every call, encoded by a FLUX-shaped
+        VAE with its constructor's random weights (the pretrained ones are not on the box): the data path of BASELINE.json configs[3]
+        for throughput runs (train.py --vae-in-rank, tools/config4_bench.py)."""
+        device = torch.device(device)
+        g = torch.Generator(device=device).manual_seed(seed)
+
+        def images():
+            x = torch.rand((batch, 3, res, res), generator=g, device=device) * 2 - 1
+            text = torch.randn((batch, text_len, text_dim), generator=g, device=device).to(torch.bfloat16)
+            pooled = torch.randn((batch, class_dim), generator=g, device=device).to(torch.bfloat16)
+            return x, text, pooled
+
+        vae = VAE_inference(device)
+        # the VAE's constructor leaves its parameters uninitialised (the reference always loads the pretrained file): seeded fan-in
+        # scaled weights, unit norm scales, zero biases -- activations stay O(1) through the encoder
+        gw = torch.Generator(device="cpu").manual_seed(seed + 2)
+        with torch.no_grad():
+            for name, prm in vae.VAE.named_parameters():
+                if prm.dim() >= 2:
+                    fan_in = prm[0].numel()
+                    prm.copy_((torch.randn(prm.shape, generator=gw) / fan_in ** 0.5).to(prm.device))
+                elif name.endswith("weight"):
+                    prm.fill_(1.0)
+                else:
+                    prm.zero_()
+        return cls(images, vae, generator=torch.Generator(device=device).manual_seed(seed + 1))

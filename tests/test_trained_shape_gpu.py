@@ -340,3 +340,17 @@ def test_train_entry_point_five_steps_at_the_trained_shape():
     assert rec["steps"] == 5 and rec["dim"] == 1216 and rec["num_heads"] == 19 and rec["num_blocks"] == 19
     assert len(rec["losses"]) == 5 and all(np.isfinite(rec["losses"])) and all(1e-2 < l < 20 for l in rec["losses"])
     assert rec["replayed_steps"] == 2 and rec["param_norm_moved"]      # (train() captures after max(3, graph_after) eager steps)
+
+
+def test_train_entry_point_with_vae_encode_in_the_rank():
+    """train.py --vae-in-rank (SURVEY 8f-1 / BASELINE configs[3]'s data path): synthetic 256^2 IMAGES are encoded by the HIP FLUX-VAE inside the
+    training rank in front of every step (the reference runs the VAE on dedicated loader GPUs, helpers/VAE_T5_CLIP.py:176-182).  Three steps
+    of a 2-block model: exit code 0, finite plausible losses, parameters moved; the step is eager (the encode is not part of a captured step)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--steps", "3", "--batch", "4", "--accumulation-steps", "1", "--num-blocks", "2",
+                          "--max-res", "256", "--vae-in-rank", "--json"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    print("[train.py --vae-in-rank]", rec)
+    assert rec["steps"] == 3 and rec["num_blocks"] == 2 and len(rec["losses"]) == 3
+    assert all(np.isfinite(rec["losses"])) and all(1e-2 < l < 20 for l in rec["losses"]) and rec["param_norm_moved"]
