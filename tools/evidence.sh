@@ -43,6 +43,18 @@ bash tools/pmc_collect.sh > gpurun_out/${R}_pmc_collect.log 2>&1
   echo "== tools/probes/gemm_ksweep.py"; python tools/probes/gemm_ksweep.py 20 2>&1 | grep -v amdgpu
 ) > gpurun_out/${R}_gemm8p_probe.txt 2>&1
 bash tools/pmc_attn.sh > gpurun_out/${R}_pmc_attention.txt 2>&1
+# round 4: the fused SwiGLU backward against its two-pass form, attention-forward workgroup geometries and the de-phased dK/dV kernel (probes build),
+# config 4's end-to-end line and the VAE encode's kernel table
+( echo "== tools/probes/swiglu_bwd_bench.py"; python tools/probes/swiglu_bwd_bench.py 2>&1 | grep -v amdgpu
+  echo "== tools/probes/attn_fwd_geo.sh"; bash tools/probes/attn_fwd_geo.sh 2>&1 | grep -v amdgpu
+  echo "== attention backward, lockstep (product) vs de-phased dK/dV kernel (probes build, MMDIT_ATTN_DKV_DP=1)"
+  MMDIT_LIB=tools/scratch/probes/libmmdit_hip.so python tools/attn_bench.py 30 2>&1 | grep "attn"
+  MMDIT_LIB=tools/scratch/probes/libmmdit_hip.so MMDIT_ATTN_DKV_DP=1 python tools/attn_bench.py 30 2>&1 | grep "attn"
+) > gpurun_out/${R}_round4_ab.txt 2>&1
+python tools/config4_bench.py 2>/dev/null | grep "^{" > gpurun_out/${R}_config4_line.json
+cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_v -o run -- python3 tools/probes/vae_encode_512.py > gpurun_out/${R}_vae_prof.log 2>&1
+python tools/rocpd_stats.py $(find gpurun_out/prof_${R}_v -name "*.db" | head -1) 7 30 > gpurun_out/${R}_config4_vae_encode_kernel_stats.txt; rm -rf gpurun_out/prof_${R}_v
 # MMDiT-L training step (config 4's model, batch 16) and the 28-step mxfp8 sampler (config 5): kernel tables
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_l -o run -- python3 tools/probes/l_config.py 16 > gpurun_out/${R}_l_prof.log 2>&1
