@@ -14,7 +14,7 @@ def norm(name):
     m = re.search(r"(gemm_dma_kernel|gemm_lean_kernel|gemm_wide_kernel|gemm_kernel)<([^>]*)>", name)   # demangled (csv output)
     if m:
         return m.group(1) + "<" + ",".join(_T.get(a.strip(), a.strip()) for a in m.group(2).split(",")) + ">"
-    _E8 = {"0": "bf16", "1": "swiglu", "2": "qk", "3": "f32"}
+    _E8 = {"0": "bf16", "1": "swiglu", "2": "qk", "3": "f32", "4": "swiglu_bwd"}
     m = re.search(r"gemm8_kernel<(\d+), (true|false), (true|false), (\d)", name)   # demangled: the names ops._variant gives the 8-phase kernel
     if m:
         return "gemm8_kernel<%s,%s,%s,%s>" % (m.group(1), _T[m.group(2)], _T[m.group(3)], _E8.get(m.group(4), m.group(4)))
