@@ -293,7 +293,8 @@ struct QkRequest {
   void* Q; void* K; void* V;
 };
 
-static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only, unsigned* zero_mask = nullptr, const QkRequest* qkr = nullptr) {
+static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only, unsigned* zero_mask = nullptr, const QkRequest* qkr = nullptr,
+                             bool no_dma_override = false) {
   MMDIT_CHECK_ARG(args && count >= 1 && count <= MAXG);
   const mmdit_gemm_args* a0 = &args[0];
   GroupParams gp;
@@ -305,7 +306,10 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   static const char* raster_env = mmdit_exp_env("MMDIT_GEMM_RASTER");
   // fp8 (e4m3) operands: DMA kernel only, row-major x row-major, K a multiple of the 128-wide fp8 K-tile, per-tensor scales
   const bool fp8 = a0->a_dtype == MMDIT_FP8 || a0->b_dtype == MMDIT_FP8;
-  bool dma = !no_dma && a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16;
+  bool dma = !no_dma && !no_dma_override && a0->precision == MMDIT_PREC_BF16 && a0->a_dtype == MMDIT_BF16 && a0->b_dtype == MMDIT_BF16;
+  // weight gradients whose reduction length is not a multiple of the K tile: the 8-phase kernel's K-tail instantiation takes them (gemm8p.hip KT);
+  // if the planner ends up elsewhere the launch is re-planned without the LDS-DMA kernels (below)
+  bool ktail_any = false;
   if (fp8) {
     MMDIT_CHECK_ARG(a0->a_dtype == MMDIT_FP8 && a0->b_dtype == MMDIT_FP8 && a0->precision == MMDIT_PREC_BF16 && split_k_of(a0) == 1 && !a0->stream_k);
     dma = true;
@@ -324,7 +328,10 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     MMDIT_CHECK_ARG((a->split_k > 1 ? a->split_k : 1) == split_k);
     if (fp8) MMDIT_CHECK_ARG(!a->a_kmajor && !a->b_kmajor && a->K % bk == 0 && a->scale_a && a->scale_b && !a->conv_mode && a->scale_mode == a0->scale_mode &&
                              (a->scale_mode == 0 || (a->scale_mode == 1 && aligned16(a->scale_a) && aligned16(a->scale_b))));
-    if (a->K % bk != 0) dma = false;
+    if (a->K % bk != 0) {
+      if (!fp8 && a->a_kmajor && a->b_kmajor && a->c_dtype == MMDIT_F32 && a->K > bk && !a->conv_mode) ktail_any = true;
+      else dma = false;
+    }
     if (a->a_kmajor && a->M < 8) dma = false;
     if (a->b_kmajor && a->N < 8) dma = false;
     if (a->conv_mode) {
@@ -542,9 +549,10 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   //  variant measured slower, 1.73 vs 1.59 ms per step)
   const bool p8 = p8_mode > 0 && ((kk && cfg == CFG_256x256) || (lean && (cfg == CFG_256x256 || (cfg == CFG_320x256 && p8_mode == 1 && !qkr))));
   if (swiglu_bwd && !p8) return MMDIT_ERR_SHAPE;
+  if (dma && ktail_any && !(kk && p8)) return gemm_grouped_impl(args, count, stream, plan_only, zero_mask, qkr, true);   // (only that kernel adds a K tail)
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
-  if (p8) return launch_gemm8(cfg, a0->a_kmajor, a0->b_kmajor, gp, s);
+  if (p8) return launch_gemm8(cfg, a0->a_kmajor, a0->b_kmajor, gp, s, ktail_any);
   if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
   if (kk) return launch_lean_wgrad(gp, s);
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, fp8, gp, s);

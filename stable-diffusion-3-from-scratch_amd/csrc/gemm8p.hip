@@ -454,9 +454,14 @@ __device__ __forceinline__ void epi8_f32_slot(AccT<MT>& acc, float* slot, int wm
 #define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define VMCNT8(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-template <int MT, bool A_KM, bool B_KM, int EPI>
+// KT (weight gradients only): the reduction length need not be a multiple of the 64-deep K tile (text rows = 154 x batch: 2464 at MMDiT-L batch 16,
+// 2002 at the reference's own batch 13).  The main loop runs the whole K tiles; the item that ends at the end of K then adds the remaining
+// K % 64 rows from one more tile whose k-rows beyond K are zero-filled on their way into LDS (a plain load + ds_write pass in the LDS-DMA image,
+// un-pipelined: once per output tile).  A separate instantiation: launches whose K are all multiples of 64 run the code without it.
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   static_assert(MT == 256 || MT == 320, "tile rows");
+  static_assert(!KT || (A_KM && B_KM && EPI == EPI_F32), "K tail: the weight-gradient kernel");
   static_assert(EPI == EPI_F32 ? (A_KM && B_KM && MT == 256) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major, 256 rows); bf16 epilogues take a row-major A");
   static_assert(!(EPI == EPI_SWIGLU || EPI == EPI_QK) || !B_KM, "fused epilogues: row-major weight");
   static_assert(EPI != EPI_SWIGLU_BWD || (B_KM && MT == 256), "SwiGLU backward epilogue: the data-gradient layout, 256-row tiles");
@@ -762,6 +767,35 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       if (wr == 0) BAR8();         // rejoin
       BAR8();                      // every wave's requests have landed and every wave has left the operand buffers
     }
+    if constexpr (KT) {
+      const Problem& q = gp.p[item.pi];
+      const int kfull = q.nk * 64, ktail = q.K - kfull;
+      if (ktail > 0 && item.h1 == 2 * q.nk) {      // (workgroup-uniform) this item ends at the end of K
+        // the tail tile into buffer 0, in the image the LDS-DMA writes (piece i of a half-tile: k-rows 32 i + 4 wave + (lane >> 4), 16 bytes per lane)
+        const bf16_t* Ab = (const bf16_t*)q.A + (int64_t)kfull * q.lda;
+        const bf16_t* Bb = (const bf16_t*)q.B + (int64_t)kfull * q.ldb;
+        const int kr0 = wave * 4 + (lane >> 4);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int i = 0; i < 2; i++) {
+            const int kr = kr0 + 32 * i;
+            u32x4 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+            if (kr < ktail) {
+              va = *(const u32x4*)(Ab + (int64_t)kr * q.lda + min((int)rowA + h * 64, limA));
+              vb = *(const u32x4*)(Bb + (int64_t)kr * q.ldb + min((int)rowB + h * 32, limB));
+            }
+            *LDS_PTR(u32x4, smem + (h ? XA1 : XA0) + wave * 1024 + lane * 16 + i * 8192) = va;
+            *LDS_PTR(u32x4, smem + (h ? XB1 : XB0) + wave * 1024 + lane * 16 + i * 8192) = vb;
+          }
+        __syncthreads();
+        readB(fb0, 0, XB0); readB(fb1s, 0, XB1); readA(0, XA0);
+        mma(acc.a[0][0], fb0); mma(acc.a[0][1], fb1s);
+        readA(0, XA1);
+        mma(acc.a[1][1], fb1s); mma(acc.a[1][0], fb0);
+        __syncthreads();             // every wave has left the buffers (epilogue staging / the next prologue reuse them)
+      }
+    }
     if (DEFER) { prev = item; pending = true; }
     else {
       run_epilogue(item);
@@ -772,9 +806,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   if (DEFER && pending) run_epilogue(prev);
 }
 
-template <int MT, bool A_KM, bool B_KM, int EPI>
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false>
 int launch8(const GroupParams& gp, hipStream_t s) {
-  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI>;
+  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI, KT>;
   constexpr int smem = Geo<MT>::SMEM;
   static unsigned long long attr_done = 0;   // one bit per device
   if (!mmdit_device_once(attr_done)) {
@@ -806,8 +840,12 @@ int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s) {
 
 // MT x 256 tiles (cfg CFG_256x256 or CFG_320x256).  a_km && b_km: fp32 weight gradients (256 rows; the K-decomposed schedule of gemm.hip);
 // otherwise bf16 output with the bias / SiLU, SwiGLU (gp.act) or QKV (gp.qk_on) epilogue.  gemm.hip has checked the rest.
-int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s) {
-  if (a_km) return b_km && cfg == CFG_256x256 ? launch8<256, true, true, EPI_F32>(gp, s) : MMDIT_ERR_ARG;
+int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s, bool ktail) {
+  if (a_km) {
+    if (!b_km || cfg != CFG_256x256) return MMDIT_ERR_ARG;
+    return ktail ? launch8<256, true, true, EPI_F32, true>(gp, s) : launch8<256, true, true, EPI_F32>(gp, s);
+  }
+  if (ktail) return MMDIT_ERR_ARG;
   if (cfg == CFG_320x256) return launch8_bf16<320>(b_km, gp, s);
   if (cfg == CFG_256x256) return launch8_bf16<256>(b_km, gp, s);
   return MMDIT_ERR_ARG;

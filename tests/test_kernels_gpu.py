@@ -744,6 +744,52 @@ def test_gemm_swiglu_epilogue_equals_gemm_plus_row_kernel(ops, M, h, K, bias):
         ops.gemm(rnd(64, 64, dtype=torch.bfloat16), rnd(2 * 72, 64, dtype=torch.bfloat16), act=ops.ACT_SWIGLU, aux=torch.empty((64, 144), dtype=torch.bfloat16, device="cuda"))
 
 
+def test_gemm_wgrad_reduction_length_not_a_multiple_of_the_k_tile(ops):
+    """Weight gradients dW = dY^T X whose reduction length (rows = tokens x batch) is NOT a multiple of the 64-deep K tile -- the text stream:
+    154 x 16 = 2464 rows at MMDiT-L batch 16, 154 x 13 = 2002 at the reference's own batch (src/train.py:13) -- stay on the 8-phase weight-gradient
+    kernel (its K-tail instantiation zero-fills the k-rows beyond K on their way into LDS) instead of the register-staged kernel: plan bit 256, results
+    against float64 products of the same bf16 operands.  Grouped with whole-K-tile problems as in a block's launch; K-decomposed (stream_k) and plain;
+    accumulation into an existing gradient; a K below one tile falls back (no fast path, still correct)."""
+    def make(shapes, seed, **kw):
+        probs, refs = [], []
+        for i, (rows, M, N) in enumerate(shapes):
+            dY, X = rnd(rows, M, seed=seed + 2 * i, dtype=torch.bfloat16), rnd(rows, N, seed=seed + 2 * i + 1, dtype=torch.bfloat16)
+            probs.append(dict(A=dY, B=X, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, **kw))
+            refs.append(dY.double().T @ X.double())
+        return probs, refs
+
+    def plan(probs):
+        arr = (ops.GemmArgs * len(probs))()
+        for i, p in enumerate(probs):
+            ops._fill_gemm(arr[i], **p)
+        return ops._lib.lib().mmdit_gemm_plan(arr, len(probs))
+
+    # (a) an MMDiT-L block's group: image rows 16384, text rows 2464 (= 38 K tiles + 32 rows), K-decomposed
+    shapes = [(16384, 1024, 1024), (2464, 1024, 1024), (16384, 3072, 1024), (2464, 3072, 1024), (2464, 1024, 4096), (2464, 8192, 1024)]
+    probs, refs = make(shapes, 500, stream_k=True)
+    assert plan(probs) & 256, plan(probs)
+    for o, r in zip(ops.gemm_grouped(probs), refs):
+        assert rel(o, r) < 1e-5
+    # (b) the reference's batch (154 x 13 = 2002 rows: 31 tiles + 18 rows) at its trained width, plain (not K-decomposed) and grouped with image rows
+    probs, refs = make([(3328, 1216, 1216), (2002, 1216, 1216), (3328, 4864, 1216), (2002, 4864, 1216), (2002, 1216, 9728)], 520)
+    assert plan(probs) & 256, plan(probs)
+    for o, r in zip(ops.gemm_grouped(probs), refs):
+        assert rel(o, r) < 1e-5
+    # ... and shapes for which the planner does not pick 256 x 256 tiles: whatever kernel runs, the result is right (ragged output, one tile + 36 rows)
+    for rows, M, N in [(2002, 456, 264), (100, 512, 256), (2464, 1024, 1024)]:
+        probs, refs = make([(rows, M, N)], 525)
+        assert rel(ops.gemm_grouped(probs)[0], refs[0]) < 1e-5
+    # (c) accumulation into an existing gradient
+    probs, refs = make([(2464, 1024, 1024)], 530, stream_k=True)
+    base = rnd(1024, 1024, seed=531)
+    probs[0]["out"], probs[0]["accumulate"] = base.clone(), True
+    assert rel(ops.gemm_grouped(probs)[0], refs[0] + base.double()) < 1e-5
+    # (d) fewer rows than one K tile: not the LDS-DMA kernels, still right
+    probs, refs = make([(40, 256, 256)], 540)
+    assert not plan(probs) & 256
+    assert rel(ops.gemm_grouped(probs)[0], refs[0]) < 1e-5
+
+
 @pytest.mark.parametrize("M,h,K", [(16384, 3072, 768), (3000, 512, 128), (700, 264, 64)])
 def test_gemm_swiglu_bwd_epilogue_equals_gemm_plus_row_kernel(ops, M, h, K):
     """act=ACT_SWIGLU_BWD (the SwiGLU backward formed in the epilogue of the down-projection's data-gradient GEMM) must be BIT-identical
