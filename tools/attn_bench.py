@@ -1,4 +1,4 @@
-"""Attention micro-benchmark on the MMDiT-B shape (batch 64, 12 heads, 256 image + 154 text tokens, head_dim 64).
+"""Attention micro-benchmark on the MMDiT-B shape (batch 64, 12 heads, 256 image + 154 text tokens, head_dim 64) or `reps B H N M`.
 Times forward and backward (prep + dQ + dK/dV launches) with HIP events; checks the outputs against a torch fp32 reference.
 python tools/attn_bench.py [reps]"""
 import os
@@ -12,6 +12,8 @@ from sd3_amd import ops  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 B, H, N, M, hd = 64, 12, 256, 154, 64
+if len(sys.argv) > 5:      # python tools/attn_bench.py reps B H N M   (e.g. 20 16 16 1024 154: MMDiT-L 512^2 batch 16)
+    B, H, N, M = (int(v) for v in sys.argv[2:6])
 S = N + M
 g = torch.Generator(device="cuda").manual_seed(0)
 rnd = lambda *s: torch.randn(s, generator=g, device="cuda").to(torch.bfloat16)

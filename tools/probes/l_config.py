@@ -13,10 +13,16 @@ tr = model_trainer(net, batchSize=B, accumulation_steps=1, totalSteps=1000, lr=1
                    hip_optimizer=os.environ.get("HIPOPT", "1") != "0")
 losses = [float(tr.train_step(s)) for s in range(1, 4)]
 torch.cuda.synchronize()
+mode = "eager"
+if os.environ.get("L_GRAPH", "1") != "0":      # replay the whole step from a hipGraph, as bench.py does (L_GRAPH=0: eager launches)
+    mode = "hipGraph replay" if tr.capture_graph_agreed(4) else "eager (capture failed)"
+    for s in range(4, 6):
+        tr.train_step(s)
+    torch.cuda.synchronize()
 t0 = time.perf_counter()
 n = 5
-for s in range(4, 4 + n):
+for s in range(6, 6 + n):
     tr.train_step(s)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / n
-print(f"MMDiT-L 512^2 batch {B}: losses {losses}, {dt * 1e3:.1f} ms/step, {B / dt:.1f} img/s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
+print(f"MMDiT-L 512^2 batch {B} [{mode}]: losses {losses}, {dt * 1e3:.1f} ms/step, {B / dt:.1f} img/s, peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
