@@ -770,7 +770,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     if constexpr (KT) {
       const Problem& q = gp.p[item.pi];
       const int kfull = q.nk * 64, ktail = q.K - kfull;
-      if (ktail > 0 && item.h1 == 2 * q.nk) {      // (workgroup-uniform) this item ends at the end of K
+      if (ktail > 0 && item.h1 == 2 * q.nk && item.h0 < item.h1) {      // (workgroup-uniform) the ONE item of the tile that ends at the end of K (an empty
+                                                                         //  split-K slice behind it has h0 == h1 == 2 nk as well)
         // the tail tile into buffer 0, in the image the LDS-DMA writes (piece i of a half-tile: k-rows 32 i + 4 wave + (lane >> 4), 16 bytes per lane)
         const bf16_t* Ab = (const bf16_t*)q.A + (int64_t)kfull * q.lda;
         const bf16_t* Bb = (const bf16_t*)q.B + (int64_t)kfull * q.ldb;

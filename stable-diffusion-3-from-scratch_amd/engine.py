@@ -199,13 +199,11 @@ def _wgrad_flush(m, pending):
     else:
         ctx = _NullCtx()
     with ctx:
-        # one launch per kernel variant: K-decomposed (long reductions) / regular, and -- a grouped launch runs ONE kernel -- reductions
-        # whose length is a multiple of the 64-deep K tile apart from the others: the LDS-DMA kernels need K % 64 == 0, and e.g. the text
-        # stream's 154 * batch rows are not for a per-GPU batch that is not a multiple of 32; grouped with them, the image stream's
-        # weight gradients (87 % of the FLOPs) fell back to the register-staged kernel too (MMDiT-L at batch 16: 31 of 96 ms per step)
-        # (cutting an unaligned reduction into floor(rows / 64) * 64 rows for the fast launch + an accumulate launch over the rest was
-        #  measured slower, MMDiT-L batch 16: 85.5 vs 77.6 ms/step same box -- the short text tiles then share the image tiles' launch and
-        #  lengthen its makespan, while the register-staged kernel handles the text problems alone well enough)
+        # one launch per kernel variant: K-decomposed (long reductions) / regular, and reductions whose length is a multiple of the 64-deep K
+        # tile apart from the others (the text stream's 154 * batch rows are not, for a per-GPU batch that is not a multiple of 32): the
+        # unaligned group runs on the 8-phase kernel's K-tail instantiation (csrc/gemm8p.hip KT; round 4 -- before, it fell to the
+        # register-staged kernel), the aligned group on the plain one.  Merging the two launches gains nothing: MMDiT-L's 256 image tiles are
+        # exactly one round, the 256 short text tiles a second one either way.
         for flag in (True, False):
             for aligned in (True, False):
                 part = [pd for pd in pending if (bool(pd[1].get("stream_k")) or pd[1].get("split_k", 1) > 1) == flag and (pd[1]["A"].shape[0] % 64 == 0) == aligned]

@@ -784,6 +784,11 @@ def test_gemm_wgrad_reduction_length_not_a_multiple_of_the_k_tile(ops):
     base = rnd(1024, 1024, seed=531)
     probs[0]["out"], probs[0]["accumulate"] = base.clone(), True
     assert rel(ops.gemm_grouped(probs)[0], refs[0] + base.double()) < 1e-5
+    # (c2) few output tiles, so that the K decomposition cuts every tile into MORE slices than it has K tiles (empty slices behind the last one)
+    probs, refs = make([(2464, 256, 128), (2464, 384, 256), (2100, 128, 128)], 535, stream_k=True)
+    assert plan(probs) & 256, plan(probs)
+    for o, r in zip(ops.gemm_grouped(probs), refs):
+        assert rel(o, r) < 1e-5
     # (d) fewer rows than one K tile: not the LDS-DMA kernels, still right
     probs, refs = make([(40, 256, 256)], 540)
     assert not plan(probs) & 256
@@ -1212,9 +1217,8 @@ def test_trainer_hip_loss_equals_torch_loss_step():
 
 def test_weight_gradient_flush_groups_by_k_alignment():
     """engine._wgrad_flush: a block's weight gradients dW = dY^T X in grouped launches.  The text stream's 154 * batch rows are not a
-    multiple of the 64-deep K tile of the LDS-DMA kernels for most batch sizes; a grouped launch runs ONE kernel, so such problems
-    get a launch of their own (register-staged kernel) instead of dragging the aligned image problems there with them.  All outputs
-    must equal the fp32 products of the bf16 operands."""
+    multiple of the 64-deep K tile for most batch sizes; such problems get a launch of their own (the 8-phase kernel's K-tail instantiation
+    since round 4, the register-staged kernel before).  All outputs must equal the fp32 products of the bf16 operands."""
     from sd3_amd import engine
     got = {}
     shapes = [(16384, 256, 128), (2464, 256, 128), (2464, 384, 256), (4096, 128, 384), (2100, 128, 128), (64, 256, 128)]

@@ -10,6 +10,8 @@ import sd3_amd  # noqa
 from sd3_amd import _lib, ops
 
 B, H, N, M = 64, 12, 256, 154
+if len(sys.argv) > 4:      # python tools/probes/attn_bwd_trace.py B H N M   (e.g. 4 19 4096 154: the 1024^2 stage; the first tiles are traced)
+    B, H, N, M = (int(v) for v in sys.argv[1:5])
 S = N + M
 g = torch.Generator(device="cuda").manual_seed(0)
 rnd = lambda *s: torch.randn(s, generator=g, device="cuda").to(torch.bfloat16)
@@ -35,16 +37,18 @@ for _ in range(3):
     assert rc == 0, rc
 torch.cuda.synchronize()
 t = trace.cpu().numpy().astype("float64")
-nq = (S + 63) // 64
+nq_all = (S + 63) // 64
 PT = 9                      # stamps per tile
-last = 2 + PT * nq + 1
+nq = min(nq_all, (NS - 3) // PT)      # tiles that fit the 72 stamp slots of a wave (long sequences: the first 7)
+last = 2 + PT * nq + 1 if nq == nq_all else 1 + PT * nq
 nwg = ((S + 255) // 256) * B * H
 t = t[:min(nwg, 2048)]
 ids = np.arange(t.shape[0])
-sel = t[((ids >> 3) % 2) == 0]                 # workgroups whose 256 keys are all real (key tile 0)
+ntile = (S + 255) // 256
+sel = t[((ids >> 3) % ntile) == 0] if (B * H) % 8 == 0 else t[(ids % ntile) == 0]      # workgroups of key tile 0 (all 256 keys real)
 names = ["barrier 1 (leave previous tile)", "wait for chunks + LDS write", "barrier 2", "q 0-31: S/dP MFMAs issued", "q 0-31: softmax arithmetic", "q 0-31: dV/dK MFMAs issued",
          "q 32-63: S/dP MFMAs issued", "q 32-63: softmax arithmetic", "q 32-63: dV/dK MFMAs issued"]
-print(f"workgroups traced: {t.shape[0]}; wave lifetime (median over waves 0..7 of key-tile-0 workgroups): "
+print(f"B {B} H {H} S {S} ({nq_all} tiles, {nq} traced); workgroups traced: {t.shape[0]}; start -> last stamp (median over waves 0..7 of key-tile-0 workgroups): "
       f"{[int(np.median(sel[:, w, last] - sel[:, w, 0])) for w in range(8)]} ticks")
 for w in (0, 4, 1, 7):
     full = sel[:, w, :]
@@ -52,8 +56,8 @@ for w in (0, 4, 1, 7):
     print(f"--- wave {w}: prologue {np.median(d[:, 0]):.0f}; median ticks per phase, tiles 1..{nq - 2} averaged (tile 0 and the ragged last tile apart)")
     mid = np.stack([d[:, 1 + PT * j:1 + PT * (j + 1)] for j in range(1, nq - 1)], 0).mean(0)
     for k, nm in enumerate(names):
-        print(f"    {nm:<34} {np.median(mid[:, k]):8.0f}   (tile 0: {np.median(d[:, 1 + k]):6.0f}, last tile: {np.median(d[:, 1 + PT * (nq - 1) + k]):6.0f})")
-    print(f"    {'tile total':<34} {np.median(mid.sum(1)):8.0f};   loop end + stores {np.median(d[:, 1 + PT * nq] + d[:, 2 + PT * nq]):.0f}")
+        print(f"    {nm:<34} {np.median(mid[:, k]):8.0f}   (tile 0: {np.median(d[:, 1 + k]):6.0f}, last traced tile: {np.median(d[:, 1 + PT * (nq - 1) + k]):6.0f})")
+    print(f"    {'tile total':<34} {np.median(mid.sum(1)):8.0f}" + (f";   loop end + stores {np.median(d[:, 1 + PT * nq] + d[:, 2 + PT * nq]):.0f}" if nq == nq_all else ""))
 # one workgroup's two waves of a SIMD side by side: absolute times inside tile 3
 wg = sel[5]
 t3 = wg[:, 2 + PT * 3:2 + PT * 4 + 1] - wg[0, 2 + PT * 3]
