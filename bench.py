@@ -227,9 +227,19 @@ def main():
         # the measurement is never lost to the capture.  --graph makes this rank's own capture error fatal (after the agreement).
         if trainer.capture_graph_agreed(step + 1, strict=args.graph):
             launch = "hipGraph replay"
+        c_before = param_checksum()
+        warm = []
         for _ in range(2):              # (the first replays also warm the graph's own memory; eager fallback: the same step count on every rank)
             step += 1
-            trainer.train_step(step)
+            warm.append(trainer.train_step(step).clone())
+        if launch == "hipGraph replay":
+            # the replays must have trained on EVERY rank, or every rank goes back to eager launches (model_trainer.keep_graph_if_agreed)
+            ok = all(1e-3 < float(l) < 10 for l in warm) and param_checksum() != c_before
+            if not trainer.keep_graph_if_agreed(ok):
+                launch = "eager (replay check failed on some rank)"
+                for _ in range(2):
+                    step += 1
+                    trainer.train_step(step)
     warmup_effective = step
     sync()
     check0 = param_checksum()

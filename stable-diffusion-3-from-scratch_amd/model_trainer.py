@@ -442,6 +442,27 @@ class model_trainer:
             raise err
         return ok_all
 
+    def keep_graph_if_agreed(self, ok_local, what="the first replayed steps"):
+        """Second half of the collective launch-mode decision: after the first replays every rank reports whether ITS replayed steps
+        trained (finite, plausible losses; parameters moved).  MIN over the ranks; a failure anywhere -> every rank drops its graph and
+        goes on with eager launches (the same collectives per step, issued from the host).  A captured step that replays wrongly on some
+        rank (never observed; graph capture with RCCL collectives has only run on one rank so far) then costs the replay's ~1 % instead of
+        the run.  Returns True when the ranks keep replaying."""
+        import sys
+        if self._graph is None:
+            return False
+        ok_all = bool(ok_local)
+        if dist.is_initialized() and self.world > 1:
+            flag = torch.tensor([1 if ok_local else 0], dtype=torch.int32,
+                                device=self.device if dist.get_backend(self.subgroup) == "nccl" else torch.device("cpu"))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.subgroup)
+            ok_all = bool(int(flag))
+        if not ok_all:
+            self._graph, self._slots = None, None
+        print(f"[model_trainer rank {self.rank}/{self.world}] {what}: {'ok' if ok_local else 'NOT ok on this rank'}; "
+              f"launch mode for all ranks from here on: {'hipGraph replay' if ok_all else 'eager'}", file=sys.stderr, flush=True)
+        return ok_all
+
     def _wait_for_watchdog(self, timeout_s=None):
         """Block until RCCL's watchdog thread has retired every EAGER collective of this process.
 

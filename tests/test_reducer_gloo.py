@@ -455,6 +455,12 @@ def _agree_worker(rank, world, port, fail_rank, q):
     tr.capture_graph = fake_capture
     agreed = tr.capture_graph_agreed(2)
     kept = tr._graph is sentinel
+    if fail_rank is None:
+        # second half of the decision: the replay check.  Every rank fine -> the graph stays; rank 1 reports a bad replay -> BOTH drop it
+        assert tr.keep_graph_if_agreed(True) and tr._graph is sentinel
+        assert not tr.keep_graph_if_agreed(rank != 1) and tr._graph is None
+        assert not tr.keep_graph_if_agreed(True)          # (no graph: nothing to keep, and no collective is issued)
+        tr._graph = sentinel if kept else None
     strict_raised = False
     if fail_rank is not None:
         tr._graph = None
