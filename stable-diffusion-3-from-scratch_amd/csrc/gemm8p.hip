@@ -517,6 +517,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   bf16x8 fa[2 * FI], fb0[4], fb1s[4];
   bf16x8 (&fb1)[4] = MT == 256 ? fb1s : fb0;      // (320 rows: ONE set of B fragments, see REREAD below)
 #define FB1 fb1
+#ifdef MMDIT_G8_SPLITWAIT     // experiment (-DMMDIT_G8_SPLITWAIT, NOT the product): fragments in k-step order and a COUNTED lgkmcnt in front of the phase's first barrier,
+                              // so that the first k-step's MFMAs start while the second one's reads are in flight.  Measured (same box, tools/gemm_bench.py):
+                              // 8192^3 NT 1470 -> 1511, NN 1420 -> 1444, TN 1318 -> 1316 TF, SwiGLU up-projection 280 -> 268 us, block weight gradients
+                              // 462 -> 455 us; all GEMM tests pass.  Not shipped: it breaks the hazard rule the schedule is built on -- the other
+                              // group restages this half-tile one barrier later, and a read that has not retired by then is protected only by the
+                              // DMA's latency (>= 500 cycles against <= 250 of queued LDS reads): a race with a margin, for 1.5-3 %.
+  auto readA1 = [&](int buf, int x, int ks) {
+#pragma unroll
+    for (int i = 0; i < FI; i++) fa[i * 2 + ks] = frag(A_KM, smem + buf * KBUF + x + (A_KM ? aoff[A_KM ? i * 2 + ks : 0] : aoff[ks] + i * 2048));
+  };
+  auto readB1 = [&](bf16x8 (&fb)[4], int buf, int x, int ks) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) fb[j * 2 + ks] = frag(B_KM, smem + buf * KBUF + x + (B_KM ? boff[B_KM ? j * 2 + ks : 0] : boff[ks] + j * 2048));
+  };
+#endif
   auto readA = [&](int buf, int x) {
 #pragma unroll
     for (int i = 0; i < FI; i++)
@@ -630,12 +645,23 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     else VMCNT8(NA * (PAW - 1) + NB * 2);
   };
 
+#ifdef MMDIT_G8_SPLITWAIT
+#define P1_READS(cur) readB1(fb0, cur, XB0, 0); readA1(cur, XA0, 0); __builtin_amdgcn_sched_barrier(0); readB1(fb0, cur, XB0, 1); readA1(cur, XA0, 1);
+#define P1_WAIT() asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(((A_KM ? 2 : 1) * FI + (B_KM ? 4 : 2)) > 15 ? 15 : ((A_KM ? 2 : 1) * FI + (B_KM ? 4 : 2))) : "memory")
+#define P3_READS(cur) readA1(cur, XA1, 0); __builtin_amdgcn_sched_barrier(0); readA1(cur, XA1, 1);
+#define P3_WAIT() asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((A_KM ? 2 : 1) * FI) : "memory")
+#else
+#define P1_READS(cur) readB(fb0, cur, XB0); __builtin_amdgcn_sched_barrier(0); readA(cur, XA0);
+#define P1_WAIT() LGKM0()
+#define P3_READS(cur) readA(cur, XA1);
+#define P3_WAIT() LGKM0()
+#endif
 #define KTILE8(cur)                                                                                          \
   {                                                                                                          \
     /* P1 */                                                                                                 \
-    readB(fb0, cur, XB0); __builtin_amdgcn_sched_barrier(0); readA(cur, XA0);                                 \
+    P1_READS(cur)                                                                                            \
     if (REREAD) stageB(0, 1, (cur) ^ 1); else stageA(1, 1, (cur) ^ 1);                           \
-    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    P1_WAIT(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                    \
     mma(acc.a[0][0], fb0);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P2 */                                                                                                 \
@@ -645,9 +671,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     mma(acc.a[0][1], FB1);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P3 */                                                                                                 \
-    readA(cur, XA1);                                                                                         \
+    P3_READS(cur)                                                                                            \
     if (REREAD) stageB(1, 2, cur); else stageB(0, 2, cur);                                       \
-    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    P3_WAIT(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                    \
     mma(acc.a[1][1], FB1);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P4 */                                                                                                 \
