@@ -1036,8 +1036,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 //    tile_r2s_sw writes), two tiles ahead, with counted vmcnt waits; no staging registers, no ds_write.
 // Hazards (barrier intervals: group 0 has V(b) in interval 2b and M(b) in 2b + 1, group 1 one later).  Tile j is read from M(2j - 1) (S / dP of
 // its first block) to M(2j + 1) (dV / dK of its second), i.e. until interval 4j + 4: its stage is refilled (tile j + 4) in M(2j + 2), interval
-// 4j + 5 / 4j + 6.  The LDS reads of an M phase are requested at the end of the V phase before it, so tile j is first read at the end of
-// V(2j - 1) (interval 4j - 2 / 4j - 1); the wait for it sits at the end of V(2j - 2) of every wave (interval <= 4j - 3).
+// 4j + 5 / 4j + 6.  All LDS fragment reads sit in the M phases (row fragments of block b + 1 first, transposed fragments of block b + 1 behind
+// the dV / dK MFMAs of block b); tile j is first read at the start of M(2j - 1), and the wait for it sits at the end of V(2j - 2) of every
+// wave (interval <= 4j - 3), two barriers earlier.
 // ------------------------------------------------------------------------------------------------
 constexpr int DKV_ST = 4;                            // ring stages (a power of two)
 constexpr int DKV_STB = 2 * KT * 128 + 2 * KT * 4;   // 16896 B: Q tile, dO tile, lse row, delta row
@@ -1255,15 +1256,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_dp_kernel(const bf16_t* __re
   if (grp == 1) bar();                     // group 1 runs one barrier behind from here on
 #endif
   for (int bq = 0; bq < nblk; bq++) {
-    // ---- V phase: the arithmetic of block bq; at its end the LDS reads of the M phase are REQUESTED (they complete under the barrier and
-    // the first MFMAs: nothing of the M phase waits for LDS latency with an idle matrix pipe)
+    // ---- V phase: the arithmetic of block bq (pure VALU work); at its end the wait for tile (bq >> 1) + 1, first read in the NEXT M phase
     if (active) softmax_bwd(bq);
 #ifdef MMDIT_DKV_NODMA
     if (bq == 0) wait_tiles(0);
 #else
     if (!(bq & 1)) wait_tiles(max(0, min(1, nq - 2 - (bq >> 1))));
 #endif
-    if (false) wait_tiles(0);   // tile (bq >> 1) + 1 (first read at the end of the NEXT V phase) has landed
     __builtin_amdgcn_s_barrier();
     // ---- M phase.  ALL LDS fragment traffic lives here, between the MFMAs (the V phase is pure VALU work): the row fragments of block
     // bq + 1 are requested first and arrive under the dV / dK MFMAs of block bq (whose transposed fragments were requested in the previous
