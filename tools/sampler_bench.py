@@ -47,6 +47,19 @@ class _Enc:
         return torch.randn(1, 154, 2304, generator=g) * 3, torch.randn(1, 768, generator=g)
 
 
+def fwd_flops(d, blocks, N, M=154):
+    """algorithmic FLOPs of one forward per image (GEMM + attention matmuls, multiply-add = 2)."""
+    S, h = N + M, 4 * d
+    f = 2 * d * d + 2 * 768 * d + 2 * M * 2304 * d + 2 * N * 64 * d + 2 * N * d * d + 4 * d * d + 2 * N * d * 64
+    for i in range(blocks):
+        last = i == blocks - 1
+        f += 2 * d * d + 4 * d * d * (3 if last else 4) + 2 * d * d * (2 if last else 4) + 8 * N * d * d + 2 * M * d * d * (3 if last else 4) + 4 * S * S * d
+        f += 6 * d * h * N + (0 if last else 6 * d * h * M)
+    return f
+
+
+import json  # noqa: E402
+F_FWD = fwd_flops(cfg["dim"], cfg["num_blocks"], (res // 16) ** 2)
 net.text_encoders = _Enc()
 for prec in ("fast", "fp8", "mxfp8"):
     net.set_precision(prec)
@@ -58,3 +71,8 @@ for prec in ("fast", "fp8", "mxfp8"):
     dt = time.perf_counter() - t0
     print(f"{'MMDiT-B 256^2' if args.B else 'MMDiT-L 512^2'} sampler, {args.steps} Euler steps, CFG, batch {args.batch} [{'bf16' if prec == 'fast' else prec}]: "
           f"{dt * 1e3:.1f} ms, {args.batch / dt:.2f} images/s, finite={bool(torch.isfinite(out).all())}")
+    peak = 2.5e15 if prec == "fast" else 5.0e15        # dense bf16 / fp8 MFMA peak (MI355X_MICROARCH.md)
+    ach = args.batch / dt * args.steps * 2 * F_FWD     # CFG: two forwards per step and image
+    print(json.dumps({"metric": "sampler images/sec", "value": round(args.batch / dt, 2), "config": {"workload": f"{'MMDiT-B 256^2' if args.B else 'MMDiT-L 512^2'} {args.steps}-step Euler CFG sampler", "batch": args.batch},
+                      "dtype": "bf16" if prec == "fast" else prec, "roofline": {"bound": "mfma", "achieved": round(ach / 1e12, 1), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                                                                               "tflop_per_image": round(args.steps * 2 * F_FWD / 1e12, 2)}}))
