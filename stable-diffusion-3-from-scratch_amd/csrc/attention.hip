@@ -1049,12 +1049,24 @@ __device__ __forceinline__ void attn_glds4(const void* gptr, uint32_t lds_dst_) 
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gptr), "s"(lds_dst) : "memory", "m0");
 }
 
-template <typename TG, bool FUSE>
+template <typename TG, bool FUSE, bool TRACE = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_dp_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
                                                               const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
-                                                              int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV, QkFuse F = QkFuse()) {
+                                                              int BH, int H, int S, int n_img, float scale, TG* __restrict__ dK, TG* __restrict__ dV, QkFuse F = QkFuse(),
+                                                              unsigned long long* __restrict__ trace = nullptr) {
   constexpr int NW = 8;
+  // TRACE (tools/probes/attn_bwd_trace.py --dp): lane 0 of every wave stamps the cycle counter: 0 start, 1 prologue done (first S / dP issued);
+  // per block: +0 V-phase arithmetic issued, +1 past the barrier, +2 row reads + DMA issued, +3 dV / dK MFMAs issued, +4 S / dP MFMAs issued and past
+  // the second barrier
+  int tpos = 0;
+  auto stamp = [&]() {
+    if constexpr (TRACE) {
+      if (blockIdx.x < 2048 && (threadIdx.x & 63) == 0 && tpos < 72) trace[((int64_t)blockIdx.x * NW + (threadIdx.x >> 6)) * 72 + tpos] = __builtin_readcyclecounter();
+      tpos++;
+    }
+  };
+  stamp();
   extern __shared__ __attribute__((aligned(16))) char smem[];      // dkv_lds_bytes<FUSE>(): the ring; afterwards the fused epilogue's tiles
 #ifdef MMDIT_DKV_GRP_LSB     // experiment: which waves share a SIMD?
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave & 1;
@@ -1252,18 +1264,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_dp_kernel(const bf16_t* __re
   asm volatile("" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]));
   bar();                                   // tile 0 has landed for every wave
   if (active) { read_rows(0); mfma_sdp(); read_tr(0); }
+  stamp();
 #ifndef MMDIT_DKV_NOSTAGGER    // (experiment: both groups in the same phase -- the same code as a lockstep kernel)
   if (grp == 1) bar();                     // group 1 runs one barrier behind from here on
 #endif
   for (int bq = 0; bq < nblk; bq++) {
     // ---- V phase: the arithmetic of block bq (pure VALU work); at its end the wait for tile (bq >> 1) + 1, first read in the NEXT M phase
     if (active) softmax_bwd(bq);
+    stamp();
 #ifdef MMDIT_DKV_NODMA
     if (bq == 0) wait_tiles(0);
 #else
     if (!(bq & 1)) wait_tiles(max(0, min(1, nq - 2 - (bq >> 1))));
 #endif
     __builtin_amdgcn_s_barrier();
+    stamp();
     // ---- M phase.  ALL LDS fragment traffic lives here, between the MFMAs (the V phase is pure VALU work): the row fragments of block
     // bq + 1 are requested first and arrive under the dV / dK MFMAs of block bq (whose transposed fragments were requested in the previous
     // M phase); the transposed fragments of block bq + 1 are requested behind those MFMAs and arrive under the S / dP MFMAs and the V phase.
@@ -1272,13 +1287,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_dp_kernel(const bf16_t* __re
 #ifndef MMDIT_DKV_NODMA          // (ablation: the loop re-reads the first three tiles)
     if (!(bq & 1) && t2 < nq) issue(t2);   // refill the stage of tile (bq >> 1) - 1: every wave left it two barriers ago
 #endif
+    stamp();
     if (active) {
       __builtin_amdgcn_sched_barrier(0);
       mfma_dkv();
       __builtin_amdgcn_sched_barrier(0);
+      stamp();
       if (bq + 1 < nblk) { read_tr(bq + 1); __builtin_amdgcn_sched_barrier(0); mfma_sdp(); }
-    }
+    } else stamp();
     __builtin_amdgcn_s_barrier();
+    stamp();
   }
 #ifndef MMDIT_DKV_NOSTAGGER
   if (grp == 0) bar();                     // rejoin
@@ -1407,6 +1425,23 @@ extern "C" int mmdit_probe_attn_bwd_dkv_trace(const void* Q, const void* K, cons
                                               int batch, int heads, int S, int n_img, float scale, void* dK, void* dV, void* trace, mmdit_stream_t stream) {
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<8, bf16_t, false, true>), dim3(((S + 255) / 256) * batch * heads), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)Q, (const bf16_t*)K,
                      (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)dK, (bf16_t*)dV, QkFuse(),
+                     (unsigned long long*)trace);
+  return mmdit_launch_status();
+}
+#endif
+
+#ifdef MMDIT_PROBES
+// the same stamps for the de-phased kernel (plain epilogue): trace = 2048 workgroups x 8 waves x 72 slots
+extern "C" int mmdit_probe_attn_bwd_dkv_dp_trace(const void* Q, const void* K, const void* V, const void* dOx, const void* dOc, const float* lse, const float* delta,
+                                                 int batch, int heads, int S, int n_img, float scale, void* dK, void* dV, void* trace, mmdit_stream_t stream) {
+  static unsigned long long raised = 0;
+  if (!mmdit_device_once(raised)) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_dp_kernel<bf16_t, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, dkv_lds_bytes<false>());
+    if (e != hipSuccess) return (int)e;
+    mmdit_device_mark(raised);
+  }
+  hipLaunchKernelGGL((attn_bwd_dkv_dp_kernel<bf16_t, false, true>), dim3(((S + 255) / 256) * batch * heads), dim3(512), dkv_lds_bytes<false>(), (hipStream_t)stream, (const bf16_t*)Q,
+                     (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)dK, (bf16_t*)dV, QkFuse(),
                      (unsigned long long*)trace);
   return mmdit_launch_status();
 }
