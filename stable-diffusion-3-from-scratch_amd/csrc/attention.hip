@@ -573,6 +573,19 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_dma_kernel(const bf16_t* __r
     }
     // p = 2^(s c - m): the scale-and-shift and the row sums as packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot);
     // the 32 v_exp_f32 stay scalar -- they are the VALU floor of a tile
+#ifdef MMDIT_ATTN_SCALAR_MATH      // experiment: one-value fp32 instructions (they co-issue with the other waves' MFMAs; v_pk_* do not: tools/probes/mfma_valu_mix.hip)
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float t = fmaf(s[kb][r], c, -m);       // (compile with -fno-slp-vectorize, or the compiler packs these again)
+        const float pe = (DBG & 1) ? t : fast_exp2(t);
+        s[kb][r] = pe;
+        if (!(DBG & 32)) rs += pe;
+      }
+    l += rs + partner32(rs, lane);
+#else
     f32x2 rs2 = {0.f, 0.f};
     const f32x2 c2 = {c, c}, nm2 = {-m, -m};
 #pragma unroll
@@ -588,6 +601,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_dma_kernel(const bf16_t* __r
       }
     const float rs = rs2[0] + rs2[1];
     l += rs + partner32(rs, lane);
+#endif
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
       if (j * KT + kb * 32 < S)
