@@ -601,11 +601,18 @@ class model_trainer:
             dist.barrier()
         self.model.train()
         batch_loss, t0 = 0.0, time.time()
+        replay_checks = 0
         opt_steps = self.start_step // self.accumulation_steps
         for step in range(opt_steps, self.totalSteps):
             if self.graph_after is not None and self._graph is None and step - opt_steps == max(3, self.graph_after):
-                self.capture_graph_agreed(step + 1)      # (every rank reaches this line at the same step: the decision is collective)
+                if self.capture_graph_agreed(step + 1):      # (every rank reaches this line at the same step: the decision is collective)
+                    replay_checks = 2
             loss = self.train_step(step + 1)
+            if replay_checks > 0:
+                # second vote, after each of the first two replays: a replay that did not train on some rank sends every rank back to eager launches
+                replay_checks -= 1
+                if not self.keep_graph_if_agreed(bool(torch.isfinite(loss)) and 1e-3 < float(loss) < 1e3, what=f"replayed step {step + 1}"):
+                    replay_checks = 0
             if self.keep_losses:
                 self.loss_history.append(loss)
             n = step + 1
