@@ -187,7 +187,11 @@ def test_replay_with_gradient_collectives_one_rank_rccl():
     One-rank RCCL group (the boxes of this pool have one GPU): the same code path as N ranks, and AVG over one rank is the identity,
     so the replayed steps must equal the eager steps of the same trainer."""
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1")
+    import socket
+    with socket.socket() as _s:      # a free rendezvous port (a fixed one can be taken on a shared box)
+        _s.bind(("127.0.0.1", 0))
+        _port = _s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1")
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     tr = None

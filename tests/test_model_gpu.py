@@ -400,7 +400,11 @@ def test_trainer_step_and_reducer_path_single_rank():
         return losses, [p.detach().clone() for p in net.parameters()], tr
 
     l0, p0, _ = run(False)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    import socket
+    with socket.socket() as _s:      # a free rendezvous port (a fixed one can be taken on a shared box)
+        _s.bind(("127.0.0.1", 0))
+        _port = _s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1")
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
