@@ -141,14 +141,17 @@ __global__ __launch_bounds__(256) void gate_residual_fwd_kernel(const float* __r
 // (X_out = acc * gate[b] + X_in, Transformer_Block_Dual.py:64-76: dx is d(X_out)): dacc = dx * gate[b] for the producing GEMM's
 // dgrad / wgrad, dgate[b] += sum_rows dx * acc, dbias[b] += sum_rows dacc (per-batch partial rows of the projection's bias
 // gradient) -- dx is in registers here, so the separate pass over it (mmdit_gate_residual_bwd) disappears.
-constexpr int LN_BWD_RCH = 16;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
+#ifndef MMDIT_LN_BWD_RCH
+#define MMDIT_LN_BWD_RCH 16
+#endif
+constexpr int LN_BWD_RCH = MMDIT_LN_BWD_RCH;   // rows per block: B * rows_per_batch / 16 blocks keep every CU busy with several waves
 template <int NITX, typename TG, typename TA, bool GATED>
 __device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ mean_i,
                                                 const float* __restrict__ rstd_i, const float* __restrict__ scale, int64_t ld_mod,
                                                 const float* __restrict__ dres, int d, int rpb, int nchunk,
                                                 float* __restrict__ dx, float* __restrict__ dscale, float* __restrict__ dshift, int64_t ld_dmod,
                                                 const TA* __restrict__ acc, const float* __restrict__ gate, int64_t ld_gate, TA* __restrict__ dacc,
-                                                float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias) {
+                                                float* __restrict__ dgate, int64_t ld_dgate, float* __restrict__ dbias, int64_t ld_dbias, int rch = LN_BWD_RCH) {
   constexpr int NIT = NITX < 0 ? -NITX : NITX;      // NITX < 0: d == 256 * NIT exactly, no lane of any iteration is out of range
   constexpr bool EXACT = NITX < 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -174,8 +177,8 @@ __device__ __forceinline__ void ln_mod_bwd_body(int block, const TG* __restrict_
       for (int e = 0; e < 4; e++) { sg[it][e] = 0.f; sb[it][e] = 0.f; }
     }
   }
-  const int rend = min(rpb, (chunk + 1) * LN_BWD_RCH);
-  for (int rl = chunk * LN_BWD_RCH + wave; rl < rend; rl += 4) {
+  const int rend = min(rpb, (chunk + 1) * rch);
+  for (int rl = chunk * rch + wave; rl < rend; rl += 4) {
     const int64_t row = (int64_t)b * rpb + rl;
     const float mean = mean_i[row], rstd = rstd_i[row];
     float g[NIT][4], xh[NIT][4];
@@ -270,16 +273,16 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const TG* __restrict__ 
 
 // two adaLN backward problems of the same width in one launch (see ln_mod_fwd_pair_kernel)
 struct LnBwdProb {
-  const void* dout; const float* x; const float* mean; const float* rstd; const float* scale; int64_t ld_mod; const float* dres; int rpb, nchunk;
+  const void* dout; const float* x; const float* mean; const float* rstd; const float* scale; int64_t ld_mod; const float* dres; int rpb, nchunk;   // nchunk chunks of rch rows per sample
   float* dx; float* dscale; float* dshift; int64_t ld_dmod;
   const void* acc; const float* gate; int64_t ld_gate; void* dacc; float* dgate; int64_t ld_dgate; float* dbias; int64_t ld_dbias;
 };
 template <int NIT, typename TG, typename TA, bool GATED>
-__global__ __launch_bounds__(256) void ln_mod_bwd_pair_kernel(LnBwdProb p0, LnBwdProb p1, int nblk0, int d) {
+__global__ __launch_bounds__(256) void ln_mod_bwd_pair_kernel(LnBwdProb p0, LnBwdProb p1, int nblk0, int d, int rch) {
   const bool first = (int)blockIdx.x < nblk0;     // (workgroup-uniform)
   const LnBwdProb& p = first ? p0 : p1;
   ln_mod_bwd_body<NIT, TG, TA, GATED>(first ? (int)blockIdx.x : (int)blockIdx.x - nblk0, (const TG*)p.dout, p.x, p.mean, p.rstd, p.scale, p.ld_mod, p.dres, d, p.rpb, p.nchunk,
-                                      p.dx, p.dscale, p.dshift, p.ld_dmod, (const TA*)p.acc, p.gate, p.ld_gate, (TA*)p.dacc, p.dgate, p.ld_dgate, p.dbias, p.ld_dbias);
+                                      p.dx, p.dscale, p.dshift, p.ld_dmod, (const TA*)p.acc, p.gate, p.ld_gate, (TA*)p.dacc, p.dgate, p.ld_dgate, p.dbias, p.ld_dbias, rch);
 }
 
 // -------------------------------------------------------------------------------------------
@@ -1065,18 +1068,23 @@ extern "C" int mmdit_ln_modulate_fwd_pair(const mmdit_ln_fwd_problem* a, const m
 }
 
 extern "C" int mmdit_ln_modulate_bwd_pair(const mmdit_ln_bwd_problem* a, const mmdit_ln_bwd_problem* b, int d, int dout_dtype, mmdit_stream_t stream) {
-  MMDIT_CHECK_ARG(a && b && d > 0 && d % 4 == 0 && d <= 4096);
+  MMDIT_CHECK_ARG(a && b && d > 0 && d % 4 == 0 && d <= 4096 && a->rows_per_batch > 0 && b->rows_per_batch > 0);
   const bool gated = a->acc != nullptr;
   MMDIT_CHECK_ARG((b->acc != nullptr) == gated);
   LnBwdProb q[2];
   const mmdit_ln_bwd_problem* src[2] = {a, b};
   int nb[2];
+  // rows per workgroup: 16, or 32 when 16 would give more workgroups than fit the chip at once (4 of these 256-thread workgroups per CU): the
+  // image + text launch of MMDiT-B at batch 64 is 1640 workgroups of 16 rows = 1.6 rounds, or 820 of 32 rows = one round -- measured 68.4 -> 63.8 us
+  // (single-stream launches, one round either way, are faster with 16: 42 vs 47 us)
+  const long wg16 = (long)(a->rows / a->rows_per_batch) * ((a->rows_per_batch + 15) / 16) + (long)(b->rows / b->rows_per_batch) * ((b->rows_per_batch + 15) / 16);
+  const int rch = wg16 > 1024 && wg16 <= 2048 ? 32 : LN_BWD_RCH;
   for (int i = 0; i < 2; i++) {
     const mmdit_ln_bwd_problem* p = src[i];
     MMDIT_CHECK_ARG(p->dout && p->x && p->mean && p->rstd && p->scale && p->dx && p->dscale && p->dshift && p->rows > 0 && p->rows_per_batch > 0 &&
                     p->rows % p->rows_per_batch == 0 && p->ld_mod % 4 == 0);
     if (gated) MMDIT_CHECK_ARG(p->gate && p->dacc && p->dgate && p->ld_gate % 4 == 0);
-    const int nchunk = (p->rows_per_batch + LN_BWD_RCH - 1) / LN_BWD_RCH;
+    const int nchunk = (p->rows_per_batch + rch - 1) / rch;
     nb[i] = (p->rows / p->rows_per_batch) * nchunk;
     q[i] = LnBwdProb{p->dout, p->x, p->mean, p->rstd, p->scale, p->ld_mod, p->dres, p->rows_per_batch, nchunk, p->dx, p->dscale, p->dshift, p->ld_dmod,
                      p->acc, p->gate, p->ld_gate, p->dacc, p->dgate, p->ld_dgate, p->dbias, p->ld_dbias};
@@ -1085,7 +1093,7 @@ extern "C" int mmdit_ln_modulate_bwd_pair(const mmdit_ln_bwd_problem* a, const m
   const int nit = nit_for(d);
   dim3 grid(nb[0] + nb[1]);
 // (the backward keeps its range checks: without them the batched loads cost 24 more VGPRs = one wave per SIMD less, measured 79 -> 84 us)
-#define LNP(T, G) NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_pair_kernel<(NIT < 0 ? -NIT : NIT), T, T, G>), grid, dim3(256), 0, s, q[0], q[1], nb[0], d))
+#define LNP(T, G) NIT_SWITCH(nit, hipLaunchKernelGGL((ln_mod_bwd_pair_kernel<(NIT < 0 ? -NIT : NIT), T, T, G>), grid, dim3(256), 0, s, q[0], q[1], nb[0], d, rch))
   if (dout_dtype == MMDIT_BF16) { if (gated) { LNP(bf16_t, true); } else { LNP(bf16_t, false); } }
   else if (dout_dtype == MMDIT_F32) { if (gated) { LNP(float, true); } else { LNP(float, false); } }
   else return MMDIT_ERR_DTYPE;
