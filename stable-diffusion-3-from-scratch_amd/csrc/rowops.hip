@@ -1074,11 +1074,18 @@ extern "C" int mmdit_ln_modulate_bwd_pair(const mmdit_ln_bwd_problem* a, const m
   LnBwdProb q[2];
   const mmdit_ln_bwd_problem* src[2] = {a, b};
   int nb[2];
-  // rows per workgroup: 16, or 32 when 16 would give more workgroups than fit the chip at once (4 of these 256-thread workgroups per CU): the
-  // image + text launch of MMDiT-B at batch 64 is 1640 workgroups of 16 rows = 1.6 rounds, or 820 of 32 rows = one round -- measured 68.4 -> 63.8 us
-  // (single-stream launches, one round either way, are faster with 16: 42 vs 47 us)
-  const long wg16 = (long)(a->rows / a->rows_per_batch) * ((a->rows_per_batch + 15) / 16) + (long)(b->rows / b->rows_per_batch) * ((b->rows_per_batch + 15) / 16);
-  const int rch = wg16 > 1024 && wg16 <= 2048 ? 32 : LN_BWD_RCH;
+  // rows per workgroup: 16, or more when 16 would give more workgroups than fit the chip at once (4 of these 256-thread workgroups per CU): the
+  // image + text launch of MMDiT-B at batch 64 is 1640 workgroups of 16 rows = 1.6 rounds, 832 of 32 rows or 1024 of 28 rows = one round -- measured
+  // 68.4 (16) -> 63.8 us (32) (single-stream launches, one round either way, are faster with 16: 42 vs 47 us)
+  // (generalised: the smallest multiple of 4 rows -- one row per wave and step -- for which the launch fits the chip in ONE round; the resident
+  //  workgroups per CU follow from the kernel's registers: 4 up to d = 768, 3 at d = 1024, 2 above)
+  auto wgs = [&](int r) { return (long)(a->rows / a->rows_per_batch) * ((a->rows_per_batch + r - 1) / r) + (long)(b->rows / b->rows_per_batch) * ((b->rows_per_batch + r - 1) / r); };
+  const int nit_ = nit_for(d), nit_abs = nit_ < 0 ? -nit_ : nit_;
+  const long slots = 256L * (nit_abs <= 3 ? 4 : nit_abs == 4 ? 3 : 2);
+  int rch = LN_BWD_RCH;
+  if (wgs(LN_BWD_RCH) > slots && wgs(LN_BWD_RCH) <= 2 * slots)
+    for (int r = LN_BWD_RCH + 4; r <= 64; r += 4)
+      if (wgs(r) <= slots) { rch = r; break; }
   for (int i = 0; i < 2; i++) {
     const mmdit_ln_bwd_problem* p = src[i];
     MMDIT_CHECK_ARG(p->dout && p->x && p->mean && p->rstd && p->scale && p->dx && p->dscale && p->dshift && p->rows > 0 && p->rows_per_batch > 0 &&
