@@ -100,7 +100,8 @@ def self_launch(n):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                   TORCH_FR_BUFFER_SIZE=os.environ.get("TORCH_FR_BUFFER_SIZE", "2000"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     code = 0
     alive = list(procs)
@@ -163,6 +164,9 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # the flight recorder must be on BEFORE the process group exists: model_trainer.capture_graph polls its per-group status to know
+        # that RCCL's watchdog has retired every eager collective (deterministic capture hand-off, model_trainer._wait_for_watchdog)
+        os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
@@ -171,9 +175,10 @@ def main():
 
     import sd3_amd  # noqa: F401
     from sd3_amd import ops
-    from sd3_amd.model_trainer import model_trainer
+    from sd3_amd.model_trainer import loss_is_plausible, model_trainer
     from sd3_amd.models.diff_model import diff_model
 
+    BENCH_WINDOW = (1e-3, 10.0)      # N(0, 1) synthetic latents: the loss starts near 2; model_trainer.LOSS_WINDOW is the general one
     dev = torch.device(f"cuda:{local_rank}")
     torch.manual_seed(1234)
     net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu", device=dev,
@@ -234,7 +239,7 @@ def main():
             warm.append(trainer.train_step(step).clone())
         if launch == "hipGraph replay":
             # the replays must have trained on EVERY rank, or every rank goes back to eager launches (model_trainer.keep_graph_if_agreed)
-            ok = all(1e-3 < float(l) < 10 for l in warm) and param_checksum() != c_before
+            ok = all(loss_is_plausible(l, BENCH_WINDOW) for l in warm) and param_checksum() != c_before
             if not trainer.keep_graph_if_agreed(ok):
                 launch = "eager (replay check failed on some rank)"
                 for _ in range(2):
@@ -258,10 +263,10 @@ def main():
     loss_first, loss_val = float(losses[0]), float(losses[-1])
     check1 = param_checksum()
     # the line must prove that the timed steps trained: a finite, plausible loss in every timed step and parameters that moved
-    if not all(1e-3 < float(l) < 10 for l in losses) or check1 == check0:
+    if not all(loss_is_plausible(l, BENCH_WINDOW) for l in losses) or check1 == check0:
         raise RuntimeError(f"bench: the timed steps did not train (losses {[float(l) for l in losses]}, parameter norm sum {check0} -> {check1})")
 
-    roofline = None
+    roofline, allreduce = None, None
     if not args.no_roofline:
         # three extra (untimed) steps with every GEMM launch bracketed by HIP events.  EVERY rank runs them -- the steps contain
         # the gradient all-reduce, so a rank-0-only loop would leave the other ranks out of the collectives -- rank 0 reports.
@@ -274,15 +279,24 @@ def main():
             trainer.train_step(step)
         torch.cuda.synchronize()
         engine._WG_OVERLAP = overlap
+        profile, ops.PROFILE = ops.PROFILE, None
+        if trainer.reducer.enabled:
+            # three more eager steps with the side-stream overlap back on and HIP events around every bucket's collective: how long the
+            # collectives take and how much of that the main stream waits for after the backward (reducer.timing_summary)
+            trainer.reducer.timing = True
+            for _ in range(3):
+                step += 1
+                trainer.train_step(step)
+            allreduce = trainer.reducer.timing_summary(steps=3)
+            trainer.reducer.timing = False
         trainer._graph = graph
     if rank == 0 and not args.no_roofline:
         stats = {}
-        for name, flops, e0, e1 in ops.PROFILE:
+        for name, flops, e0, e1 in profile:
             s = stats.setdefault(name, [0, 0.0, 0.0])
             s[0] += 1
             s[1] += flops
             s[2] += e0.elapsed_time(e1) * 1e-3
-        ops.PROFILE = None
         tot_t = sum(s[2] for s in stats.values())
         tot_f = sum(s[1] for s in stats.values())
         dom = max(stats.items(), key=lambda kv: kv[1][2])
@@ -318,6 +332,8 @@ def main():
             out["optimizer_table_builds"] = trainer.optim.table_builds
         if roofline is not None:
             out["roofline"] = roofline
+        if allreduce is not None:
+            out.update(allreduce)      # allreduce_total_ms / allreduce_exposed_ms / buckets_per_step (eager steps, per step)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -79,6 +79,11 @@ class OracleConfig:
     # rounding noise from an implementation's (tools/probes/parity_budget.py).  Tables the reference computes in fp32 (time-embedding
     # denominators, RoPE angles and their cos / sin) keep their fp32 values.
     dtype: torch.dtype = torch.float32
+    # backward of the bf16 mode: the HIP fast path stores every gradient that feeds a GEMM (dY of each Linear, the data gradients the
+    # GEMMs write) in bf16, as the reference's autocast backward does.  grad_round=True rounds the gradient to bf16 at exactly those
+    # points (the outputs of every Linear and every stored activation) when autograd runs through this restatement; False (default)
+    # leaves the backward in the arithmetic dtype (straight-through roundings), which is what the committed goldens were made with.
+    grad_round: bool = False
 
     @property
     def head_dim(self):
@@ -97,12 +102,28 @@ def _rb(x: torch.Tensor) -> torch.Tensor:
     return x + (x.to(torch.bfloat16).to(x.dtype) - x).detach()
 
 
+class _RoundGrad(torch.autograd.Function):
+    """Identity in forward; the incoming gradient is rounded to bf16 in backward (a gradient the HIP path stores as bf16)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(g.dtype)
+
+
+def _rg(cfg: "OracleConfig", x):
+    return _RoundGrad.apply(x) if cfg.grad_round and cfg.gemm != "fp32" and x.requires_grad else x
+
+
 def _lin(cfg: OracleConfig, x, w, b=None):
     """nn.Linear; in gemm=bf16 / fp8 mode both operands are rounded to bf16 first."""
     if cfg.gemm in ("bf16", "fp8", "mxfp8"):
         x = _rb(x)
         w = _rb(w)
-    return F.linear(x, w, b)
+    return _rg(cfg, F.linear(x, w, b))
 
 
 def _q8(x: torch.Tensor):
@@ -150,8 +171,8 @@ def _lin8(cfg: OracleConfig, x, ws, b=None):
 
 
 def _act(cfg: OracleConfig, x):
-    """Activation tensor that the HIP fast path stores as bf16."""
-    return _rb(x) if cfg.gemm in ("bf16", "fp8", "mxfp8") else x
+    """Activation tensor that the HIP fast path stores as bf16 (and, with grad_round, whose gradient it stores as bf16)."""
+    return _rg(cfg, _rb(x)) if cfg.gemm in ("bf16", "fp8", "mxfp8") else x
 
 
 # ----------------------------------------------------------------------------
@@ -312,7 +333,7 @@ def attention(x, c, sd, prefix: str, cfg: OracleConfig, hw, last: bool, taps: Op
     v = torch.cat([v_x, v_c], dim=2)
     if taps is not None:
         taps["q"], taps["k"], taps["v"] = q.detach(), k.detach(), v.detach()
-    o = attention_core(q, k, v, hd ** -0.5, cfg.attn_core)
+    o = _rg(cfg, attention_core(q, k, v, hd ** -0.5, cfg.attn_core))
     if taps is not None:
         taps["attn_core"] = o.detach()
     o_x = o[:, :, :N].permute(0, 2, 1, 3).reshape(B, N, -1)

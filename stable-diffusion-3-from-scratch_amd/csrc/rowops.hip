@@ -1081,7 +1081,31 @@ extern "C" int mmdit_ln_modulate_bwd_pair(const mmdit_ln_bwd_problem* a, const m
   //  workgroups per CU follow from the kernel's registers: 4 up to d = 768, 3 at d = 1024, 2 above)
   auto wgs = [&](int r) { return (long)(a->rows / a->rows_per_batch) * ((a->rows_per_batch + r - 1) / r) + (long)(b->rows / b->rows_per_batch) * ((b->rows_per_batch + r - 1) / r); };
   const int nit_ = nit_for(d), nit_abs = nit_ < 0 ? -nit_ : nit_;
-  const long slots = 256L * (nit_abs <= 3 ? 4 : nit_abs == 4 ? 3 : 2);
+  // resident workgroups = CUs of THIS device x workgroups per CU.  Per CU: the measured table (4 / 3 / 2 by row width), capped by what the
+  // occupancy query says for the exact instantiation being launched -- the query follows the kernel's registers if they ever grow, but on ROCm 7.2
+  // it over-reports by one workgroup in some SGPR bands (MI355X_MICROARCH.md, "Residency"), so it is an upper bound, never the value.
+  // Queried once per (device, instantiation); a wrong answer costs speed (two rounds instead of one), never correctness.
+  int per_cu = nit_abs <= 3 ? 4 : nit_abs == 4 ? 3 : 2, cus = 256;
+  {
+    static int occ[64][17][2][2], cu_count[64];      // 0 = not asked yet
+    const int dev = mmdit_current_device(), ti = dout_dtype == MMDIT_BF16 ? 0 : 1, gi = gated ? 1 : 0, ni = nit_abs > 16 ? 16 : nit_abs;
+    if (!cu_count[dev]) {
+      int n = 0;
+      cu_count[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    cus = cu_count[dev];
+    if (!occ[dev][ni][ti][gi]) {
+      int nbq = 0;
+      hipError_t e = hipErrorUnknown;
+#define LNQ(T, G) NIT_SWITCH(nit_, e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nbq, (const void*)ln_mod_bwd_pair_kernel<(NIT < 0 ? -NIT : NIT), T, T, G>, 256, 0))
+      if (dout_dtype == MMDIT_BF16) { if (gated) { LNQ(bf16_t, true); } else { LNQ(bf16_t, false); } }
+      else if (dout_dtype == MMDIT_F32) { if (gated) { LNQ(float, true); } else { LNQ(float, false); } }
+#undef LNQ
+      occ[dev][ni][ti][gi] = (e == hipSuccess && nbq > 0) ? nbq : 8;
+    }
+    per_cu = per_cu < occ[dev][ni][ti][gi] ? per_cu : occ[dev][ni][ti][gi];
+  }
+  const long slots = (long)cus * per_cu;
   int rch = LN_BWD_RCH;
   if (wgs(LN_BWD_RCH) > slots && wgs(LN_BWD_RCH) <= 2 * slots)
     for (int r = LN_BWD_RCH + 4; r <= 64; r += 4)

@@ -77,6 +77,16 @@ def _watchdog_status():
         return None
 
 
+LOSS_WINDOW = (1e-3, 1e3)     # a rectified-flow MSE on latents of O(1) variance starts near 2 and stays far inside this window
+
+
+def loss_is_plausible(loss, window=LOSS_WINDOW):
+    """The ONE test "did this step train" of the launch-mode votes (train(), bench.py): a finite loss inside `window`.  bench.py passes
+    the tighter (1e-3, 10) its N(0, 1) synthetic latents justify."""
+    v = float(loss)
+    return math.isfinite(v) and window[0] < v < window[1]
+
+
 class SyntheticData:
     """Synthetic (x0, text, pooled) batches shaped like the loader-GPU wire format (model_trainer.py:353-355):
     bf16 latents (B,16,res/8,res/8), bf16 text (B,154,2304) with Gemma-like large variance on tokens 0..76 and
@@ -207,6 +217,8 @@ class model_trainer:
         self._graph, self._slots, self._loss_out, self._graph_loss = None, None, None, None
         self._slots_primed = False   # the batches drawn at capture time are the inputs of the first replay (nothing drawn is dropped)
         self.replayed_steps = 0      # optimizer steps served by the hipGraph so far
+        self._carry_inputs = None    # micro-batches drawn at a capture whose graph was dropped before a replay trained on them
+        self.capture_handoff = None  # how capture_graph() knew RCCL's watchdog was idle: "polled" / "heuristic" (None: no collectives)
         self.keep_losses, self.loss_history = False, []     # keep_losses: train() appends every step's loss (device scalars)
         self.last_grad_norm = None   # hip_optimizer: device scalar, the unscaled gradient norm of the last step
         if is_main_process():
@@ -334,6 +346,8 @@ class model_trainer:
         return self._eager_step(step)
 
     def _eager_step(self, step, inputs=None):
+        if inputs is None and self._carry_inputs is not None:
+            inputs, self._carry_inputs = self._carry_inputs, None      # drawn for a capture that was dropped before any replay used them
         loss = None
         for k in range(self.accumulation_steps):
             l = self.micro_step(final=(k == self.accumulation_steps - 1), inputs=inputs[k] if inputs is not None else None)
@@ -378,7 +392,9 @@ class model_trainer:
             self._slots = [tuple(x.to(self.device).clone() for x in self._draw()) for _ in range(self.accumulation_steps)]
         torch.cuda.synchronize(self.device)
         if self.reducer.enabled and self.device.type == "cuda":
-            self._wait_for_watchdog()
+            # "polled" = the watchdog's own counters said it had retired every eager collective; "heuristic" = fixed delay (the process
+            # group was created without TORCH_FR_BUFFER_SIZE, i.e. by a caller that did not go through init_distributed())
+            self.capture_handoff = "polled" if self._wait_for_watchdog() else "heuristic"
         self.optim.sync_lr(self.device)
         self.optim.prepare_capture()
         # the loss leaves the graph through a persistent buffer written by a kernel of the graph (not through a tensor of the graph's
@@ -435,12 +451,19 @@ class model_trainer:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.subgroup)
             ok_all = bool(int(flag))
         if not ok_all and ok_local:
-            self._graph, self._slots = None, None
+            self._drop_graph()
         print(f"[model_trainer rank {self.rank}/{self.world}] step capture: {'ok' if ok_local else 'FAILED (' + type(err).__name__ + ': ' + str(err) + ')'}; "
               f"launch mode for all ranks: {'hipGraph replay' if ok_all else 'eager'}; {self.reducer.describe()}", file=sys.stderr, flush=True)
         if err is not None and strict:
             raise err
         return ok_all
+
+    def _drop_graph(self):
+        """Back to eager launches.  Batches drawn into the static slots that no replay has trained on yet (a capture that the ranks
+        then voted down) are not thrown away: the next eager step trains on them."""
+        if self._slots is not None and self._slots_primed:
+            self._carry_inputs = [tuple(x.clone() for x in slot) for slot in self._slots]
+        self._graph, self._slots, self._slots_primed = None, None, False
 
     def keep_graph_if_agreed(self, ok_local, what="the first replayed steps"):
         """Second half of the collective launch-mode decision: after the first replays every rank reports whether ITS replayed steps
@@ -458,7 +481,7 @@ class model_trainer:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.subgroup)
             ok_all = bool(int(flag))
         if not ok_all:
-            self._graph, self._slots = None, None
+            self._drop_graph()
         print(f"[model_trainer rank {self.rank}/{self.world}] {what}: {'ok' if ok_local else 'NOT ok on this rank'}; "
               f"launch mode for all ranks from here on: {'hipGraph replay' if ok_all else 'eager'}", file=sys.stderr, flush=True)
         return ok_all
@@ -526,7 +549,9 @@ class model_trainer:
 
     def _abandon_capture(self):
         """A capture that raised leaves host state behind that no launch backs: put it back so that eager steps can continue."""
-        self._graph, self._slots = None, None
+        if self._slots is not None:      # (drawn for the capture, trained on by nobody: the next eager step takes them)
+            self._carry_inputs = [tuple(x.clone() for x in slot) for slot in self._slots]
+        self._graph, self._slots, self._slots_primed = None, None, False
         self.reducer.reset()
         if self.grad_scaler is not None and self.grad_scaler.is_enabled():
             from torch.amp.grad_scaler import _refresh_per_optimizer_state
@@ -611,7 +636,7 @@ class model_trainer:
             if replay_checks > 0:
                 # second vote, after each of the first two replays: a replay that did not train on some rank sends every rank back to eager launches
                 replay_checks -= 1
-                if not self.keep_graph_if_agreed(bool(torch.isfinite(loss)) and 1e-3 < float(loss) < 1e3, what=f"replayed step {step + 1}"):
+                if not self.keep_graph_if_agreed(loss_is_plausible(loss), what=f"replayed step {step + 1}"):
                     replay_checks = 0
             if self.keep_losses:
                 self.loss_history.append(loss)

@@ -245,6 +245,12 @@ def gemm_swiglu_bwd(problems):
     [g | u], dbias = fp32 (2h,) accumulating bias gradient or None.  Returns the list of d[g | u] (M, 2h) bf16 -- the bits of gemm() followed
     by mlp_act_bwd() -- or None when the planner would not run these problems on the 8-phase 256 x 256 kernel (caller: the two passes)."""
     n = len(problems)
+    # what the fused launch needs beyond the plain GEMM (csrc/gemm.hip: 16-byte aligned [g | u] and d[g | u] rows, hidden width a multiple of 8):
+    # an arena slice that does not offer it takes the two-pass path like a shape the planner refuses, instead of raising
+    for q in problems:
+        aux, out = q["aux"], q.get("out")
+        if aux.data_ptr() % 16 or aux.stride(0) % 8 or aux.shape[-1] % 16 or (out is not None and (out.data_ptr() % 16 or out.stride(0) % 8)):
+            return None
     arr = (GemmArgs * n)()
     outs = [_fill_gemm(arr[i], **dict(problems[i], b_kmajor=True, act=ACT_SWIGLU_BWD)) for i in range(n)]
     if PROFILE is not None:

@@ -50,12 +50,39 @@ class GradReducer:
         self.skip = False        # True on non-final gradient-accumulation micro-steps (no_sync semantics)
         self._views_wanted = False
         self.buckets = 0         # buckets averaged so far (tests / logs)
+        # rs_ag / direct: the shard / receive / send buffers, ONE set per (role, length, dtype, device), reused by every bucket of that
+        # size in every step (the collectives of a rank are ordered on the side stream, so a buffer is free again when the next bucket
+        # of its size starts); nothing is allocated per bucket per step -- at MMDiT-B that was ~300 MB of allocator traffic per block
+        self._bufs = {}
+        # timing (eager steps only -- events recorded inside a captured step cannot be read): set `timing = True`, run steps, read
+        # timing_summary(): per-bucket HIP events around each collective on the side stream + one pair around the main stream's wait
+        self.timing = False
+        self._tev, self._texposed = [], []
 
     def describe(self):
         """One line for the logs: what this rank's reducer will do."""
         backend = dist.get_backend(self.group) if dist.is_initialized() else "none"
         wire = "bf16" if self.wire_dtype == torch.bfloat16 else "fp32"
         return f"GradReducer(world={self.world}, enabled={self.enabled}, backend={backend}, algorithm={self.algorithm}, wire={wire})"
+
+    def _buf(self, role, n, dtype, device):
+        key = (role, n, dtype, device)
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = torch.empty(n, dtype=dtype, device=device)
+        return b
+
+    def timing_summary(self, steps=1):
+        """{"allreduce_total_ms", "allreduce_exposed_ms", "buckets_per_step"} per step over the steps run since `timing` was set: total =
+        sum of the collectives' own durations on the side stream, exposed = how long the main stream had to wait for the side stream
+        in finish() (0 when the last bucket's collective ended before the backward did).  Synchronises the device."""
+        torch.cuda.synchronize()
+        total = sum(e0.elapsed_time(e1) for e0, e1 in self._tev)
+        exposed = sum(max(0.0, e0.elapsed_time(e1)) for e0, e1 in self._texposed)
+        out = {"allreduce_total_ms": round(total / max(1, steps), 3), "allreduce_exposed_ms": round(exposed / max(1, steps), 3),
+               "buckets_per_step": len(self._tev) // max(1, steps)}
+        self._tev, self._texposed = [], []
+        return out
 
     def _side(self, device):
         if self._stream is None:
@@ -69,6 +96,18 @@ class GradReducer:
         self.buckets += 1
         W, n = self.world, flat.numel()
         nccl = dist.get_backend(self.group) == "nccl"
+        if self.timing and flat.is_cuda and not torch.cuda.is_current_stream_capturing():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            try:
+                self._average_untimed(flat, W, n, nccl)
+            finally:
+                e1.record()
+                self._tev.append((e0, e1))
+            return
+        self._average_untimed(flat, W, n, nccl)
+
+    def _average_untimed(self, flat, W, n, nccl):
         algo = self.algorithm if (n % W == 0 and n > 0) else "allreduce"
         if algo == "allreduce":
             if nccl:
@@ -80,7 +119,7 @@ class GradReducer:
             return
         s = n // W
         if algo == "rs_ag":
-            shard = torch.empty(s, dtype=flat.dtype, device=flat.device)
+            shard = self._buf("shard", s, flat.dtype, flat.device)
             dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM, group=self.group)
             if not nccl:
                 shard.div_(W)
@@ -89,11 +128,13 @@ class GradReducer:
         # (rs_ag / direct on a non-RCCL backend are multi-step and stay synchronous: test-only there)
         # direct: shard j of every rank -> rank j (one all-to-all), fp32 sum there, averaged shard -> everyone (one all-to-all)
         wire = self.wire_dtype or flat.dtype
-        send = flat if wire == flat.dtype else flat.to(wire)
-        recv = torch.empty(n, dtype=wire, device=flat.device)
+        send = flat if wire == flat.dtype else self._buf("send", n, wire, flat.device).copy_(flat)
+        recv = self._buf("recv", n, wire, flat.device)
         dist.all_to_all_single(recv, send, group=self.group)
-        shard = torch.sum(recv.view(W, s), dim=0, dtype=torch.float32).div_(W)       # (rank order: the same summation on every rank)
-        send2 = shard.to(wire).unsqueeze(0).expand(W, s).contiguous().view(-1)
+        shard = self._buf("sum", s, torch.float32, flat.device)
+        torch.sum(recv.view(W, s), dim=0, dtype=torch.float32, out=shard).div_(W)    # (rank order: the same summation on every rank)
+        send2 = self._buf("send2", n, wire, flat.device)
+        send2.view(W, s).copy_(shard.unsqueeze(0).expand(W, s))                      # (rounds to the wire format)
         if wire == flat.dtype:
             dist.all_to_all_single(flat, send2, group=self.group)
         else:
@@ -209,6 +250,11 @@ class GradReducer:
                 torch._foreach_copy_(tensors, outs)
         self._inflight = []
         if self._stream is not None:
+            if self.timing and not torch.cuda.is_current_stream_capturing():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()                      # main stream: the backward is done here
+                e1.record(self._stream)          # side stream: the last collective is done here
+                self._texposed.append((e0, e1))
             torch.cuda.current_stream().wait_stream(self._stream)
 
     def reset(self):

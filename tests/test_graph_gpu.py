@@ -40,7 +40,8 @@ class _CpuSource:
         return x0.cuda(), c.to(torch.bfloat16).cuda(), cp.cuda()
 
 
-def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reducer=False, slots=False, lr=1e-3, accum=1, keep_graph=False, hip_loss=True):
+def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reducer=False, slots=False, lr=1e-3, accum=1, keep_graph=False, hip_loss=True,
+                   drop_after=None):
     """One trainer: three eager warm-up steps, snapshot of everything (parameters, AdamW state, loss scale, every RNG stream),
     n_steps eager; restore; capture; n_steps replayed with the given host pattern between replays.  Returns (eager losses,
     replayed losses, eager final parameters, replayed final parameters, trainer)."""
@@ -88,6 +89,9 @@ def graph_vs_eager(cname, batch, max_res, n_steps=3, pattern="each", force_reduc
         def steps():
             out = []
             for s in range(4, 4 + n_steps):
+                if drop_after is not None and tr._graph is not None and s - 4 == drop_after:
+                    # the ranks vote the graph down (model_trainer.keep_graph_if_agreed): a REAL graph is dropped, eager launches continue
+                    assert tr.keep_graph_if_agreed(False) is False and tr._graph is None and tr._slots is None
                 l = tr.train_step(s)
                 if pattern == "each":
                     out.append(float(l))
@@ -192,12 +196,16 @@ def test_replay_with_gradient_collectives_one_rank_rccl():
         _s.bind(("127.0.0.1", 0))
         _port = _s.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1")
+    # a caller that creates the process group itself must switch the flight recorder on first (model_trainer.init_distributed does):
+    # capture_graph() polls its per-group status for the watchdog hand-off instead of sleeping ("Embedding")
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     tr = None
     try:
         l0, l1, p0, p1, tr = graph_vs_eager("micro", 4, 128, n_steps=3, pattern="burst", force_reducer=True)
         assert tr.reducer.enabled and tr.model.grad_reducer is tr.reducer and tr.reducer.buckets > 0
+        assert tr.capture_handoff == "polled", tr.capture_handoff      # (not the fixed-delay heuristic)
     finally:
         if tr is not None:          # the graph holds the captured collectives: release it before the communicator goes away
             tr._graph = None
@@ -206,6 +214,45 @@ def test_replay_with_gradient_collectives_one_rank_rccl():
         torch.cuda.synchronize()
         dist.destroy_process_group()
     check(l0, l1, p0, p1, "micro 1-rank RCCL")
+
+
+def test_dropping_a_real_graph_with_collectives_then_eager_steps():
+    """the drop-the-graph path on the real thing.  One-rank RCCL group, the step captured WITH its per-block all-reduces; two
+    replays, then the second launch-mode vote fails (keep_graph_if_agreed(False)): the hipGraph, its private pool and its registered RNG
+    generators are released while the trainer goes on with eager steps -- which must continue the run exactly where an all-eager run
+    of the same trainer would be (same data / RNG order, same parameters to the backward's run-to-run noise)."""
+    import torch.distributed as dist
+    import socket
+    with socket.socket() as _s:
+        _s.bind(("127.0.0.1", 0))
+        _port = _s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    tr = None
+    try:
+        l0, l1, p0, p1, tr = graph_vs_eager("micro", 4, 128, n_steps=5, pattern="burst", force_reducer=True, drop_after=2)
+        assert tr._graph is None and tr.replayed_steps == 2 and tr.reducer.enabled
+        more = [float(tr.train_step(s)) for s in (9, 10)]      # and it keeps training
+        assert all(1e-3 < x < 10 for x in more)
+    finally:
+        if tr is not None:
+            tr._graph = None
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+    check(l0, l1, p0, p1, "micro 1-rank RCCL, graph dropped after two replays")
+
+
+def test_graph_dropped_before_its_first_replay_keeps_the_drawn_batches():
+    """a capture that the ranks vote down before any replay (capture_graph_agreed's mismatch path) has already drawn one batch
+    per micro-step into the static input slots.  Those batches are the next eager step's inputs -- nothing drawn is dropped -- so the
+    run equals the all-eager run step by step (CPU data source + the reference's CPU conditioning draw, two accumulation micro-steps)."""
+    l0, l1, p0, p1, tr = graph_vs_eager("micro", 4, 128, n_steps=3, pattern="each", slots=True, accum=2, drop_after=0)
+    assert tr._graph is None and tr.replayed_steps == 0 and tr._carry_inputs is None
+    check(l0, l1, p0, p1, "micro slots accum2, graph dropped before its first replay")
 
 
 def test_fp8_weight_caches_follow_replays():

@@ -405,6 +405,7 @@ def test_trainer_step_and_reducer_path_single_rank():
         _s.bind(("127.0.0.1", 0))
         _port = _s.getsockname()[1]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_port), RANK="0", WORLD_SIZE="1")
+    os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
     if not dist.is_initialized():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:

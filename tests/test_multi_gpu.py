@@ -84,7 +84,8 @@ def _train(rank, world, data_world, accum, force):
 def _worker(rank, world, port, accum, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                      TORCH_FR_BUFFER_SIZE=os.environ.get("TORCH_FR_BUFFER_SIZE", "2000"))      # (capture hand-off polls the flight recorder)
     import torch.distributed as dist
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
@@ -157,7 +158,8 @@ def _graph_worker(rank, world, port, q):
     three replays, on the trainer's own synthetic data (seed 1234 + rank)."""
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
-                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+                      TORCH_FR_BUFFER_SIZE=os.environ.get("TORCH_FR_BUFFER_SIZE", "2000"))      # (capture hand-off polls the flight recorder)
     import torch.distributed as dist
     torch.cuda.set_device(rank)
     dist.init_process_group("nccl", init_method="env://", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
@@ -176,6 +178,7 @@ def _graph_worker(rank, world, port, q):
     net.train()
     losses = [float(tr.train_step(s + 1)) for s in range(3)]
     tr.capture_graph(4)
+    assert tr.capture_handoff == "polled", tr.capture_handoff     # the watchdog hand-off polled the flight recorder (not the fixed delay)
     losses += [float(tr.train_step(s + 4)) for s in range(3)]
     torch.cuda.synchronize(dev)
     q.put((rank, losses, [p.detach().cpu().numpy().copy() for p in net.parameters()], tr.reducer.buckets))

@@ -235,6 +235,8 @@ def test_8_phase_gemm_kernels_have_no_scratch_access_in_their_k_loop():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_spills.py")], capture_output=True, text=True, timeout=600)
+    if r.returncode == 77:
+        pytest.skip("no hipcc on this machine (tools/check_spills.py honours HIPCC): " + r.stderr.strip())
     assert r.returncode == 0, r.stdout + r.stderr
 
 
