@@ -138,6 +138,9 @@ __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const
 #ifdef MMDIT_PROBES
       if (gp.debug & 16) { if (t[0] == 0x12345678u) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t; continue; }   // ablation: staging without the global stores
 #endif
+#ifdef MMDIT_PROBES
+      if (gp.debug & 1024) { if (row < p.M && col < p.N) __builtin_nontemporal_store(t, (u32x4*)(C + (int64_t)row * p.ldc + col)); continue; }      // experiment: streaming stores
+#endif
       if (row < p.M && col < p.N) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
@@ -553,6 +556,19 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         for (int j = 0; j < 2; j++) c[i * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + ks], fa[i * 2 + ks], c[i * 2 + j], 0, 0, 0);
   };
 
+  // first K tile of an item whose accumulators are NOT zeroed (drain schedule below): the first k-step starts from a constant-zero C
+  auto mma0 = [&](f32x4 (&c)[2 * FI], const bf16x8 (&fb)[4]) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < FI; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) c[i * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2], fa[i * 2], z, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < FI; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++) c[i * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j * 2 + 1], fa[i * 2 + 1], c[i * 2 + j], 0, 0, 0);
+  };
+
   // ---- staging of the current item.  The per-lane source offset of a DMA piece is formed when the piece is issued (four VALU operations in a
   // phase whose vector ALU is otherwise idle) from TWO registers per operand -- holding one offset per (half-tile, piece) would cost 8 / 10
   // registers this kernel does not have:
@@ -656,6 +672,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 #define P3_READS(cur) readA(cur, XA1);
 #define P3_WAIT() LGKM0()
 #endif
+#ifdef MMDIT_PROBES      // timing experiment (debug bit 256, results are garbage): K tiles 1 and 2 behind a drain do not wait for the drain's stores
+#define WAIT3X() do { if (DRAIN && relax > 0) { relax--; VMCNT8(1 * PAW + 2 * 2 + 4 * FI); } else wait3(); } while (0)
+#else
+#define WAIT3X() wait3()
+#endif
 #define KTILE8(cur)                                                                                          \
   {                                                                                                          \
     /* P1 */                                                                                                 \
@@ -678,9 +699,41 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P4 */                                                                                                 \
     if (REREAD) { readB(fb0, cur, XB0); stageA(1, 2, cur); } else stageB(1, 2, cur);             \
-    wait3();                                                                                                 \
+    WAIT3X();                                                                                                \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
     mma(acc.a[1][0], fb0);                                                                                   \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    next_ktile();                                                                                            \
+  }
+
+  // the first K tile of an item (KEEP schedule, 256 rows): always from a constant-zero C (no zero-fill of the accumulators); with `dr` the previous
+  // tile drains in its load sections.  The counted wait of P4 must then leave the stagings of P2, P3, P4 in flight AND the 3 x FI stores issued
+  // between them (each phase: stores first, then its staging).
+#define KTILE8D(cur)                                                                                         \
+  {                                                                                                          \
+    P1_READS(cur)                                                                                            \
+    if (dr) drain_q(acc.a[0][0], 0, 0);                                                                      \
+    stageA(1, 1, (cur) ^ 1);                                                                                 \
+    P1_WAIT(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                    \
+    mma0(acc.a[0][0], fb0);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    readB(FB1, cur, XB1);                                                                                    \
+    if (dr) drain_q(acc.a[0][1], 0, 1);                                                                      \
+    stageA(0, 2, cur);                                                                                       \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mma0(acc.a[0][1], FB1);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    P3_READS(cur)                                                                                            \
+    if (dr) drain_q(acc.a[1][1], 1, 1);                                                                      \
+    stageB(0, 2, cur);                                                                                       \
+    P3_WAIT(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                    \
+    mma0(acc.a[1][1], FB1);                                                                                  \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    if (dr) drain_q(acc.a[1][0], 1, 0);                                                                      \
+    stageB(1, 2, cur);                                                                                       \
+    if (dr) VMCNT8(1 * PAW + 2 * 2 + 3 * FI); else wait3();                                                  \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mma0(acc.a[1][0], fb0);                                                                                  \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     next_ktile();                                                                                            \
   }
@@ -692,6 +745,42 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   // have been issued, i.e. under their latency (~1.4 us per tile of a K = 768 launch); otherwise (320 rows: the staging aliases the operand
   // buffers; weight gradients: ticket + long reductions) right behind the item's main loop.
   constexpr bool DEFER = MT == 256 && EPI != EPI_F32;
+  // DRAIN (round 5): the epilogue of a FULL tile runs inside the FIRST K tile of the workgroup's next item.  That K tile's MFMAs start from a
+  // constant-zero C (mma0), so quadrant q's accumulator registers still hold the previous tile until phase q's MFMAs overwrite them: each
+  // quadrant is converted and stored in the load section of the phase that precedes its first MFMA, while the other wave group's MFMAs run.
+  // No LDS staging: a v_permlane16_swap pair turns two 16 x 16 C^T fragments (lane = row, 4 consecutive columns) into 8 consecutive columns
+  // per lane, one global_store_dwordx4 per 16 rows x 64 B.  The stores are issued UNCONDITIONALLY (full tiles only; partial tiles keep the
+  // staged epilogue) because the counted vmcnt of that K tile's P4 counts them: 3 quadrants x FI stores are younger than the staging it waits for.
+  // MEASURED (round 5, profiles/r05_gemm_drain_ab.txt; same box, N = 6144, K = 768, 256 x 256 tiles): staged deferred epilogue 272 us, drain 275 us,
+  // drain WITHOUT its stores 231 us -- the stores cost the same ~41 us per launch (322 MB) whether they leave in a burst behind the main loop or
+  // inside the next tile's first K tile, with the following waits relaxed (debug 256), as streaming stores (debug 1024), or with the workgroups'
+  // start times spread over a tile period (debug >> 16): correct, bit-identical, not faster.  NOT the product: probes builds only.
+#ifdef MMDIT_PROBES
+  constexpr bool DRAIN = DEFER && EPI == EPI_BF16;
+#else
+  constexpr bool DRAIN = false;
+#endif
+  char* dr_ptr = nullptr;      // this lane's first output element of the previous tile (row lane & 15, 8-column group of its 16-lane row)
+  uint32_t dr_ld = 0;          // bytes per output row
+  bool prev_drain = false;     // the pending item is drained inside the next item's first K tile
+  auto drain_q = [&](f32x4 (&c)[2 * FI], int qm, int qn) {
+    char* pq = dr_ptr + (int64_t)(qm * QR) * dr_ld + qn * 64;
+#pragma unroll
+    for (int i = 0; i < FI; i++) {
+      const f32x4 a = c[i * 2], b = c[i * 2 + 1];
+      const uint32_t a0 = pack_bf2(a[0], a[1]), a1 = pack_bf2(a[2], a[3]), b0 = pack_bf2(b[0], b[1]), b1 = pack_bf2(b[2], b[3]);
+      // rows of 16 lanes: fragment j = 0 columns {0-3, 4-7, 8-11, 12-15}; after the swap row 0 holds j = 0 columns 0-7, row 1 j = 1 columns 0-7,
+      // row 2 j = 0 columns 8-15, row 3 j = 1 columns 8-15
+      const auto x = __builtin_amdgcn_permlane16_swap(a0, b0, false, false), y = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+#ifdef MMDIT_PROBES
+      if (gp.debug & 512) { asm volatile("" ::"v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1])); continue; }      // ablation: conversion + swaps, no stores
+#endif
+#ifdef MMDIT_PROBES
+      if (gp.debug & 1024) { __builtin_nontemporal_store((u32x4){x[0], y[0], x[1], y[1]}, (u32x4*)(pq + (int64_t)(i * 16) * dr_ld)); continue; }      // experiment: streaming stores
+#endif
+      *(u32x4*)(pq + (int64_t)(i * 16) * dr_ld) = (u32x4){x[0], y[0], x[1], y[1]};
+    }
+  };
   auto run_epilogue = [&](const Item& it) {
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------------
   const Problem& q = gp.p[it.pi];
@@ -762,6 +851,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   }
   };
 
+#ifdef MMDIT_PROBES      // experiment: start-time skew -- workgroup b waits ((b / 8) % 32) / 32 of a span of (debug >> 16) * 256 cycles (spread inside each XCD)
+  if (gp.debug >> 16) {
+    const long long span = (long long)(gp.debug >> 16) * 256, until = __builtin_readcyclecounter() + span * (((int)blockIdx.x / 8) % 32) / 32;
+    while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
+  }
+#endif
   Item item = item_at(gp, pos, end), prev = item;
   bool pending = false;
   while (item.valid) {
@@ -771,24 +866,40 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       if (REREAD) { stageA(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageB(0, 0, 0); stageA(0, 1, 1); stageB(1, 1, 1); stageA(1, 1, 1); }
       else { stageA(0, 0, 0); stageB(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageA(0, 1, 1); stageB(0, 1, 1); stageB(1, 1, 1); }
     }
-    if (DEFER && pending) run_epilogue(prev);
+    const bool dr = DRAIN && pending && prev_drain && nkt > 0;      // (workgroup-uniform)
+#ifdef MMDIT_PROBES
+    int relax = (dr && (gp.debug & 256)) ? 2 : 0;
+#endif
+    if (DEFER && pending && !dr) run_epilogue(prev);
+    if (!DRAIN || nkt == 0) {      // (DRAIN: the first K tile starts from a constant-zero C)
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+      for (int a = 0; a < 2; a++)
 #pragma unroll
-      for (int b = 0; b < 2; b++)
+        for (int b = 0; b < 2; b++)
 #pragma unroll
-        for (int i = 0; i < 2 * FI; i++) acc.a[a][b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          for (int i = 0; i < 2 * FI; i++) acc.a[a][b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     if (nkt > 0) {
       wait3();                     // (DEFER: the epilogue's stores are younger than every request -- this also waits for all but a few of them)
       BAR8();
       if (wr == 1) BAR8();         // group 1 runs one barrier behind from here on
       int t = 0;
+      if constexpr (DRAIN) {       // the first K tile peeled: with or without the previous tile's drain
+        KTILE8D(0)
 #pragma unroll 1
-      for (; t + 1 < nkt; t += 2) {
-        KTILE8(0)
-        KTILE8(1)
+        for (t = 1; t + 1 < nkt; t += 2) {
+          KTILE8(1)
+          KTILE8(0)
+        }
+        if (t < nkt) KTILE8(1)
+      } else {
+#pragma unroll 1
+        for (; t + 1 < nkt; t += 2) {
+          KTILE8(0)
+          KTILE8(1)
+        }
+        if (t < nkt) KTILE8(0)
       }
-      if (t < nkt) KTILE8(0)
       VMCNT8(0);                   // the trailing (unused) requests have landed
       if (wr == 0) BAR8();         // rejoin
       BAR8();                      // every wave's requests have landed and every wave has left the operand buffers
@@ -823,8 +934,24 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         __syncthreads();             // every wave has left the buffers (epilogue staging / the next prologue reuse them)
       }
     }
-    if (DEFER) { prev = item; pending = true; }
-    else {
+    if (DEFER) {
+      prev = item; pending = true;
+      if constexpr (DRAIN) {
+        const Problem& q = gp.p[item.pi];
+        const int m0 = item.tm * MT, n0 = item.tn * 256;
+        prev_drain = m0 + MT <= q.M && n0 + 256 <= q.N && !q.bias && gp.act == MMDIT_ACT_NONE && (q.ldc & 7) == 0 && ((uintptr_t)q.C & 15) == 0;
+#ifdef MMDIT_PROBES
+        if (gp.debug & 128) prev_drain = false;      // A/B: the staged deferred epilogue everywhere
+#endif
+        dr_ld = (uint32_t)q.ldc * 2;
+#ifdef MMDIT_PROBES
+        const int m0w = (gp.debug & 2048) ? 0 : m0;      // experiment: every tile row block writes to rows [0, 256) -- the output stays L2-resident
+#else
+        const int m0w = m0;
+#endif
+        dr_ptr = (char*)q.C + ((int64_t)(m0w + wr * (MT / 2) + (lane & 15)) * q.ldc + n0 + wc * 64 + ((lane >> 4) & 1) * 16 + (lane >> 5) * 8) * 2;
+      }
+    } else {
       run_epilogue(item);
       if (MT != 256) BAR8();       // (the staging lives in the operand buffers the next prologue overwrites)
     }
