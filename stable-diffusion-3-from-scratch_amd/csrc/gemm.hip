@@ -272,7 +272,11 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
   }
   // (e4m3 operands: a 256x256 round costs 1.67 rounds of 128x128 tiles -- tools/probes/fp8_bench.py: qkv 80 vs 96 us, w12 190 vs 226 us
   // in favour of 256x256, out-proj / w3 (N = 768) 37 vs 39 us, 98 vs 107 us in favour of 128x128)
-  const double r256 = args[0].a_dtype == MMDIT_FP8 ? 1.67 : 1.58;
+  // (round 5: MX operands with a bf16 / SwiGLU output run the 8-phase kernel at 256x256 (gemm8p.hip MX) -- out-proj 32.0 vs 38.0 us, w3 76.4 vs
+  //  100.1 us in favour of 256x256 now: a 256x256 round costs ~1.2 rounds of 128x128 tiles there)
+  const bool mx8 = args[0].a_dtype == MMDIT_FP8 && args[0].scale_mode == 1 && args[0].K % 128 == 0 && !args[0].gate && !args[0].residual &&
+                   (args[0].c_dtype == MMDIT_BF16 || args[0].act == MMDIT_ACT_SWIGLU);
+  const double r256 = mx8 ? 1.2 : args[0].a_dtype == MMDIT_FP8 ? 1.67 : 1.58;
   const double c128 = (double)((t128 * split_k + 511) / 512), c256 = r256 * (double)((t256 * split_k + 255) / 256);
   if (lean_ok) {
     // 320x256 tiles (lean kernel): a round costs 1.25x a 256x256 round (tile area); MMDiT-B's N = 768 GEMMs at batch 64 fit ONE round
@@ -547,7 +551,14 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   static const int p8_mode = p8_env ? atoi(p8_env) : 1;      // 1: every lean launch; 2: only the 256x256 ones
   // (the QKV launch with the QK-norm / RoPE epilogue stays on the wide kernel at 320 rows: with that epilogue's registers the 320-row 8-phase
   //  variant measured slower, 1.73 vs 1.59 ms per step)
-  const bool p8 = p8_mode > 0 && ((kk && cfg == CFG_256x256) || (lean && (cfg == CFG_256x256 || (cfg == CFG_320x256 && p8_mode == 1 && !qkr))));
+  // MX (e4m3 operands with E8M0 block scales) on the 8-phase loop: 256 x 256 tiles, bf16 output (bias allowed) or the SwiGLU epilogue (bf16 or MX output)
+  bool mx8 = p8_mode > 0 && dma && fp8 && gp.mx && cfg == CFG_256x256 && !qkr && !stream_k && split_k == 1 && (a0->act == MMDIT_ACT_NONE || swiglu) && !a0->accumulate;
+  for (int i = 0; i < count && mx8; i++) {
+    const mmdit_gemm_args* a = &args[i];
+    mx8 = (a->c_dtype == MMDIT_BF16 || (swiglu && a->c_dtype == MMDIT_FP8)) && (!a->aux || (swiglu && a->c_dtype == MMDIT_BF16)) && !a->gate && !a->residual && a->K % 128 == 0 &&
+          a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) && (int64_t)a->M * a->lda < (1ll << 32) && (int64_t)a->N * a->ldb < (1ll << 32);
+  }
+  const bool p8 = mx8 || (p8_mode > 0 && ((kk && cfg == CFG_256x256) || (lean && (cfg == CFG_256x256 || (cfg == CFG_320x256 && p8_mode == 1 && !qkr)))));
   if (swiglu_bwd && !p8) return MMDIT_ERR_SHAPE;
   if (dma && ktail_any && !(kk && p8)) return gemm_grouped_impl(args, count, stream, plan_only, zero_mask, qkr, true);   // (only that kernel adds a K tail)
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)

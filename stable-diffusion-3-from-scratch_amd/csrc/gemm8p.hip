@@ -24,6 +24,7 @@
 #include "gemm_tile.h"
 
 using namespace gemm;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
 
 namespace {
 
@@ -304,7 +305,7 @@ __device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const G
 // SwiGLU-fused w12 GEMM: the wave's columns 0..31 are gate rows, 32..63 up rows of the SAME 32 hidden indices 128 tn + 32 wn + c (the DMA
 // source mapping interleaves them), so group q (columns (q & 3) * 16 ..) pairs with group q + 2; aux[M, 2h] (if given) gets the bf16
 // pre-activations, C[M, h] = silu(g) * u formed from the ROUNDED values (bit-identical to the GEMM followed by mmdit_swiglu_fwd)
-template <int MT>
+template <int MT, bool MXOUT = false>      // MXOUT: the MX-operand kernel (only there may the activation leave as e4m3 + block scales)
 __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage) {
   bf16_t* Hout = (bf16_t*)p.C;
   bf16_t* GU = (bf16_t*)p.aux;
@@ -363,6 +364,38 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (MXOUT && p.c_scales) {
+      // MX output (mxfp8 inference: the down-projection reads e4m3 + E8M0 block scales): the wave's 32 hidden indices of a row are ONE 32-block --
+      // a lane holds 8 of them (fragments j = 0, 1), the lanes wr, wr + 16, wr + 32, wr + 48 the rest.  Codes staged as 32 rows x 32 B and stored
+      // 16 B per lane; the arithmetic (mx_exponent / mx_pack4 on the bf16-ROUNDED activation) is that of gemm_tile.h epilogue_swiglu and of
+      // mmdit_mxfp8_quantize: bit-identical to the bf16 output followed by the quantise pass.
+#pragma unroll
+      for (int il = 0; il < 2; il++) {
+        float hv[8];
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+          for (int e = 0; e < 2; e++) { hv[4 * j + 2 * e] = __builtin_bit_cast(float, pa[il][j][e] << 16); hv[4 * j + 2 * e + 1] = __builtin_bit_cast(float, pa[il][j][e] & 0xffff0000u); }
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; e++) amax = fmaxf(amax, fabsf(hv[e]));
+        amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+        float inv;
+        const int ex = mx_exponent(amax, inv);
+        const int row = il * 16 + wr;
+#pragma unroll
+        for (int j = 0; j < 2; j++) *LDS_PTR(unsigned, stage + row * 32 + j * 16 + wq * 4) = mx_pack4(hv + 4 * j, inv);
+        const int myrow = m0 + wm * (MT / 2) + i * 32 + row;
+        if (wq == 0 && myrow < p.M) p.c_scales[mx_scale_index(myrow, hc >> 5, p.M)] = (unsigned char)(ex + 127);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const int r = lane >> 1, row = m0 + wm * (MT / 2) + i * 32 + r;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 32 + (lane & 1) * 16);
+      if (row < p.M) *(u32x4*)((unsigned char*)p.C + (int64_t)row * p.ldc + hc + (lane & 1) * 16) = t;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      continue;
+    }
     // the activation: 32 rows x 64 B (chunk c of row r at c ^ (r & 3))
 #pragma unroll
     for (int il = 0; il < 2; il++)
@@ -461,9 +494,18 @@ __device__ __forceinline__ void epi8_f32_slot(AccT<MT>& acc, float* slot, int wm
 // 2002 at the reference's own batch 13).  The main loop runs the whole K tiles; the item that ends at the end of K then adds the remaining
 // K % 64 rows from one more tile whose k-rows beyond K are zero-filled on their way into LDS (a plain load + ds_write pass in the LDS-DMA image,
 // un-pipelined: once per output tile).  A separate instantiation: launches whose K are all multiples of 64 run the code without it.
-template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false>
+// MX (round 5; inference, BASELINE configs[4]): e4m3 operands with E8M0 block scales on the SAME loop.  A row of 128 e4m3 values is 128 bytes, so
+// the LDS image, the DMA pieces, the swizzle and the fragment reads are those of the bf16 kernel byte for byte: a lane's two 16-byte fragments of a
+// K tile (chunks g and 4 + g of its row, g = lane >> 4: the bf16 k-steps 0 and 1) are exactly registers 0-3 and 4-7 of the 16x16x128 operand
+// (k = 16 g + [0, 16) and 64 + 16 g + [0, 16): tools/probes/mx16_probe.hip), ONE v_mfma_scale_f32_16x16x128_f8f6f4 replaces the two bf16 MFMAs
+// and a K tile is 128 deep.  The accumulator layout is that of 16x16x32, so the epilogues are shared.  Scales: lane (r, g) supplies the E8M0 byte
+// of row r, 32-block g of the K tile; in the tensor's layout (mx_scale_index) the bytes of the four 32-row blocks of a 128-row group share a dword,
+// so a lane loads 2 dwords per operand and K tile straight from global memory (L2-resident, a few KB per tile) with inline-asm loads one K tile
+// ahead -- they are older than every staging the counted wait of P4 leaves in flight, no extra wait, no LDS -- and op_sel picks the byte.
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   static_assert(MT == 256 || MT == 320, "tile rows");
+  static_assert(!MX || (!A_KM && !B_KM && MT == 256 && (EPI == EPI_BF16 || EPI == EPI_SWIGLU)), "MX: row-major e4m3 operands, 256-row tiles, bf16 / SwiGLU epilogue");
   static_assert(!KT || (A_KM && B_KM && EPI == EPI_F32), "K tail: the weight-gradient kernel");
   static_assert(EPI == EPI_F32 ? (A_KM && B_KM && MT == 256) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major, 256 rows); bf16 epilogues take a row-major A");
   static_assert(!(EPI == EPI_SWIGLU || EPI == EPI_QK) || !B_KM, "fused epilogues: row-major weight");
@@ -583,10 +625,68 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   uint64_t curA = 0, curB = 0, stepA = 0, stepB = 0;
   int nkt = 0, krem = 0;                   // K tiles of the current item; K tiles behind the one being multiplied
   int swig_h = 0;                          // SwiGLU: rows between the gate and the up half of the packed weight
+  // ---- MX operands: 8-register fragments (lo = chunk g, hi = chunk 4 + g of the row) and the scale dwords of two K tiles -----------------------
+  constexpr int NSC = !MX ? 1 : EPI == EPI_SWIGLU ? 6 : 4;      // A (rows i & 1 = 0, 1), B (j = 0, 1) -- SwiGLU: gate and up rows
+  i32x8 xa[MX ? FI : 1], xb0[MX ? 2 : 1], xb1[MX ? 2 : 1];
+  uint32_t sc[2][NSC];
+  uint32_t soffA = 0, soffB = 0;            // per-lane byte offsets into the scale tensors (this item)
+  uint64_t scurA = 0, scurB = 0, sstepA = 0, sstepB = 0, supB = 0;      // wave-uniform: scale bytes of the current K tile; bytes per K tile; gate -> up rows
+  auto xreadA = [&](int buf, int x) {
+#pragma unroll
+    for (int i = 0; i < (MX ? FI : 1); i++) {
+      xa[i].lo = *LDS_PTR(const i32x4_t, smem + buf * KBUF + x + aoff[0] + i * 2048);
+      xa[i].hi = *LDS_PTR(const i32x4_t, smem + buf * KBUF + x + aoff[1] + i * 2048);
+    }
+  };
+  auto xreadB = [&](i32x8 (&xb)[MX ? 2 : 1], int buf, int x) {
+#pragma unroll
+    for (int j = 0; j < (MX ? 2 : 1); j++) {
+      xb[j].lo = *LDS_PTR(const i32x4_t, smem + buf * KBUF + x + boff[0] + j * 2048);
+      xb[j].hi = *LDS_PTR(const i32x4_t, smem + buf * KBUF + x + boff[1] + j * 2048);
+    }
+  };
+  // scale dwords of K tile (current + d) into set `set` (inline asm: the compiler must neither count nor wait for these loads)
+  auto sload = [&](int set, int d) {
+    if constexpr (MX) {
+      const int dd = min(d, krem);
+      const uint64_t pa = scurA + (uint64_t)(uint32_t)dd * sstepA, pb = scurB + (uint64_t)(uint32_t)dd * sstepB;
+      const uint64_t ua = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa);
+      const uint64_t ub = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pb);
+      asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128" : "=v"(sc[set][0]), "=v"(sc[set][1]) : "v"(soffA), "s"(ua) : "memory");
+      asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128" : "=v"(sc[set][2]), "=v"(sc[set][3]) : "v"(soffB), "s"(ub) : "memory");
+      if constexpr (EPI == EPI_SWIGLU) {
+        const uint64_t pu = pb + supB;
+        const uint64_t uu = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pu >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pu);
+        asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128" : "=v"(sc[set][4]), "=v"(sc[set][5]) : "v"(soffB), "s"(uu) : "memory");
+      }
+    }
+  };
+  // the loads of set `set` have been waited for (counted vmcnt in front of this point): from here on the registers hold the data
+  auto spin = [&](int set) {
+    if constexpr (MX) {
+#pragma unroll
+      for (int k = 0; k < NSC; k++) asm volatile("" : "+v"(sc[set][k]));
+    }
+  };
+  // quadrant (qm, qn) of the K tile whose scales are in set `set`: c^T += B-fragment x A-fragment (first operand = the weight rows = output columns)
+  auto mmax = [&](f32x4 (&c)[2 * FI], const i32x8 (&xb)[MX ? 2 : 1], int set, int qm, int qn) {
+    if constexpr (MX) {
+      // B bytes: plain -- byte (wc & 1) * 2 + qn of the dword (shift by 16 (wc & 1), op_sel qn); SwiGLU -- byte wc of the gate (qn = 0) / up (qn = 1) dword
+      uint32_t sb[2];
+#pragma unroll
+      for (int j = 0; j < 2; j++) sb[j] = EPI == EPI_SWIGLU ? sc[set][2 + 2 * qn + j] >> (8 * wc) : sc[set][2 + j] >> (16 * (wc & 1));
+#pragma unroll
+      for (int i = 0; i < FI; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+          c[i * 2 + j] = mx16_mfma(xb[j], xa[i], c[i * 2 + j], EPI == EPI_SWIGLU ? 0 : qn, (int)sb[j], qm * 2 + (i >> 1), (int)sc[set][i & 1]);
+    }
+  };
+
   auto item_setup = [&](const Item& it) {
     const Problem& q = gp.p[it.pi];
     const int m0 = it.tm * MT, n0 = it.tn * 256;
-    ld2A = (uint32_t)q.lda * 2; ld2B = (uint32_t)q.ldb * 2;
+    ld2A = (uint32_t)q.lda * (MX ? 1 : 2); ld2B = (uint32_t)q.ldb * (MX ? 1 : 2);      // bytes per operand row (e4m3: one byte per value)
     if (A_KM) {   // (MT = 256 only) piece i: k-rows (8 i + wave) * 4 + (lane >> 4); LDS chunk (lane & 15) holds global chunk (lane & 15) ^ SWZ_K(k-row)
       const int kr = wave * 4 + (lane >> 4), lr0 = ((lane & 15) ^ SWZ_K(kr)) * 8;
       rowA = m0 + (lr0 >> 6) * 128 + (lr0 & 63); chkA = kr * ld2A; limA = q.M - 8;
@@ -610,6 +710,22 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     stepB = B_KM ? (uint64_t)64 * q.ldb * 2 : 128;
     curA = (uint64_t)(uintptr_t)q.A + kt0 * stepA;
     curB = (uint64_t)(uintptr_t)q.B + kt0 * stepB;
+    if constexpr (MX) {
+      // scale bytes of (row, K half) at ((half * rows_pad + (row & ~127)) * 2 + (row & 31) * 8 + (blk & 1) * 4 + ((row >> 5) & 3): mx_scale_index
+      const int64_t padA = ((int64_t)q.M + 127) & ~(int64_t)127, padB = ((int64_t)q.N + 127) & ~(int64_t)127;
+      sstepA = (uint64_t)padA * 4; sstepB = (uint64_t)padB * 4;                 // two 64-wide halves per K tile
+      const uint32_t lane_part = (uint32_t)((lane & 15) * 8 + ((lane >> 4) & 1) * 4);
+      soffA = (uint32_t)(wr * 256) + lane_part + (uint32_t)(lane >> 5) * (uint32_t)(padA * 2);
+      scurA = (uint64_t)(uintptr_t)q.scale_a + (uint64_t)kt0 * sstepA + (uint64_t)m0 * 2;
+      if constexpr (EPI == EPI_SWIGLU) {
+        soffB = lane_part + (uint32_t)(lane >> 5) * (uint32_t)(padB * 2);
+        scurB = (uint64_t)(uintptr_t)q.scale_b + (uint64_t)kt0 * sstepB + (uint64_t)(it.tn * 128) * 2;
+        supB = (uint64_t)(q.N >> 1) * 2;
+      } else {
+        soffB = (uint32_t)((wc >> 1) * 256) + lane_part + (uint32_t)(lane >> 5) * (uint32_t)(padB * 2);
+        scurB = (uint64_t)(uintptr_t)q.scale_b + (uint64_t)kt0 * sstepB + (uint64_t)n0 * 2;
+      }
+    }
   };
   // half-tile h of K tile (current + d), d = 0 / 1 / 2 -> buffer buf
   auto stageA = [&](int h, int d, int buf) {
@@ -650,7 +766,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       glds16(voff, src, dst + i * 8192);
     }
   };
-  auto next_ktile = [&]() { curA += stepA; curB += stepB; krem--; };
+  auto next_ktile = [&]() { curA += stepA; curB += stepB; krem--; if constexpr (MX) { scurA += sstepA; scurB += sstepB; } };
   // Two schedules.  KEEP (256 rows): B0 stays in registers from P1 to P4; stagings P1(t): A1(t+1), P2(t): A0(t+2), P3(t): B0(t+2), P4(t): B1(t+2);
   // the three youngest half-tiles at the counted wait are A, B, B.  REREAD (320 rows: 160 accumulator + 40 A-fragment registers leave room for ONE
   // set of B fragments): P4 reads B0 again, so B0 is restaged last -- P1(t): B0(t+1), P2(t): A0(t+2), P3(t): B1(t+2), P4(t): A1(t+2); youngest A, B, A.
@@ -706,6 +822,35 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     next_ktile();                                                                                            \
   }
 
+  // MX K tile (KEEP schedule): the phases of KTILE8 with 8-register fragments and one scaled MFMA per 16 x 16 block; P1 requests the NEXT K tile's
+  // scale dwords into the other register set (older than every staging P4's counted wait leaves in flight)
+#define KTILE8X(cur)                                                                                         \
+  {                                                                                                          \
+    xreadB(xb0, cur, XB0); __builtin_amdgcn_sched_barrier(0); xreadA(cur, XA0);                              \
+    sload((cur) ^ 1, 1);                                                                                     \
+    stageA(1, 1, (cur) ^ 1);                                                                                 \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mmax(acc.a[0][0], xb0, cur, 0, 0);                                                                       \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    xreadB(xb1, cur, XB1);                                                                                   \
+    stageA(0, 2, cur);                                                                                       \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mmax(acc.a[0][1], xb1, cur, 0, 1);                                                                       \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    xreadA(cur, XA1);                                                                                        \
+    stageB(0, 2, cur);                                                                                       \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mmax(acc.a[1][1], xb1, cur, 1, 1);                                                                       \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    stageB(1, 2, cur);                                                                                       \
+    wait3();                                                                                                 \
+    spin((cur) ^ 1);                                                                                         \
+    LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
+    mmax(acc.a[1][0], xb0, cur, 1, 0);                                                                       \
+    __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
+    next_ktile();                                                                                            \
+  }
+
   // the first K tile of an item (KEEP schedule, 256 rows): always from a constant-zero C (no zero-fill of the accumulators); with `dr` the previous
   // tile drains in its load sections.  The counted wait of P4 must then leave the stagings of P2, P3, P4 in flight AND the 3 x FI stores issued
   // between them (each phase: stores first, then its staging).
@@ -756,7 +901,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   // inside the next tile's first K tile, with the following waits relaxed (debug 256), as streaming stores (debug 1024), or with the workgroups'
   // start times spread over a tile period (debug >> 16): correct, bit-identical, not faster.  NOT the product: probes builds only.
 #ifdef MMDIT_PROBES
-  constexpr bool DRAIN = DEFER && EPI == EPI_BF16;
+  constexpr bool DRAIN = DEFER && EPI == EPI_BF16 && !MX;
 #else
   constexpr bool DRAIN = false;
 #endif
@@ -789,7 +934,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   if (gp.debug & 8) { if (acc.a[0][0][0][0] == 12345.f) ((float*)q.C)[0] = 1.f; return; }      // ablation (MMDIT_GEMM_DEBUG=8): no epilogue
 #endif
   if constexpr (EPI == EPI_BF16) epi8_bf16<MT>(acc, q, gp, m0, n0, wr, wc, lane, stage);
-  else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT>(acc, q, m0, it.tn, wr, wc, lane, stage);
+  else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT, MX>(acc, q, m0, it.tn, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[it.pi & 1], m0, n0, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_SWIGLU_BWD) epi8_swiglu_bwd<MT>(acc, q, m0, n0, wr, wc, lane, stage);
   else {
@@ -862,6 +1007,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   while (item.valid) {
     item_setup(item);
     if (nkt > 0) {
+      if constexpr (MX) sload(0, 0);      // (first: the scale dwords of K tile 0 are older than the stagings the first counted wait leaves in flight)
       // prologue: K tile 0 whole, three half-tiles of K tile 1 (in the order the loop continues; second argument: K tiles ahead)
       if (REREAD) { stageA(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageB(0, 0, 0); stageA(0, 1, 1); stageB(1, 1, 1); stageA(1, 1, 1); }
       else { stageA(0, 0, 0); stageB(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageA(0, 1, 1); stageB(0, 1, 1); stageB(1, 1, 1); }
@@ -892,6 +1038,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
           KTILE8(0)
         }
         if (t < nkt) KTILE8(1)
+      } else if constexpr (MX) {
+        spin(0);
+#pragma unroll 1
+        for (; t + 1 < nkt; t += 2) {
+          KTILE8X(0)
+          KTILE8X(1)
+        }
+        if (t < nkt) KTILE8X(0)
       } else {
 #pragma unroll 1
         for (; t + 1 < nkt; t += 2) {
@@ -960,9 +1114,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   if (DEFER && pending) run_epilogue(prev);
 }
 
-template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false>
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false>
 int launch8(const GroupParams& gp, hipStream_t s) {
-  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI, KT>;
+  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI, KT, MX>;
   constexpr int smem = Geo<MT>::SMEM;
   static unsigned long long attr_done = 0;   // one bit per device
   if (!mmdit_device_once(attr_done)) {
@@ -978,6 +1132,12 @@ int launch8(const GroupParams& gp, hipStream_t s) {
 
 template <int MT>
 int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s) {
+  if (gp.mx) {         // e4m3 operands with E8M0 block scales (inference): 256-row tiles, row-major weight, bf16 output or the SwiGLU epilogue
+    if constexpr (MT == 256) {
+      if (b_km || gp.qk_on || gp.act == MMDIT_ACT_SWIGLU_BWD || gp.act == MMDIT_ACT_SILU) return MMDIT_ERR_ARG;
+      return gp.act == MMDIT_ACT_SWIGLU ? launch8<MT, false, false, EPI_SWIGLU, false, true>(gp, s) : launch8<MT, false, false, EPI_BF16, false, true>(gp, s);
+    } else return MMDIT_ERR_SHAPE;
+  }
   if (gp.qk_on) {      // (at 320 rows the QKV epilogue does not fit the register budget without spills in the K loop: gemm.hip keeps that launch on the wide kernel)
     if constexpr (MT == 256) return b_km ? MMDIT_ERR_ARG : launch8<MT, false, false, EPI_QK>(gp, s);
     else return MMDIT_ERR_SHAPE;

@@ -115,6 +115,23 @@ __device__ __forceinline__ f32x16 mx_mfma(i32x8 a, i32x8 b, f32x16 c, int oa, in
   }
 }
 
+// the 16x16x128 form (gemm8p.hip MX): same literal-op_sel dispatch
+template <int OA, int OB>
+__device__ __forceinline__ f32x4 mx16_mfma_lit(i32x8 a, i32x8 b, f32x4 c, int sa, int sb) {
+  return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, OA, sa, OB, sb);
+}
+__device__ __forceinline__ f32x4 mx16_mfma(i32x8 a, i32x8 b, f32x4 c, int oa, int sa, int ob, int sb) {
+  switch (oa * 4 + ob) {
+#define MMDIT_MX_CASE(A, B) case A * 4 + B: return mx16_mfma_lit<A, B>(a, b, c, sa, sb);
+    MMDIT_MX_CASE(0, 0) MMDIT_MX_CASE(0, 1) MMDIT_MX_CASE(0, 2) MMDIT_MX_CASE(0, 3)
+    MMDIT_MX_CASE(1, 0) MMDIT_MX_CASE(1, 1) MMDIT_MX_CASE(1, 2) MMDIT_MX_CASE(1, 3)
+    MMDIT_MX_CASE(2, 0) MMDIT_MX_CASE(2, 1) MMDIT_MX_CASE(2, 2) MMDIT_MX_CASE(2, 3)
+    MMDIT_MX_CASE(3, 0) MMDIT_MX_CASE(3, 1) MMDIT_MX_CASE(3, 2)
+#undef MMDIT_MX_CASE
+    default: return mx16_mfma_lit<3, 3>(a, b, c, sa, sb);
+  }
+}
+
 // fp8 operand fragment of the 64-wide MX MFMA (v_mfma_scale_f32_32x32x64_f8f6f4).  K layout of the instruction (established with
 // block scales that vary along K, tools/probes/mx_dbg.py): registers 0-3 of lane l hold k = 16 (l >> 5) + [0, 16), registers 4-7
 // k = 32 + 16 (l >> 5) + [0, 16) of row l & 31 -- the 16-byte chunks (l >> 5) and 2 + (l >> 5) of the 64-byte row.  The E8M0 scale
