@@ -236,11 +236,14 @@ def test_gradients_parity_mode_vs_reference_golden(cname, h, w, golden_dir):
 
 @pytest.mark.parametrize("cname,h,w", [("micro", 16, 16), ("xs", 64, 64), ("b", 32, 32)])
 def test_gradients_fast_mode_vs_oracle_autograd(cname, h, w):
-    """Backward of the BENCHMARKED (bf16) mode against torch autograd through the CPU oracle run with the same rounding points
-    (bf16 GEMM operands and stored activations, flash-style attention), every parameter, at micro / XS / MMDiT-B depth (12 blocks,
-    d = 768, 32x32 latents, batch 2).  Bars: rel-L2 6e-2 per parameter through 2-3 blocks and 1e-1 through 12 blocks (bf16
-    gradients flip roundings chaotically through depth, as the forward does); the three scalar parameters (heavily cancelling sums) 2e-1, at
-    B depth ten times the oracle's own fp32-vs-float64 distance if that is more; the per-parameter numbers are printed."""
+    """Backward of the BENCHMARKED (bf16) mode against torch autograd through the CPU oracle run with the same rounding points in BOTH
+    directions (forward: bf16 GEMM operands and stored activations, flash-style attention; backward: every gradient that feeds a GEMM rounded
+    to bf16, `grad_round=True`), every parameter, at micro / XS / MMDiT-B depth (12 blocks, d = 768, 32x32 latents, batch 2).
+    Bars (round 5, from the per-block backward tests of tests/test_trained_shape_gpu.py -- one block's gradients sit within max(5e-3, 2 x the
+    oracle's own fp32-vs-float64 distance) -- and the numbers measured here: tensors <= 7.4e-3 at B depth, <= 6.7e-3 at micro / XS): every tensor
+    parameter rel-L2 < 2e-2 at B depth, 1.5e-2 through 2-3 blocks; the three scalar parameters (heavily cancelling sums over the whole text /
+    time path: measured 7.3e-2 / 9.4e-3 at B, <= 5e-2 at micro / XS) < max(1e-1, 2 x the oracle's own fp32-vs-float64 distance), never more than
+    3e-1.  (Against the oracle WITHOUT gradient rounding learnable_scalar read 2.8e-1 at B depth: most of that was the comparator.)"""
     x, c, cp = make_inputs(6, 2, h, w, text_scale=30.0)
     t = torch.tensor([0.35, 0.8])
     net, sd = build(cname, precision="fast")
@@ -248,18 +251,17 @@ def test_gradients_fast_mode_vs_oracle_autograd(cname, h, w):
     v = net(x.cuda(), t, c.cuda(), cp.cuda())
     v.pow(2).mean().backward()
     sdr = {k: val.clone().requires_grad_(not k.endswith("freqs")) for k, val in sd.items()}
-    vo = O.forward(sdr, O.OracleConfig(**CONFIGS[cname], attn_core="flash_bf16", gemm="bf16"), x, t, c, cp)
+    vo = O.forward(sdr, O.OracleConfig(**CONFIGS[cname], attn_core="flash_bf16", gemm="bf16", grad_round=True), x, t, c, cp)
     vo.pow(2).mean().backward()
-    bar = 1e-1 if cname == "b" else 6e-2
+    bar = 2e-2 if cname == "b" else 1.5e-2
     # The three scalar parameters are sums with heavy cancellation over the whole text path (learnable_scalar: sum over B x 77 x 2304 products
     # of the gradient that has come back through every block); at B depth their error is rounding noise amplified by that cancellation.  The
     # yardstick: how far the ORACLE's own gradient of the scalar moves when it is run in exact (float64) arithmetic between the same rounding
-    # points (learnable_scalar 5.6e-2, learnable_scalar2 1.1e-2, every tensor parameter <= 1e-2, against which their bar of 1e-1 stands): the
-    # scalars get the same factor of ten over their own floor, and never less than 2e-1.
+    # points (round 5, with gradient rounding: learnable_scalar 7.0e-2, learnable_scalar2 1.4e-2, time_scale 4.0e-3).
     floor = {}
     if cname == "b":
         sd64 = {k: (val.double().clone().requires_grad_(not k.endswith("freqs")) if val.is_floating_point() else val) for k, val in sd.items()}
-        O.forward(sd64, O.OracleConfig(**CONFIGS[cname], attn_core="flash_bf16", gemm="bf16", dtype=torch.float64), x.double(), t.double(), c.double(), cp.double()).pow(2).mean().backward()
+        O.forward(sd64, O.OracleConfig(**CONFIGS[cname], attn_core="flash_bf16", gemm="bf16", grad_round=True, dtype=torch.float64), x.double(), t.double(), c.double(), cp.double()).pow(2).mean().backward()
         floor = {n: rel(sdr[n].grad, sd64[n].grad) for n, p in net.named_parameters() if p.requires_grad and p.numel() == 1}
         print(f"[grads fast] {cname}: oracle fp32 vs float64 distance of the scalar parameters: " + ", ".join(f"{n} {v:.2e}" for n, v in floor.items()))
     res = []
@@ -273,7 +275,7 @@ def test_gradients_fast_mode_vs_oracle_autograd(cname, h, w):
     for r, n, k in res[:6]:
         print(f"    {r:.3e}  {n}  ({k} elements)")
     for r, n, k in res:
-        assert r < (max(2e-1, 10.0 * floor.get(n, 0.0)) if k == 1 else bar), (n, r)
+        assert r < (min(3e-1, max(1e-1, 2.0 * floor.get(n, 0.0))) if k == 1 else bar), (n, r)
     net.zero_grad()
 
 

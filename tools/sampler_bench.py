@@ -16,6 +16,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--B", action="store_true")
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--steps", type=int, default=28)
+ap.add_argument("--modes", default="fast,fp8,mxfp8", help="precision modes to time (comma separated)")
 args = ap.parse_args()
 cfg = dict(dim=768, num_heads=12, num_blocks=12) if args.B else dict(dim=1024, num_heads=16, num_blocks=24)
 res = 256 if args.B else 512
@@ -61,7 +62,7 @@ def fwd_flops(d, blocks, N, M=154):
 import json  # noqa: E402
 F_FWD = fwd_flops(cfg["dim"], cfg["num_blocks"], (res // 16) ** 2)
 net.text_encoders = _Enc()
-for prec in ("fast", "fp8", "mxfp8"):
+for prec in args.modes.split(","):
     net.set_precision(prec)
     net.sample_imgs(args.batch, 2, ["x"], cfg_scale=3.0, width=res, height=res, generator=torch.Generator().manual_seed(0))
     torch.cuda.synchronize()
