@@ -232,7 +232,9 @@ def test_dropping_a_real_graph_with_collectives_then_eager_steps():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     tr = None
     try:
-        l0, l1, p0, p1, tr = graph_vs_eager("micro", 4, 128, n_steps=5, pattern="burst", force_reducer=True, drop_after=2)
+        # (four steps, as the other replay tests: the backward's fp32 atomics make two runs of the SAME code drift apart step by step,
+        #  tools/probes/determinism.py, and check()'s parameter bars are sized for three to four steps)
+        l0, l1, p0, p1, tr = graph_vs_eager("micro", 4, 128, n_steps=4, pattern="burst", force_reducer=True, drop_after=2)
         assert tr._graph is None and tr.replayed_steps == 2 and tr.reducer.enabled
         more = [float(tr.train_step(s)) for s in (9, 10)]      # and it keeps training
         assert all(1e-3 < x < 10 for x in more)
