@@ -559,10 +559,20 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
           a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) && (int64_t)a->M * a->lda < (1ll << 32) && (int64_t)a->N * a->ldb < (1ll << 32);
   }
   const bool p8 = mx8 || (p8_mode > 0 && ((kk && cfg == CFG_256x256) || (lean && (cfg == CFG_256x256 || (cfg == CFG_320x256 && p8_mode == 1 && !qkr)))));
+  // implicit-GEMM convolutions on the 8-phase loop (round 5): 256 x 256 tiles, every problem a convolution with C % 64 == 0, bf16 output (bias) or fp32 output
+  // (bias + residual), nothing else in the epilogue
+  bool conv8 = p8_mode > 0 && conv && dma && !fp8 && cfg == CFG_256x256 && !stream_k && split_k == 1 && a0->act == MMDIT_ACT_NONE && !a0->accumulate &&
+               (a0->c_dtype == MMDIT_BF16 || a0->c_dtype == MMDIT_F32);
+  for (int i = 0; i < count && conv8; i++) {
+    const mmdit_gemm_args* a = &args[i];
+    conv8 = a->conv_mode && a->conv_C % 64 == 0 && !a->aux && !a->gate && (a->c_dtype == MMDIT_F32 || !a->residual) && a->N % 8 == 0 && a->ldc % 8 == 0 && aligned16(a->C) &&
+            (!a->residual || (a->ld_res % 4 == 0 && aligned16(a->residual))) && (!a->bias || aligned16(a->bias));
+  }
   if (swiglu_bwd && !p8) return MMDIT_ERR_SHAPE;
   if (dma && ktail_any && !(kk && p8)) return gemm_grouped_impl(args, count, stream, plan_only, zero_mask, qkr, true);   // (only that kernel adds a K tail)
-  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
+  if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 || conv8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
+  if (conv8) return launch_gemm8_conv(a0->c_dtype == MMDIT_F32, gp, s);
   if (p8) return launch_gemm8(cfg, a0->a_kmajor, a0->b_kmajor, gp, s, ktail_any);
   if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
   if (kk) return launch_lean_wgrad(gp, s);

@@ -42,7 +42,7 @@ template <int MT> struct Geo {
   static constexpr int NB32 = MT / 64;                     // 32-row blocks of a wave's rows (4 / 5)
 };
 
-enum Epi8 { EPI_BF16 = 0, EPI_SWIGLU = 1, EPI_QK = 2, EPI_F32 = 3, EPI_SWIGLU_BWD = 4 };
+enum Epi8 { EPI_BF16 = 0, EPI_SWIGLU = 1, EPI_QK = 2, EPI_F32 = 3, EPI_SWIGLU_BWD = 4, EPI_F32R = 5 };
 
 #define SWZ_R(r) (((r) >> 1) & 7)
 #define SWZ_K(k) ((((k) & 3) << 2) ^ ((((k) >> 3) & 1) << 1))
@@ -458,6 +458,43 @@ __device__ __forceinline__ void epi8_f32(AccT<MT>& acc, const Problem& p, int m0
     }
 }
 
+// fp32 output + bias + residual (the FLUX-VAE convolutions, vae.py _conv3: y = conv(x) + b (+ shortcut)): staged per 32 x 32 block like epi8_f32, the read-back
+// side (8 lanes per row, 4 columns each) adds the bias and the residual row and stores 16 bytes
+template <int MT>
+__device__ __forceinline__ void epi8_f32r(AccT<MT>& acc, const Problem& p, int m0, int n0, int wm, int wn, int lane, char* stage) {
+  float* C = (float*)p.C;
+  const int wr = lane & 15, wq = lane >> 4;
+  const int rr = lane >> 3, rc = lane & 7;
+#pragma unroll
+  for (int i = 0; i < Geo<MT>::NB32; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int col = n0 + wn * 64 + j * 32 + rc * 4;
+      const int row0 = m0 + wm * (MT / 2) + i * 32 + rr;
+      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias && col < p.N) b4 = *(const f32x4*)(p.bias + col);
+#pragma unroll
+      for (int il = 0; il < 2; il++)
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+          const int row = il * 16 + wr;
+          *LDS_PTR(f32x4, stage + row * 128 + (((jj * 4 + wq) ^ (row & 7)) << 4)) = grp(acc, i, il * 4 + j * 2 + jj);
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = row0 + it * 8;
+        if (row >= p.M || col >= p.N) continue;
+        t += b4;
+        if (p.residual) t += *(const f32x4*)(p.residual + (int64_t)row * p.ld_res + col);
+        *(f32x4*)(C + (int64_t)row * p.ldc + col) = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // a partial tile of the split tail into its workspace slot (row-major [256][256] fp32, device-scope write-through stores)
 template <int MT>
 __device__ __forceinline__ void epi8_f32_slot(AccT<MT>& acc, float* slot, int wm, int wn, int lane, char* stage) {
@@ -502,9 +539,15 @@ __device__ __forceinline__ void epi8_f32_slot(AccT<MT>& acc, float* slot, int wm
 // of row r, 32-block g of the K tile; in the tensor's layout (mx_scale_index) the bytes of the four 32-row blocks of a 128-row group share a dword,
 // so a lane loads 2 dwords per operand and K tile straight from global memory (L2-resident, a few KB per tile) with inline-asm loads one K tile
 // ahead -- they are older than every staging the counted wait of P4 leaves in flight, no extra wait, no LDS -- and op_sel picks the byte.
-template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false>
+// CONV (round 5; BASELINE configs[3]): A is the zero-bordered NHWC operand of an implicit-GEMM 3 x 3 convolution (gemm_common.h Problem::conv_mode): output
+// row m = (b, yo, xo) reads pixel (s yo + kh + o, s xo + kw + o), K index (kh * 3 + kw) * C + c.  Inside a kernel row the 3 C channels of the three taps are
+// contiguous, so the K tile base advances by 128 bytes and jumps by (Wp - 3) C elements every 3 C / 64 K tiles; the per-lane part of the address is the
+// pixel offset of the lane's output row, one register per (half-tile, piece) instead of the row * ld product.
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false, bool CONV = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   static_assert(MT == 256 || MT == 320, "tile rows");
+  static_assert(!CONV || (!A_KM && !B_KM && MT == 256 && !MX && (EPI == EPI_BF16 || EPI == EPI_F32R)), "implicit-GEMM convolution: row-major operands, 256-row tiles");
+  static_assert(EPI != EPI_F32R || (!A_KM && MT == 256), "fp32 + residual epilogue: row-major A, 256-row tiles");
   static_assert(!MX || (!A_KM && !B_KM && MT == 256 && (EPI == EPI_BF16 || EPI == EPI_SWIGLU)), "MX: row-major e4m3 operands, 256-row tiles, bf16 / SwiGLU epilogue");
   static_assert(!KT || (A_KM && B_KM && EPI == EPI_F32), "K tail: the weight-gradient kernel");
   static_assert(EPI == EPI_F32 ? (A_KM && B_KM && MT == 256) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major, 256 rows); bf16 epilogues take a row-major A");
@@ -683,6 +726,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     }
   };
 
+  uint32_t cvA[2][CONV ? PAW : 1];        // CONV: pixel byte offset of this lane's row in piece i of half-tile h
+  int cseg_left = 0, cseg_len = 0;        // CONV: K tiles left in / per kernel row
+  uint64_t cjump = 0;                     // CONV: extra bytes when the K index moves to the next kernel row
   auto item_setup = [&](const Item& it) {
     const Problem& q = gp.p[it.pi];
     const int m0 = it.tm * MT, n0 = it.tn * 256;
@@ -710,6 +756,23 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     stepB = B_KM ? (uint64_t)64 * q.ldb * 2 : 128;
     curA = (uint64_t)(uintptr_t)q.A + kt0 * stepA;
     curB = (uint64_t)(uintptr_t)q.B + kt0 * stepB;
+    if constexpr (CONV) {
+      const int hw = q.cHo * q.cWo, sdn = q.conv_mode == 2 ? 2 : 1, o = q.conv_mode == 2 ? 1 : 0;
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int i = 0; i < PAW; i++) {
+          const int lr = 64 * i + wave * 8 + (lane >> 3);                               // local row of the half-tile: wave row lr / 64, quadrant row lr % 64
+          const int m = min(m0 + (lr >> 6) * 128 + h * 64 + (lr & 63), q.M - 1);
+          const int bimg = m / hw, rem = m - bimg * hw, yo = rem / q.cWo, xo = rem - yo * q.cWo;
+          cvA[h][i] = (uint32_t)((((int64_t)bimg * q.cHp + sdn * yo) * q.cWp + sdn * xo) * q.cC * 2);
+        }
+      cseg_len = 3 * (q.cC / 64);
+      const int kh = kt0 / cseg_len, within = kt0 - kh * cseg_len;
+      cjump = (uint64_t)((int64_t)q.cWp - 3) * q.cC * 2;
+      curA = (uint64_t)(uintptr_t)q.A + (uint64_t)((((int64_t)(kh + o) * q.cWp + o) * q.cC) * 2) + (uint64_t)within * 128;
+      cseg_left = cseg_len - within;
+    }
     if constexpr (MX) {
       // scale bytes of (row, K half) at ((half * rows_pad + (row & ~127)) * 2 + (row & 31) * 8 + (blk & 1) * 4 + ((row >> 5) & 3): mx_scale_index
       const int64_t padA = ((int64_t)q.M + 127) & ~(int64_t)127, padB = ((int64_t)q.N + 127) & ~(int64_t)127;
@@ -730,7 +793,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   // half-tile h of K tile (current + d), d = 0 / 1 / 2 -> buffer buf
   auto stageA = [&](int h, int d, int buf) {
     const int dd = min(d, krem);
-    const char* src = (const char*)(uintptr_t)(curA + (uint64_t)(uint32_t)dd * stepA);
+    const char* src = (const char*)(uintptr_t)(curA + (uint64_t)(uint32_t)dd * stepA + (CONV && dd >= cseg_left ? cjump : 0));      // (CONV: d <= 2 < a kernel row's K tiles)
     const uint32_t dst = ldsw + buf * KBUF + (h ? XA1 : XA0);
 #pragma unroll
     for (int i = 0; i < PAW; i++) {
@@ -742,7 +805,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         int drow;
         if (MT == 256) drow = i * 128 + h * 64;                  // QR = 64: piece i is wave row i
         else drow = 0;                                           // (320: see below)
-        if (MT == 256) voff = (uint32_t)min((int)rowA + drow, limA) * ld2A + chkA;
+        if (CONV) voff = cvA[h][CONV ? i : 0] + chkA;
+        else if (MT == 256) voff = (uint32_t)min((int)rowA + drow, limA) * ld2A + chkA;
         else {
           // QR = 80: local row lr = 64 i + 8 wave + (lane >> 3) (< 160); tile row = (lr >= 80 ? 160 : 0) + h * 80 + (lr >= 80 ? lr - 80 : lr) = lr + (lr >= 80 ? 80 : 0) + h * 80
           const int lr = lr0 + (int)rowA;                        // rowA carries m0 + 8 wave + (lane >> 3)
@@ -766,7 +830,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       glds16(voff, src, dst + i * 8192);
     }
   };
-  auto next_ktile = [&]() { curA += stepA; curB += stepB; krem--; if constexpr (MX) { scurA += sstepA; scurB += sstepB; } };
+  auto next_ktile = [&]() {
+    curA += stepA; curB += stepB; krem--;
+    if constexpr (MX) { scurA += sstepA; scurB += sstepB; }
+    if constexpr (CONV) { if (--cseg_left == 0) { curA += cjump; cseg_left = cseg_len; } }
+  };
   // Two schedules.  KEEP (256 rows): B0 stays in registers from P1 to P4; stagings P1(t): A1(t+1), P2(t): A0(t+2), P3(t): B0(t+2), P4(t): B1(t+2);
   // the three youngest half-tiles at the counted wait are A, B, B.  REREAD (320 rows: 160 accumulator + 40 A-fragment registers leave room for ONE
   // set of B fragments): P4 reads B0 again, so B0 is restaged last -- P1(t): B0(t+1), P2(t): A0(t+2), P3(t): B1(t+2), P4(t): A1(t+2); youngest A, B, A.
@@ -937,6 +1005,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT, MX>(acc, q, m0, it.tn, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[it.pi & 1], m0, n0, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_SWIGLU_BWD) epi8_swiglu_bwd<MT>(acc, q, m0, n0, wr, wc, lane, stage);
+  else if constexpr (EPI == EPI_F32R) epi8_f32r<MT>(acc, q, m0, n0, wr, wc, lane, stage);
   else {
     if (it.atomic && gp.ws_slots) {
       // partial tile of the split tail through the workspace (gemm_lean.hip gemm_kk_kernel: slot store, ticket, the last slice sums)
@@ -1114,9 +1183,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   if (DEFER && pending) run_epilogue(prev);
 }
 
-template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false>
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false, bool CONV = false>
 int launch8(const GroupParams& gp, hipStream_t s) {
-  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI, KT, MX>;
+  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI, KT, MX, CONV>;
   constexpr int smem = Geo<MT>::SMEM;
   static unsigned long long attr_done = 0;   // one bit per device
   if (!mmdit_device_once(attr_done)) {
@@ -1154,6 +1223,11 @@ int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s) {
 
 // MT x 256 tiles (cfg CFG_256x256 or CFG_320x256).  a_km && b_km: fp32 weight gradients (256 rows; the K-decomposed schedule of gemm.hip);
 // otherwise bf16 output with the bias / SiLU, SwiGLU (gp.act) or QKV (gp.qk_on) epilogue.  gemm.hip has checked the rest.
+// implicit-GEMM 3 x 3 convolution (every problem of the launch has conv_mode != 0), 256 x 256 tiles: bf16 output (+ bias / SiLU) or fp32 output + bias + residual
+int gemm::launch_gemm8_conv(bool f32_out, const GroupParams& gp, hipStream_t s) {
+  return f32_out ? launch8<256, false, false, EPI_F32R, false, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, false, true>(gp, s);
+}
+
 int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s, bool ktail) {
   if (a_km) {
     if (!b_km || cfg != CFG_256x256) return MMDIT_ERR_ARG;
