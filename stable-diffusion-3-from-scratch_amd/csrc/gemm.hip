@@ -274,7 +274,7 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
   // in favour of 256x256, out-proj / w3 (N = 768) 37 vs 39 us, 98 vs 107 us in favour of 128x128)
   // (round 5: MX operands with a bf16 / SwiGLU output run the 8-phase kernel at 256x256 (gemm8p.hip MX) -- out-proj 32.0 vs 38.0 us, w3 76.4 vs
   //  100.1 us in favour of 256x256 now: a 256x256 round costs ~1.2 rounds of 128x128 tiles there)
-  const bool mx8 = args[0].a_dtype == MMDIT_FP8 && args[0].scale_mode == 1 && args[0].K % 128 == 0 && !args[0].gate && !args[0].residual &&
+  const bool mx8 = args[0].a_dtype == MMDIT_FP8 && args[0].K % 128 == 0 && !args[0].gate && !args[0].residual && !args[0].aux &&
                    (args[0].c_dtype == MMDIT_BF16 || args[0].act == MMDIT_ACT_SWIGLU);
   const double r256 = mx8 ? 1.2 : args[0].a_dtype == MMDIT_FP8 ? 1.67 : 1.58;
   const double c128 = (double)((t128 * split_k + 511) / 512), c256 = r256 * (double)((t256 * split_k + 255) / 256);
@@ -551,8 +551,8 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   static const int p8_mode = p8_env ? atoi(p8_env) : 1;      // 1: every lean launch; 2: only the 256x256 ones
   // (the QKV launch with the QK-norm / RoPE epilogue stays on the wide kernel at 320 rows: with that epilogue's registers the 320-row 8-phase
   //  variant measured slower, 1.73 vs 1.59 ms per step)
-  // MX (e4m3 operands with E8M0 block scales) on the 8-phase loop: 256 x 256 tiles, bf16 output (bias allowed) or the SwiGLU epilogue (bf16 or MX output)
-  bool mx8 = p8_mode > 0 && dma && fp8 && gp.mx && cfg == CFG_256x256 && !qkr && !stream_k && split_k == 1 && (a0->act == MMDIT_ACT_NONE || swiglu) && !a0->accumulate;
+  // e4m3 operands (E8M0 block scales or per-tensor scales) on the 8-phase loop: 256 x 256 tiles, bf16 output (bias allowed) or the SwiGLU epilogue (bf16 or MX output)
+  bool mx8 = p8_mode > 0 && dma && fp8 && cfg == CFG_256x256 && !qkr && !stream_k && split_k == 1 && (a0->act == MMDIT_ACT_NONE || swiglu) && !a0->accumulate;
   for (int i = 0; i < count && mx8; i++) {
     const mmdit_gemm_args* a = &args[i];
     mx8 = (a->c_dtype == MMDIT_BF16 || (swiglu && a->c_dtype == MMDIT_FP8)) && (!a->aux || (swiglu && a->c_dtype == MMDIT_BF16)) && !a->gate && !a->residual && a->K % 128 == 0 &&
@@ -573,7 +573,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   if (plan_only) return dma ? (cfg | (gp.stream_k ? 16 : 0) | (tail_mode ? 32 : 0) | (lean || kk ? 128 : 0) | (p8 || conv8 ? 256 : 0)) : 64;   // see mmdit_gemm_plan (128 with k-major A: the lean weight-gradient kernel)
   hipStream_t s = (hipStream_t)stream;
   if (conv8) return launch_gemm8_conv(a0->c_dtype == MMDIT_F32, gp, s);
-  if (p8) return launch_gemm8(cfg, a0->a_kmajor, a0->b_kmajor, gp, s, ktail_any);
+  if (p8) return launch_gemm8(cfg, a0->a_kmajor, a0->b_kmajor, gp, s, ktail_any, mx8);
   if (lean) return launch_lean_cfg(cfg, a0->b_kmajor, gp, s);
   if (kk) return launch_lean_wgrad(gp, s);
   if (dma) return launch_dma(cfg, a0->a_kmajor, a0->b_kmajor, a0->c_dtype, aux_dt, fp8, gp, s);

@@ -62,8 +62,8 @@ __device__ __forceinline__ f32x4& grp(AccT<MT>& acc, int i32, int q) {
 // ---- epilogues (the arithmetic and the read-back / store side are those of gemm_tile.h; only the write side knows the fragment layout) ------
 // bf16 output (+ bias, + SiLU): the wave's 32 x 64 block is converted first, staged as 32 rows x 128 B (chunk c of row r at c ^ (r & 7)) and
 // leaves as 8 rows x 128 B per wave instruction
-template <int MT>
-__device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, char* stage) {
+template <int MT, bool SC = false>      // SC (e4m3 operands with per-tensor scales): the accumulators are multiplied by alpha = scale_a * scale_b first
+__device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, char* stage, float alpha = 1.f) {
   bf16_t* C = (bf16_t*)p.C;
   const float* bias = p.bias;
   const int wr = lane & 15, wq = lane >> 4;            // write side: row within the 16-row fragment, 4-column group
@@ -118,6 +118,10 @@ __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const
     for (int q = 0; q < 8; q++) {
       const f32x4& a = grp(acc, i, q);
       float v[4] = {a[0], a[1], a[2], a[3]};
+      if constexpr (SC) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] *= alpha;
+      }
       if (bias) {
 #pragma unroll
         for (int e = 0; e < 4; e++) v[e] += bv[q & 3][e];
@@ -306,7 +310,7 @@ __device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const G
 // source mapping interleaves them), so group q (columns (q & 3) * 16 ..) pairs with group q + 2; aux[M, 2h] (if given) gets the bf16
 // pre-activations, C[M, h] = silu(g) * u formed from the ROUNDED values (bit-identical to the GEMM followed by mmdit_swiglu_fwd)
 template <int MT, bool MXOUT = false>      // MXOUT: the MX-operand kernel (only there may the activation leave as e4m3 + block scales)
-__device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage) {
+__device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int m0, int tn, int wm, int wn, int lane, char* stage, float alpha = 1.f) {
   bf16_t* Hout = (bf16_t*)p.C;
   bf16_t* GU = (bf16_t*)p.aux;
   const float* bias = p.bias;
@@ -331,6 +335,10 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
         const f32x4& ag = grp(acc, i, il * 4 + j);
         const f32x4& au = grp(acc, i, il * 4 + 2 + j);
         float vg[4] = {ag[0], ag[1], ag[2], ag[3]}, vu[4] = {au[0], au[1], au[2], au[3]};
+        if constexpr (MXOUT) {      // (the e4m3-operand kernel: per-tensor scales arrive as alpha; 1 with block scales)
+#pragma unroll
+          for (int e = 0; e < 4; e++) { vg[e] *= alpha; vu[e] *= alpha; }
+        }
         if (bias) {
 #pragma unroll
           for (int e = 0; e < 4; e++) { vg[e] += bgv[j][e]; vu[e] += buv[j][e]; }
@@ -543,8 +551,10 @@ __device__ __forceinline__ void epi8_f32_slot(AccT<MT>& acc, float* slot, int wm
 // row m = (b, yo, xo) reads pixel (s yo + kh + o, s xo + kw + o), K index (kh * 3 + kw) * C + c.  Inside a kernel row the 3 C channels of the three taps are
 // contiguous, so the K tile base advances by 128 bytes and jumps by (Wp - 3) C elements every 3 C / 64 K tiles; the per-lane part of the address is the
 // pixel offset of the lane's output row, one register per (half-tile, piece) instead of the row * ld product.
-template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false, bool CONV = false>
+// PT (with MX): e4m3 operands with PER-TENSOR scales -- unit block scales (E8M0 127 in every byte, no scale loads), alpha = scale_a * scale_b in the epilogue.
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false, bool CONV = false, bool PT = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
+  static_assert(!PT || MX, "per-tensor scales: the e4m3-operand kernel");
   static_assert(MT == 256 || MT == 320, "tile rows");
   static_assert(!CONV || (!A_KM && !B_KM && MT == 256 && !MX && (EPI == EPI_BF16 || EPI == EPI_F32R)), "implicit-GEMM convolution: row-major operands, 256-row tiles");
   static_assert(EPI != EPI_F32R || (!A_KM && MT == 256), "fp32 + residual epilogue: row-major A, 256-row tiles");
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   };
   // scale dwords of K tile (current + d) into set `set` (inline asm: the compiler must neither count nor wait for these loads)
   auto sload = [&](int set, int d) {
-    if constexpr (MX) {
+    if constexpr (MX && !PT) {
       const int dd = min(d, krem);
       const uint64_t pa = scurA + (uint64_t)(uint32_t)dd * sstepA, pb = scurB + (uint64_t)(uint32_t)dd * sstepB;
       const uint64_t ua = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa);
@@ -706,7 +716,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   };
   // the loads of set `set` have been waited for (counted vmcnt in front of this point): from here on the registers hold the data
   auto spin = [&](int set) {
-    if constexpr (MX) {
+    if constexpr (MX && !PT) {
 #pragma unroll
       for (int k = 0; k < NSC; k++) asm volatile("" : "+v"(sc[set][k]));
     }
@@ -717,12 +727,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       // B bytes: plain -- byte (wc & 1) * 2 + qn of the dword (shift by 16 (wc & 1), op_sel qn); SwiGLU -- byte wc of the gate (qn = 0) / up (qn = 1) dword
       uint32_t sb[2];
 #pragma unroll
-      for (int j = 0; j < 2; j++) sb[j] = EPI == EPI_SWIGLU ? sc[set][2 + 2 * qn + j] >> (8 * wc) : sc[set][2 + j] >> (16 * (wc & 1));
+      for (int j = 0; j < 2; j++) sb[j] = PT ? 0x7f7f7f7fu : EPI == EPI_SWIGLU ? sc[set][2 + 2 * qn + j] >> (8 * wc) : sc[set][2 + j] >> (16 * (wc & 1));
 #pragma unroll
       for (int i = 0; i < FI; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
-          c[i * 2 + j] = mx16_mfma(xb[j], xa[i], c[i * 2 + j], EPI == EPI_SWIGLU ? 0 : qn, (int)sb[j], qm * 2 + (i >> 1), (int)sc[set][i & 1]);
+          c[i * 2 + j] = mx16_mfma(xb[j], xa[i], c[i * 2 + j], EPI == EPI_SWIGLU ? 0 : qn, (int)sb[j], qm * 2 + (i >> 1), PT ? 0x7f7f7f7f : (int)sc[set][i & 1]);
     }
   };
 
@@ -773,7 +783,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       curA = (uint64_t)(uintptr_t)q.A + (uint64_t)((((int64_t)(kh + o) * q.cWp + o) * q.cC) * 2) + (uint64_t)within * 128;
       cseg_left = cseg_len - within;
     }
-    if constexpr (MX) {
+    if constexpr (MX && !PT) {
       // scale bytes of (row, K half) at ((half * rows_pad + (row & ~127)) * 2 + (row & 31) * 8 + (blk & 1) * 4 + ((row >> 5) & 3): mx_scale_index
       const int64_t padA = ((int64_t)q.M + 127) & ~(int64_t)127, padB = ((int64_t)q.N + 127) & ~(int64_t)127;
       sstepA = (uint64_t)padA * 4; sstepB = (uint64_t)padB * 4;                 // two 64-wide halves per K tile
@@ -832,7 +842,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   };
   auto next_ktile = [&]() {
     curA += stepA; curB += stepB; krem--;
-    if constexpr (MX) { scurA += sstepA; scurB += sstepB; }
+    if constexpr (MX && !PT) { scurA += sstepA; scurB += sstepB; }
     if constexpr (CONV) { if (--cseg_left == 0) { curA += cjump; cseg_left = cseg_len; } }
   };
   // Two schedules.  KEEP (256 rows): B0 stays in registers from P1 to P4; stagings P1(t): A1(t+1), P2(t): A0(t+2), P3(t): B0(t+2), P4(t): B1(t+2);
@@ -1001,8 +1011,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 #ifdef MMDIT_PROBES
   if (gp.debug & 8) { if (acc.a[0][0][0][0] == 12345.f) ((float*)q.C)[0] = 1.f; return; }      // ablation (MMDIT_GEMM_DEBUG=8): no epilogue
 #endif
-  if constexpr (EPI == EPI_BF16) epi8_bf16<MT>(acc, q, gp, m0, n0, wr, wc, lane, stage);
-  else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT, MX>(acc, q, m0, it.tn, wr, wc, lane, stage);
+  float alpha = 1.f;
+  if constexpr (PT) alpha = q.scale_a[0] * q.scale_b[0];      // e4m3 operands with per-tensor scales (device scalars)
+  if constexpr (EPI == EPI_BF16) epi8_bf16<MT, MX>(acc, q, gp, m0, n0, wr, wc, lane, stage, alpha);
+  else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT, MX>(acc, q, m0, it.tn, wr, wc, lane, stage, alpha);
   else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[it.pi & 1], m0, n0, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_SWIGLU_BWD) epi8_swiglu_bwd<MT>(acc, q, m0, n0, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_F32R) epi8_f32r<MT>(acc, q, m0, n0, wr, wc, lane, stage);
@@ -1183,9 +1195,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   if (DEFER && pending) run_epilogue(prev);
 }
 
-template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false, bool CONV = false>
+template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false, bool CONV = false, bool PT = false>
 int launch8(const GroupParams& gp, hipStream_t s) {
-  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI, KT, MX, CONV>;
+  auto k = gemm8_kernel<MT, A_KM, B_KM, EPI, KT, MX, CONV, PT>;
   constexpr int smem = Geo<MT>::SMEM;
   static unsigned long long attr_done = 0;   // one bit per device
   if (!mmdit_device_once(attr_done)) {
@@ -1200,10 +1212,11 @@ int launch8(const GroupParams& gp, hipStream_t s) {
 }
 
 template <int MT>
-int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s) {
-  if (gp.mx) {         // e4m3 operands with E8M0 block scales (inference): 256-row tiles, row-major weight, bf16 output or the SwiGLU epilogue
+int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s, bool fp8 = false) {
+  if (fp8) {           // e4m3 operands, E8M0 block scales (gp.mx) or per-tensor scales (inference): 256-row tiles, row-major weight, bf16 output or the SwiGLU epilogue
     if constexpr (MT == 256) {
       if (b_km || gp.qk_on || gp.act == MMDIT_ACT_SWIGLU_BWD || gp.act == MMDIT_ACT_SILU) return MMDIT_ERR_ARG;
+      if (!gp.mx) return gp.act == MMDIT_ACT_SWIGLU ? launch8<MT, false, false, EPI_SWIGLU, false, true, false, true>(gp, s) : launch8<MT, false, false, EPI_BF16, false, true, false, true>(gp, s);
       return gp.act == MMDIT_ACT_SWIGLU ? launch8<MT, false, false, EPI_SWIGLU, false, true>(gp, s) : launch8<MT, false, false, EPI_BF16, false, true>(gp, s);
     } else return MMDIT_ERR_SHAPE;
   }
@@ -1228,7 +1241,8 @@ int gemm::launch_gemm8_conv(bool f32_out, const GroupParams& gp, hipStream_t s) 
   return f32_out ? launch8<256, false, false, EPI_F32R, false, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, false, true>(gp, s);
 }
 
-int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s, bool ktail) {
+int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s, bool ktail, bool fp8) {
+  if (fp8) return cfg == CFG_256x256 && !a_km && !ktail ? launch8_bf16<256>(b_km, gp, s, true) : MMDIT_ERR_ARG;
   if (a_km) {
     if (!b_km || cfg != CFG_256x256) return MMDIT_ERR_ARG;
     return ktail ? launch8<256, true, true, EPI_F32, true>(gp, s) : launch8<256, true, true, EPI_F32>(gp, s);
