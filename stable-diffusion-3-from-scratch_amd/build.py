@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmmdit_hip.so")
 HEADER = os.path.join(HERE, "..", "include", "mmdit_hip.h")
-SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_lean.hip", "gemm8p.hip", "rowops.hip", "attention.hip", "vae.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_dma.hip", "gemm_lean.hip", "gemm8p.hip", "gemm8p_inf.hip", "rowops.hip", "attention.hip", "vae.hip", "optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("MMDIT_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -38,6 +38,8 @@ def _read(path):
 def source_hash(src):
     """Content hash of everything object `src` depends on."""
     headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [HEADER]
+    if src == "gemm8p_inf.hip":
+        headers.append(os.path.join(CSRC, "gemm8p.hip"))      # (it is that file, compiled with MMDIT_G8_PART 2)
     return _sha([os.path.join(CSRC, src)] + headers, " ".join([HIPCC] + FLAGS))
 
 
@@ -56,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             f.write(want[src])
         return obj, True
 
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         res = list(ex.map(cc, SOURCES))
     objs = [o for o, _ in res]
     libsha = hashlib.sha256("".join(want[s] for s in SOURCES).encode()).hexdigest()

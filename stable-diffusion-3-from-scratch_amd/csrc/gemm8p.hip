@@ -1211,15 +1211,30 @@ int launch8(const GroupParams& gp, hipStream_t s) {
   return mmdit_launch_status();
 }
 
+// The instantiations are split over two translation units (the file is compiled twice: gemm8p.hip = the training kernels, gemm8p_inf.hip = this file with
+// MMDIT_G8_PART 2 = the e4m3-operand and convolution kernels of the inference / VAE paths), so that the two halves compile in parallel.
+#ifndef MMDIT_G8_PART
+#define MMDIT_G8_PART 1
+#endif
+
+#if MMDIT_G8_PART == 2
+// e4m3 operands, E8M0 block scales (gp.mx) or per-tensor scales (inference): 256-row tiles, row-major weight, bf16 output or the SwiGLU epilogue
+}  // namespace
+int gemm::launch_gemm8_fp8(bool b_km, const GroupParams& gp, hipStream_t s) {
+  if (b_km || gp.qk_on || gp.act == MMDIT_ACT_SWIGLU_BWD || gp.act == MMDIT_ACT_SILU) return MMDIT_ERR_ARG;
+  if (!gp.mx) return gp.act == MMDIT_ACT_SWIGLU ? launch8<256, false, false, EPI_SWIGLU, false, true, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, true, false, true>(gp, s);
+  return gp.act == MMDIT_ACT_SWIGLU ? launch8<256, false, false, EPI_SWIGLU, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, true>(gp, s);
+}
+
+// implicit-GEMM 3 x 3 convolution (every problem of the launch has conv_mode != 0), 256 x 256 tiles: bf16 output (+ bias / SiLU) or fp32 output + bias + residual
+int gemm::launch_gemm8_conv(bool f32_out, const GroupParams& gp, hipStream_t s) {
+  return f32_out ? launch8<256, false, false, EPI_F32R, false, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, false, true>(gp, s);
+}
+
+#else
+
 template <int MT>
-int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s, bool fp8 = false) {
-  if (fp8) {           // e4m3 operands, E8M0 block scales (gp.mx) or per-tensor scales (inference): 256-row tiles, row-major weight, bf16 output or the SwiGLU epilogue
-    if constexpr (MT == 256) {
-      if (b_km || gp.qk_on || gp.act == MMDIT_ACT_SWIGLU_BWD || gp.act == MMDIT_ACT_SILU) return MMDIT_ERR_ARG;
-      if (!gp.mx) return gp.act == MMDIT_ACT_SWIGLU ? launch8<MT, false, false, EPI_SWIGLU, false, true, false, true>(gp, s) : launch8<MT, false, false, EPI_BF16, false, true, false, true>(gp, s);
-      return gp.act == MMDIT_ACT_SWIGLU ? launch8<MT, false, false, EPI_SWIGLU, false, true>(gp, s) : launch8<MT, false, false, EPI_BF16, false, true>(gp, s);
-    } else return MMDIT_ERR_SHAPE;
-  }
+int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s) {
   if (gp.qk_on) {      // (at 320 rows the QKV epilogue does not fit the register budget without spills in the K loop: gemm.hip keeps that launch on the wide kernel)
     if constexpr (MT == 256) return b_km ? MMDIT_ERR_ARG : launch8<MT, false, false, EPI_QK>(gp, s);
     else return MMDIT_ERR_SHAPE;
@@ -1235,14 +1250,9 @@ int launch8_bf16(bool b_km, const GroupParams& gp, hipStream_t s, bool fp8 = fal
 }  // namespace
 
 // MT x 256 tiles (cfg CFG_256x256 or CFG_320x256).  a_km && b_km: fp32 weight gradients (256 rows; the K-decomposed schedule of gemm.hip);
-// otherwise bf16 output with the bias / SiLU, SwiGLU (gp.act) or QKV (gp.qk_on) epilogue.  gemm.hip has checked the rest.
-// implicit-GEMM 3 x 3 convolution (every problem of the launch has conv_mode != 0), 256 x 256 tiles: bf16 output (+ bias / SiLU) or fp32 output + bias + residual
-int gemm::launch_gemm8_conv(bool f32_out, const GroupParams& gp, hipStream_t s) {
-  return f32_out ? launch8<256, false, false, EPI_F32R, false, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, false, true>(gp, s);
-}
-
+// otherwise bf16 output with the bias / SiLU, SwiGLU (gp.act) or QKV (gp.qk_on) epilogue; fp8: the e4m3-operand kernels of gemm8p_inf.hip.  gemm.hip has checked the rest.
 int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s, bool ktail, bool fp8) {
-  if (fp8) return cfg == CFG_256x256 && !a_km && !ktail ? launch8_bf16<256>(b_km, gp, s, true) : MMDIT_ERR_ARG;
+  if (fp8) return cfg == CFG_256x256 && !a_km && !ktail ? launch_gemm8_fp8(b_km, gp, s) : MMDIT_ERR_ARG;
   if (a_km) {
     if (!b_km || cfg != CFG_256x256) return MMDIT_ERR_ARG;
     return ktail ? launch8<256, true, true, EPI_F32, true>(gp, s) : launch8<256, true, true, EPI_F32>(gp, s);
@@ -1252,3 +1262,4 @@ int gemm::launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hip
   if (cfg == CFG_256x256) return launch8_bf16<256>(b_km, gp, s);
   return MMDIT_ERR_ARG;
 }
+#endif

@@ -255,6 +255,7 @@ int launch_dma(int cfg, bool a_km, bool b_km, int c_dtype, int aux_dtype, bool f
 int launch_lean_cfg(int cfg, bool b_km, const GroupParams& gp, hipStream_t s);
 int launch_lean_wgrad(const GroupParams& gp, hipStream_t s);   // gemm_lean.hip: k-major x k-major -> fp32, 256x256, K-decomposed schedule
 // gemm8p.hip: the de-phased 8-phase main loop on 256x256 tiles (16x16x32 MFMA): every launch the lean kernels take at that tile size
+int launch_gemm8_fp8(bool b_km, const GroupParams& gp, hipStream_t s);       // gemm8p_inf.hip: e4m3 operands (gp.mx: E8M0 block scales, else per-tensor), 256x256 tiles
 int launch_gemm8_conv(bool f32_out, const GroupParams& gp, hipStream_t s);   // gemm8p.hip CONV: implicit-GEMM 3x3 convolution, 256x256 tiles, bf16 (+ bias) or fp32 (+ bias + residual) output
 int launch_gemm8(int cfg, bool a_km, bool b_km, const GroupParams& gp, hipStream_t s, bool ktail = false, bool fp8 = false);   // ktail: some weight-gradient K is not a multiple of 64   // cfg: CFG_256x256 / CFG_320x256 (bf16 outputs only)
 

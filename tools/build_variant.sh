@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 name=$1; shift
 out=tools/scratch/$name
 mkdir -p $out
-for f in gemm gemm_dma gemm_lean gemm8p rowops attention vae optim; do
+for f in gemm gemm_dma gemm_lean gemm8p gemm8p_inf rowops attention vae optim; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c stable-diffusion-3-from-scratch_amd/csrc/$f.hip -o $out/$f.o 2>/dev/null &
 done
 wait

@@ -10,7 +10,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "stable-diffusion-3-from-scratch_amd", "csrc", "gemm8p.hip")
+SRCS = [os.path.join(ROOT, "stable-diffusion-3-from-scratch_amd", "csrc", f) for f in ("gemm8p.hip", "gemm8p_inf.hip")]      # the two translation units of the kernel
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")      # (the variable build.py honours)
 NO_COMPILER = 77                                            # exit code: hipcc not found (callers skip)
 
@@ -20,13 +20,16 @@ def main():
     if shutil.which(HIPCC) is None:
         print(f"check_spills: compiler {HIPCC!r} not found (set HIPCC)", file=sys.stderr)
         return NO_COMPILER
-    with tempfile.TemporaryDirectory() as td:
-        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps"] + sys.argv[1:] + ["-c", SRC, "-o", os.path.join(td, "o.o")],
-                           cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-        if r.returncode != 0:
-            print(r.stderr[-4000:], file=sys.stderr)
-            return 2
-        asm = open(os.path.join(td, "gemm8p-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
+    asm = []
+    for src in SRCS:
+        stem = os.path.basename(src)[:-4]
+        with tempfile.TemporaryDirectory() as td:
+            r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-save-temps"] + sys.argv[1:] + ["-c", src, "-o", os.path.join(td, "o.o")],
+                               cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                print(r.stderr[-4000:], file=sys.stderr)
+                return 2
+            asm += open(os.path.join(td, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
     bad, kernels = [], 0
     i = 0
     while i < len(asm):
