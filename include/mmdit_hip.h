@@ -59,7 +59,7 @@ typedef void* mmdit_stream_t;   /* hipStream_t */
  * (MMDIT_LIB=...) with another layout fails loudly instead of reading past a struct.  mmdit_struct_size(which): sizeof of
  * 0 mmdit_gemm_args, 1 mmdit_ln_fwd_problem, 2 mmdit_ln_bwd_problem, 3 mmdit_qk_problem, 4 mmdit_mlp_bwd_problem,
  * 5 mmdit_adamw_tensor, 6 mmdit_cast_tensor, 7 mmdit_qk_epilogue; -1 for an unknown id. */
-#define MMDIT_ABI_VERSION 6
+#define MMDIT_ABI_VERSION 7
 int mmdit_abi_version(void);
 int mmdit_struct_size(int which);
 const char* mmdit_build_arch(void);
@@ -157,6 +157,15 @@ int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogu
  * needs more slots than fit falls back to atomics.  One workspace per process: launches that use it must be stream-ordered.
  * ptr = NULL, bytes = 0 removes it.  The library never allocates. */
 int mmdit_gemm_set_workspace(void* ptr, long long bytes);
+/* Compute units the GEMM launches may count on (default: all 256 of an MI355X).  The persistent GEMM kernels launch ONE workgroup per CU and size
+ * their rounds / tile configuration for that number; a workgroup needs a whole CU (160 KiB of LDS), so while another kernel -- RCCL's collectives on the
+ * reducer's side stream -- holds C compute units, a 256-workgroup launch runs as two rounds (measured with a stand-in kernel on 8 CUs: step 28.2 -> 36.4 ms,
+ * tools/probes/cu_contention.py).  With a budget of 256 - C the planner and every persistent grid use 256 - C instead and the collectives' workgroups find
+ * free CUs.  The reference has no counterpart (DDP leaves the split to the CUDA scheduler, model_trainer.py:224); model_trainer sets it when gradients are
+ * reduced over more than one rank.  n: a multiple of 8 in [64, 256] (the XCD round-robin stays even); per device (hipSetDevice first); takes effect with the
+ * next launch -- change it only while no captured graph of earlier launches is replayed. */
+int mmdit_set_cu_budget(int n);
+int mmdit_get_cu_budget(void);
 /* Which kernel mmdit_gemm_grouped would launch for these problems (no launch): 64 = register-staged kernel (gemm.hip);
  * otherwise the LDS-DMA kernel (gemm_dma.hip) with tile configuration (value & 15): 0 = 128x128, 1 = 256x128,
  * 2 = 256x256, 3 = 320x256 (lean kernel only), plus 16 if the stream-K decomposition is used, plus 32 for the full-rounds +

@@ -256,6 +256,14 @@ int check_problem(const mmdit_gemm_args* a) {
 //  seen by another)
 static void* g_ws[64] = {};
 static long long g_ws_bytes[64] = {};
+// compute units the persistent launches may count on, per device (0 = not set: all 256); mmdit_set_cu_budget
+static int g_cu_budget[64] = {};
+extern "C" int mmdit_get_cu_budget(void) { const int n = g_cu_budget[mmdit_current_device()]; return n ? n : 256; }
+extern "C" int mmdit_set_cu_budget(int n) {
+  MMDIT_CHECK_ARG(n >= 64 && n <= 256 && n % 8 == 0);
+  g_cu_budget[mmdit_current_device()] = n;
+  return 0;
+}
 
 static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, bool stream_k, bool lean_ok) {
   static const char* force = mmdit_exp_env("MMDIT_GEMM_CFG");
@@ -277,12 +285,13 @@ static int pick_dma_cfg(const mmdit_gemm_args* args, int count, int split_k, boo
   const bool mx8 = args[0].a_dtype == MMDIT_FP8 && args[0].K % 128 == 0 && !args[0].gate && !args[0].residual && !args[0].aux &&
                    (args[0].c_dtype == MMDIT_BF16 || args[0].act == MMDIT_ACT_SWIGLU);
   const double r256 = mx8 ? 1.2 : args[0].a_dtype == MMDIT_FP8 ? 1.67 : 1.58;
-  const double c128 = (double)((t128 * split_k + 511) / 512), c256 = r256 * (double)((t256 * split_k + 255) / 256);
+  const long cu = mmdit_get_cu_budget();
+  const double c128 = (double)((t128 * split_k + 2 * cu - 1) / (2 * cu)), c256 = r256 * (double)((t256 * split_k + cu - 1) / cu);
   if (lean_ok) {
     // 320x256 tiles (lean kernel): a round costs 1.25x a 256x256 round (tile area); MMDiT-B's N = 768 GEMMs at batch 64 fit ONE round
     long t320 = 0;
     for (int i = 0; i < count; i++) t320 += (long)((args[i].M + 319) / 320) * ((args[i].N + 255) / 256);
-    const double c320 = 1.25 * 1.58 * (double)((t320 + 255) / 256);
+    const double c320 = 1.25 * 1.58 * (double)((t320 + cu - 1) / cu);
     if (c320 < c256 && c320 < c128) return CFG_320x256;
   }
   return c256 < c128 ? CFG_256x256 : CFG_128x128;
@@ -447,7 +456,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   if (stream_k && !kdec_streamk) {
     gp.stream_k = 0;
     tail_mode = true;
-    const int G = 256 * (cfg == CFG_128x128 ? 2 : 1), r = tiles % G;
+    const int G = mmdit_get_cu_budget() * (cfg == CFG_128x128 ? 2 : 1), r = tiles % G;
     int nk_min = 1 << 30;
     for (int i = 0; i < count; i++) nk_min = gp.p[i].nk < nk_min ? gp.p[i].nk : nk_min;
     full_tiles = tiles - r;

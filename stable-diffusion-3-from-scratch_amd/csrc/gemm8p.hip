@@ -1206,7 +1206,8 @@ int launch8(const GroupParams& gp, hipStream_t s) {
     mmdit_device_mark(attr_done);
   }
   const int work = total_work(gp);
-  const int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
+  const int cu = mmdit_get_cu_budget();
+  const int grid = gp.persistent && work > cu ? cu : work;   // one persistent workgroup per CU (of the budget)
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gp);
   return mmdit_launch_status();
 }

@@ -382,7 +382,7 @@ int launch_cfg(const GroupParams& gp, hipStream_t s) {
     mmdit_device_mark(attr_done);
   }
   // one resident workgroup per slot (256 CUs x workgroups that fit per CU by LDS)
-  const int slots = 256 * (smem <= 80 * 1024 ? 2 : 1);
+  const int slots = mmdit_get_cu_budget() * (smem <= 80 * 1024 ? 2 : 1);
   const int work = total_work(gp);
   const int grid = gp.stream_k ? slots : (gp.persistent && work > slots ? slots : work);
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);

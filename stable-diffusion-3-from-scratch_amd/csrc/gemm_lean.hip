@@ -216,7 +216,8 @@ int launch_lean(const GroupParams& gp, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     mmdit_device_mark(attr_done);
   }
-  const int grid = gp.total_tiles < 256 ? gp.total_tiles : 256;   // one persistent workgroup per CU
+  const int cu = mmdit_get_cu_budget();
+  const int grid = gp.total_tiles < cu ? gp.total_tiles : cu;   // one persistent workgroup per CU (of the budget)
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);
   return mmdit_launch_status();
 }
@@ -404,7 +405,8 @@ int launch_wide(const GroupParams& gp, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     mmdit_device_mark(attr_done);
   }
-  const int grid = gp.total_tiles < 256 ? gp.total_tiles : 256;   // one persistent workgroup per CU
+  const int cu = mmdit_get_cu_budget();
+  const int grid = gp.total_tiles < cu ? gp.total_tiles : cu;   // one persistent workgroup per CU (of the budget)
   hipLaunchKernelGGL(k, dim3(grid), dim3(64 * WM * WN), smem, s, gp);
   return mmdit_launch_status();
 }
@@ -723,7 +725,8 @@ int launch_kk(const GroupParams& gp, hipStream_t s) {
     mmdit_device_mark(attr_done);
   }
   const int work = total_work(gp);
-  int grid = gp.persistent && work > 256 ? 256 : work;   // one persistent workgroup per CU
+  const int cu = mmdit_get_cu_budget();
+  int grid = gp.persistent && work > cu ? cu : work;   // one persistent workgroup per CU (of the budget)
   // experiments (MMDIT_WGRAD_STREAM=1): leave CUs to the kernels of the main stream; only without the balanced tail (MMDIT_GEMM_KDEC=plain),
   // whose unit -> workgroup map is built for 256 workgroups
   static const char* g_env = mmdit_exp_env("MMDIT_GEMM_KK_GRID");

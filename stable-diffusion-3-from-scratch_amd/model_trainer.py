@@ -162,6 +162,16 @@ class model_trainer:
         broadcast_parameters(self.model)
         self.reducer = GradReducer(self.subgroup, force=force_reducer)
         if self.reducer.enabled:
+            # Compute units left to the collectives' kernels (MMDIT_RESERVED_CUS, default 0 = none): the persistent GEMM launches assume one
+            # workgroup per CU on all 256 and a workgroup needs a whole CU, so while RCCL's channels hold C of them such a launch runs as TWO
+            # rounds.  Measured with a stand-in kernel that holds C CUs for the whole step (tools/probes/cu_contention.py, MMDiT-B batch 64):
+            # C = 8: 27.1 -> 34.8 ms, 30.7 ms with the GEMM grids capped at 248; C = 16: 33.7 / 31.6; C = 32: 33.7 / 32.2.  How many CUs RCCL's
+            # all-reduce takes on an 8-GPU xGMI node (and for how much of the backward) could not be measured here -- set it together with
+            # NCCL_MAX_NCHANNELS on real hardware.  Takes effect with the next launch; must not change once a step has been captured.
+            reserved = int(os.environ.get("MMDIT_RESERVED_CUS", "0"))
+            if reserved > 0 and self.device.type == "cuda":
+                from . import _lib
+                _lib.check(_lib.lib().mmdit_set_cu_budget(max(64, (256 - reserved) // 8 * 8)), "mmdit_set_cu_budget")
             if hasattr(self.model, "grad_reducer"):
                 self.model.grad_reducer = self.reducer           # overlapped: fired from the backward schedule
             else:

@@ -839,6 +839,36 @@ def test_gemm_block_wgrads_balanced_tail(ops):
             assert rel(o, r) < 5e-5
 
 
+@pytest.mark.parametrize("budget", [248, 224, 64])
+def test_gemm_cu_budget(ops, budget):
+    """mmdit_set_cu_budget (data parallel: compute units left to the collectives' kernels): the planner and every persistent grid count on `budget`
+    CUs instead of 256.  The results do not depend on it: a forward launch (bit-identical: same tiles, same K order), the SwiGLU-fused launch, and a
+    block's eight weight gradients (round + balanced split tail, whose decomposition follows the budget: compared with the fp32 reference)."""
+    from sd3_amd import _lib
+    L = _lib.lib()
+    assert L.mmdit_get_cu_budget() == 256
+    M, d, h = 26240, 768, 3072
+    A, W, W12, b12 = rnd(M, d, seed=1, dtype=torch.bfloat16), rnd(3 * d, d, seed=2, dtype=torch.bfloat16), rnd(2 * h, d, seed=3, dtype=torch.bfloat16), rnd(2 * h, seed=4)
+    y0 = ops.gemm(A, W, out_dtype=torch.bfloat16)
+    h0 = ops.gemm(A, W12, bias=b12, act=ops.ACT_SWIGLU)
+    probs, refs = [], []
+    for i, (N, K) in enumerate([(3 * d, d), (d, d), (2 * h, d), (d, h)]):
+        for Mr in (16384, 9856):
+            dY, X = rnd(Mr, N, seed=60 + 2 * i + (Mr == 9856), dtype=torch.bfloat16), rnd(Mr, K, seed=80 + 2 * i + (Mr == 9856), dtype=torch.bfloat16)
+            probs.append(dict(A=dY, B=X, a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
+            refs.append(dY.float().T @ X.float())
+    try:
+        assert L.mmdit_set_cu_budget(250) != 0 and L.mmdit_set_cu_budget(32) != 0      # a multiple of 8 in [64, 256]
+        assert L.mmdit_set_cu_budget(budget) == 0 and L.mmdit_get_cu_budget() == budget
+        assert torch.equal(ops.gemm(A, W, out_dtype=torch.bfloat16), y0)
+        assert torch.equal(ops.gemm(A, W12, bias=b12, act=ops.ACT_SWIGLU), h0)
+        for _ in range(2):
+            for o, r in zip(ops.gemm_grouped(probs), refs):
+                assert rel(o, r) < 5e-5
+    finally:
+        assert L.mmdit_set_cu_budget(256) == 0
+
+
 @pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16)])
 def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
     """fp8 (e4m3, per-tensor scale) operand GEMM of the inference path vs the same quantised values multiplied in fp32."""
