@@ -409,6 +409,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     cfg = pick_dma_cfg(args, count, split_k, stream_k, lean_ok);
     if (swiglu && cfg != CFG_320x256) cfg = CFG_256x256;   // the activation pairs gate / up columns inside a 256-column tile
     if (swiglu_bwd) cfg = CFG_256x256;                     // (the fused backward epilogue exists at 256 rows)
+    if (qkr && fp8) cfg = CFG_256x256;                     // (MX operands + the QKV epilogue: the 8-phase kernel's 256-row tile)
     dma_cfg_tile(cfg, bm, bn);
   }
   const bool lean = lean_ok && (cfg == CFG_320x256 || (cfg == CFG_256x256 && lean_mode == 1));
@@ -525,7 +526,9 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   gp.qk_on = 0; gp.qkQ = gp.qkK = gp.qkV = nullptr; gp.qk_heads = 0; gp.qk_s_total = 0;
   if (qkr) {
     // the fused QKV epilogue exists in the wide-slot lean kernel only, for one or two streams in the caller's order, [q | k | v] columns
-    if (!lean || count > 2 || a0->act != MMDIT_ACT_NONE || a0->b_kmajor) return MMDIT_ERR_SHAPE;
+    // (round 5: ... and, for MX e4m3 operands, in the 8-phase kernel at 256 rows)
+    const bool mxqk = dma && fp8 && gp.mx && cfg == CFG_256x256 && !a0->a_kmajor && a0->c_dtype == MMDIT_BF16;
+    if (!(lean || mxqk) || count > 2 || a0->act != MMDIT_ACT_NONE || a0->b_kmajor) return MMDIT_ERR_SHAPE;
     for (int i = 0; i < count; i++) {
       if (order[i] != i || args[i].bias || args[i].N != 3 * qkr->heads * 64 || qkr->qk[i].tokens <= 0 || args[i].M % qkr->qk[i].tokens) return MMDIT_ERR_SHAPE;
       gp.qk[i].wq = qkr->qk[i].wq; gp.qk[i].wk = qkr->qk[i].wk;
@@ -561,7 +564,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   // (the QKV launch with the QK-norm / RoPE epilogue stays on the wide kernel at 320 rows: with that epilogue's registers the 320-row 8-phase
   //  variant measured slower, 1.73 vs 1.59 ms per step)
   // e4m3 operands (E8M0 block scales or per-tensor scales) on the 8-phase loop: 256 x 256 tiles, bf16 output (bias allowed) or the SwiGLU epilogue (bf16 or MX output)
-  bool mx8 = p8_mode > 0 && dma && fp8 && cfg == CFG_256x256 && !qkr && !stream_k && split_k == 1 && (a0->act == MMDIT_ACT_NONE || swiglu) && !a0->accumulate;
+  bool mx8 = p8_mode > 0 && dma && fp8 && cfg == CFG_256x256 && (!qkr || gp.mx) && !stream_k && split_k == 1 && (a0->act == MMDIT_ACT_NONE || swiglu) && !a0->accumulate;
   for (int i = 0; i < count && mx8; i++) {
     const mmdit_gemm_args* a = &args[i];
     mx8 = (a->c_dtype == MMDIT_BF16 || (swiglu && a->c_dtype == MMDIT_FP8)) && (!a->aux || (swiglu && a->c_dtype == MMDIT_BF16)) && !a->gate && !a->residual && a->K % 128 == 0 &&

@@ -558,7 +558,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   static_assert(MT == 256 || MT == 320, "tile rows");
   static_assert(!CONV || (!A_KM && !B_KM && MT == 256 && !MX && (EPI == EPI_BF16 || EPI == EPI_F32R)), "implicit-GEMM convolution: row-major operands, 256-row tiles");
   static_assert(EPI != EPI_F32R || (!A_KM && MT == 256), "fp32 + residual epilogue: row-major A, 256-row tiles");
-  static_assert(!MX || (!A_KM && !B_KM && MT == 256 && (EPI == EPI_BF16 || EPI == EPI_SWIGLU)), "MX: row-major e4m3 operands, 256-row tiles, bf16 / SwiGLU epilogue");
+  static_assert(!MX || (!A_KM && !B_KM && MT == 256 && (EPI == EPI_BF16 || EPI == EPI_SWIGLU || EPI == EPI_QK)), "MX: row-major e4m3 operands, 256-row tiles, bf16 / SwiGLU / QKV epilogue");
   static_assert(!KT || (A_KM && B_KM && EPI == EPI_F32), "K tail: the weight-gradient kernel");
   static_assert(EPI == EPI_F32 ? (A_KM && B_KM && MT == 256) : !A_KM, "fp32 epilogue = weight gradients (both operands k-major, 256 rows); bf16 epilogues take a row-major A");
   static_assert(!(EPI == EPI_SWIGLU || EPI == EPI_QK) || !B_KM, "fused epilogues: row-major weight");
@@ -1222,7 +1222,8 @@ int launch8(const GroupParams& gp, hipStream_t s) {
 // e4m3 operands, E8M0 block scales (gp.mx) or per-tensor scales (inference): 256-row tiles, row-major weight, bf16 output or the SwiGLU epilogue
 }  // namespace
 int gemm::launch_gemm8_fp8(bool b_km, const GroupParams& gp, hipStream_t s) {
-  if (b_km || gp.qk_on || gp.act == MMDIT_ACT_SWIGLU_BWD || gp.act == MMDIT_ACT_SILU) return MMDIT_ERR_ARG;
+  if (b_km || gp.act == MMDIT_ACT_SWIGLU_BWD || gp.act == MMDIT_ACT_SILU) return MMDIT_ERR_ARG;
+  if (gp.qk_on) return gp.mx && gp.act == MMDIT_ACT_NONE ? launch8<256, false, false, EPI_QK, false, true>(gp, s) : MMDIT_ERR_ARG;      // QKV projection + QK-norm / RoPE epilogue
   if (!gp.mx) return gp.act == MMDIT_ACT_SWIGLU ? launch8<256, false, false, EPI_SWIGLU, false, true, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, true, false, true>(gp, s);
   return gp.act == MMDIT_ACT_SWIGLU ? launch8<256, false, false, EPI_SWIGLU, false, true>(gp, s) : launch8<256, false, false, EPI_BF16, false, true>(gp, s);
 }

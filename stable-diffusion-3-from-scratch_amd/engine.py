@@ -346,11 +346,15 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
     sv.Q = torch.empty((B, H, S, 64), dtype=BF16, device=dev)
     sv.K, sv.V = torch.empty_like(sv.Q), torch.empty_like(sv.Q)
     fused = None
-    if _QKV_FUSE and m.fast and dev.type == "cuda" and m.T == BF16 and not m.fp8 and d == H * 64:
+    if _QKV_FUSE and m.fast and dev.type == "cuda" and m.T == BF16 and (not m.fp8 or mxf) and d == H * 64:
         # QK-norm + RoPE + joint-layout store in the QKV GEMM's epilogue (one launch, no second pass over the raw projection); None: the
-        # planner would not give these problems to the lean wide-slot kernel
-        fused = ops.gemm_qkv_norm_rope([dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T, precision=m.prec), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T, precision=m.prec)],
-                                       [(w.wq_x, w.wk_x, rope[0], rope[1], N, 0), (w.wq_c, w.wk_c, None, None, Mt, N)], H, S, sv.Q, sv.K, sv.V)
+        # planner would not give these problems to a kernel with that epilogue (bf16: the lean wide-slot kernel; MX operands: the 8-phase kernel)
+        qp = [dict(A=sv.ln1x, B=w.Wqkv_x, out_dtype=m.T, precision=m.prec), dict(A=sv.ln1c, B=w.Wqkv_c, out_dtype=m.T, precision=m.prec)]
+        if mxf:
+            qq = [_to_fp8(m, p) for p in qp]
+            qp = qq if all(x is not p for x, p in zip(qq, qp)) else None
+        if qp is not None:
+            fused = ops.gemm_qkv_norm_rope(qp, [(w.wq_x, w.wk_x, rope[0], rope[1], N, 0), (w.wq_c, w.wk_c, None, None, Mt, N)], H, S, sv.Q, sv.K, sv.V)
     if fused is not None:
         sv.qkv_x, sv.qkv_c = fused
     else:

@@ -662,6 +662,34 @@ def test_gemm_qkv_epilogue_with_qk_norm_rope_equals_gemm_plus_row_kernel(ops, Bt
     assert rel(Q1, torch.cat([qx, qc], 2)) < 6e-3 and rel(K1, torch.cat([kx, kc], 2)) < 6e-3 and rel(V1, torch.cat([vx, vc], 2)) < 6e-3
 
 
+@pytest.mark.parametrize("Bt,H,h2,w2,Mt,K", [(16, 16, 32, 32, 154, 1024), (8, 12, 16, 16, 154, 768)])
+def test_gemm_qkv_epilogue_on_mx_operands_equals_gemm_plus_row_kernel(ops, Bt, H, h2, w2, Mt, K):
+    """The same fusion on MX e4m3 operands (mxfp8 inference: the QKV projection of the 8-phase MX kernel with the QK-norm / RoPE epilogue) against
+    the MX GEMM followed by mmdit_qk_norm_rope_fwd_pair: raw q / k columns bit-identical, Q / K / V up to instruction selection."""
+    N = h2 * w2
+    S, d = N + Mt, H * 64
+    cos, sin = _rope_tables(h2, w2)
+    wqx, wkx, wqc, wkc = (1 + 0.1 * rnd(64, seed=i) for i in (1, 2, 3, 4))
+    X, C = rnd(Bt * N, K, seed=5, dtype=torch.bfloat16), rnd(Bt * Mt, K, seed=6, dtype=torch.bfloat16)
+    Wx, Wc = rnd(3 * d, K, seed=7, scale=0.05, dtype=torch.bfloat16), rnd(3 * d, K, seed=8, scale=0.05, dtype=torch.bfloat16)
+    (qx, sx), (qc, sc), (qwx, swx), (qwc, swc) = (ops.quant_mxfp8(t) for t in (X, C, Wx, Wc))
+    probs = lambda: [dict(A=qx, B=qwx, out_dtype=torch.bfloat16, scale_a=sx, scale_b=swx, scale_mode=1), dict(A=qc, B=qwc, out_dtype=torch.bfloat16, scale_a=sc, scale_b=swc, scale_mode=1)]
+    qkv_x, qkv_c = ops.gemm_grouped(probs())
+    Q2 = torch.zeros((Bt, H, S, 64), dtype=torch.bfloat16, device="cuda")
+    K2, V2 = torch.zeros_like(Q2), torch.zeros_like(Q2)
+    ops.qk_norm_rope_fwd_pair((qkv_x, wqx, wkx, cos, sin, N, 0), (qkv_c, wqc, wkc, None, None, Mt, N), Bt, H, S, Q2, K2, V2)
+    Q1 = torch.full((Bt, H, S, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    K1, V1 = Q1.clone(), Q1.clone()
+    raw = ops.gemm_qkv_norm_rope(probs(), [(wqx, wkx, cos, sin, N, 0), (wqc, wkc, None, None, Mt, N)], H, S, Q1, K1, V1)
+    assert raw is not None, "MX operands at the MMDiT block shapes must take the fused path"
+    assert torch.equal(raw[0][:, :2 * d], qkv_x[:, :2 * d]) and torch.equal(raw[1][:, :2 * d], qkv_c[:, :2 * d])
+    for a, b_, name in ((Q1, Q2, "Q"), (K1, K2, "K"), (V1, V2, "V")):
+        assert torch.isfinite(a.float()).all(), name
+        frac = float((a.view(torch.int16) != b_.view(torch.int16)).float().mean())
+        assert frac < 1e-4 and rel(a, b_) < 1e-4, (name, frac, rel(a, b_))
+    assert torch.equal(V1, V2)
+
+
 def test_gemm_lean_weight_gradient_kernel(ops):
     """gemm_kk_kernel (csrc/gemm_lean.hip: both operands k-major, fp32 out, 256x256 tiles) on the schedules it runs: whole-K rounds
     only, rounds + a split tail (atomic partial tiles into the pre-zeroed output), the balanced tail of a block's mixed image + text
