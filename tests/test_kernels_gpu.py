@@ -897,7 +897,8 @@ def test_gemm_cu_budget(ops, budget):
         assert L.mmdit_set_cu_budget(256) == 0
 
 
-@pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16)])
+@pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16),
+                                             (9000, 1304, 256, torch.bfloat16)])     # (the last: ragged M and N tiles of the 8-phase kernel's per-tensor form)
 def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
     """fp8 (e4m3, per-tensor scale) operand GEMM of the inference path vs the same quantised values multiplied in fp32."""
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -1032,7 +1033,7 @@ def _mx_reference(x):
 
 
 @pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (308, 2304, 768, torch.float32),
-                                             (16384, 2304, 768, torch.bfloat16)])
+                                             (16384, 2304, 768, torch.bfloat16), (9000, 1304, 256, torch.bfloat16)])     # (the last: ragged M and N tiles of the 8-phase MX kernel)
 def test_gemm_mxfp8_operands(ops, M, N, K, out_dtype):
     """MX (block-scaled e4m3) operand GEMM: the quantiser is bit-identical to its torch restatement (codes and E8M0 scales, in the
     GEMM's scale layout), and the GEMM -- block scales applied by v_mfma_scale_f32_32x32x64_f8f6f4 -- equals the fp32 product of
