@@ -266,6 +266,29 @@ def main():
     if not all(loss_is_plausible(l, BENCH_WINDOW) for l in losses) or check1 == check0:
         raise RuntimeError(f"bench: the timed steps did not train (losses {[float(l) for l in losses]}, parameter norm sum {check0} -> {check1})")
 
+    # shader clock and board power under the step (sysfs hwmon of this GPU, polled from a thread over extra UNTIMED steps in the launch mode of the
+    # timed ones): the MFMA peak of the roofline is quoted at 2.4 GHz, the GEMMs run at the board's power limit and clock lower
+    # (tools/probes/clock_under_load.py, profiles/r05_clock_under_load.txt)
+    clocks = None
+    if rank == 0 and world == 1 and not args.no_roofline:
+        try:
+            from tools.gpu_sensors import GpuSensors
+            sens = GpuSensors(dev)
+            if sens.available:
+                n_s = max(10, min(args.steps, 40))
+                sens.start()
+                for _ in range(n_s):
+                    step += 1
+                    trainer.train_step(step)
+                sync()
+                r = sens.stop(skip=0.2)
+                if r.get("clock_mhz"):
+                    clocks = {"shader_mhz_under_step": round(r["clock_mhz"]), "shader_mhz_range": [round(r["clock_min"]), round(r["clock_max"])],
+                              "power_w_under_step": round(r["power_w"]) if "power_w" in r else None, "samples": r["samples"],
+                              "source": f"sysfs hwmon ({sens.how}), 20 ms polls over {n_s} untimed steps"}
+        except Exception as e:      # noqa: BLE001 -- sensors are optional evidence, never a reason to lose the line
+            clocks = {"error": repr(e)}
+
     roofline, allreduce = None, None
     if not args.no_roofline:
         # three extra (untimed) steps with every GEMM launch bracketed by HIP events.  EVERY rank runs them -- the steps contain
@@ -332,6 +355,8 @@ def main():
             out["optimizer_table_builds"] = trainer.optim.table_builds
         if roofline is not None:
             out["roofline"] = roofline
+        if clocks is not None:
+            out["clocks"] = clocks
         if allreduce is not None:
             out.update(allreduce)      # allreduce_total_ms / allreduce_exposed_ms / buckets_per_step (eager steps, per step)
         if world == 1 and not args.no_cpu_baseline:

@@ -677,6 +677,25 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   // last K tile: past it the last one is requested again and never read) -- running pointers, no 64-bit multiplies by variables in the loop
   uint64_t curA = 0, curB = 0, stepA = 0, stepB = 0;
   int nkt = 0, krem = 0;                   // K tiles of the current item; K tiles behind the one being multiplied
+  // STREAM (round 5): the operand stream does not stop at an item boundary.  The stagings of an item's last two K tiles that used to repeat its
+  // last K tile (requested, never read) request the NEXT item's K tile 0 and three half-tiles of its K tile 1 instead -- exactly the state the
+  // per-item prologue leaves -- so the next item's main loop starts on data that is already in LDS, with no fill latency between two tiles.
+  // Needs the deferred epilogue's own staging (256-row tiles: the operand buffers belong to the next item by then), an even K tile count (the next
+  // item's K tile 0 must land in buffer 0) and the same problem on both sides (the per-lane chunk / row-pitch state is shared).
+  // MEASURED (round 5, profiles/r05_gemm_stream_ab.txt; correct, all GEMM / model tests pass): forced onto 256 x 256 tiles the plain bf16 launches of
+  // MMDiT-B gain 2-4 % (N = 6144, K = 768: 300 -> 295 us, N = 2304: 118 -> 113 us, data-gradient N = 6144: 295 -> 284 us), the SwiGLU launches
+  // 0-2 % (their fill latency was already hidden under the long deferred epilogue) -- and the training step, whose plain launches run on 320-row tiles
+  // (no own staging, no streaming), is 0.13 ms SLOWER with it on the same box (27.40 / 27.51 vs 27.55 / 27.64 ms): the selects in every staging cost
+  // what the boundary saves.  NOT the product: builds with -DMMDIT_G8_STREAM only.
+#ifdef MMDIT_G8_STREAM
+  constexpr bool STREAM = MT == 256 && EPI != EPI_F32 && !CONV && !MX && !KT;
+#else
+  constexpr bool STREAM = false;
+#endif
+  uint32_t rowA_n = 0, rowB_n = 0;         // the next item's lane rows
+  uint64_t curA_n = 0, curB_n = 0;         // ... and K tile 0
+  int nkt_n = 0;
+  bool strm = false;                       // (workgroup-uniform) the current item's trailing stagings belong to the next item
   int swig_h = 0;                          // SwiGLU: rows between the gate and the up half of the packed weight
   // ---- MX operands: 8-register fragments (lo = chunk g, hi = chunk 4 + g of the row) and the scale dwords of two K tiles -----------------------
   constexpr int NSC = !MX ? 1 : EPI == EPI_SWIGLU ? 6 : 4;      // A (rows i & 1 = 0, 1), B (j = 0, 1) -- SwiGLU: gate and up rows
@@ -739,25 +758,34 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   uint32_t cvA[2][CONV ? PAW : 1];        // CONV: pixel byte offset of this lane's row in piece i of half-tile h
   int cseg_left = 0, cseg_len = 0;        // CONV: K tiles left in / per kernel row
   uint64_t cjump = 0;                     // CONV: extra bytes when the K index moves to the next kernel row
+  // the lane's operand rows of an item (the part of the staging state that changes from tile to tile of one problem)
+  auto item_rows = [&](const Item& it, uint32_t& ra, uint32_t& rb) {
+    const int m0 = it.tm * MT, n0 = it.tn * 256;
+    if (A_KM) { const int kr = wave * 4 + (lane >> 4), lr0 = ((lane & 15) ^ SWZ_K(kr)) * 8; ra = m0 + (lr0 >> 6) * 128 + (lr0 & 63); }
+    else ra = m0 + wave * 8 + (lane >> 3);
+    if (B_KM) { const int kr = wave * 4 + (lane >> 4), lr0 = ((lane & 15) ^ SWZ_K(kr)) * 8; rb = n0 + (lr0 >> 5) * 64 + (lr0 & 31); }
+    else { const int lr = wave * 8 + (lane >> 3); rb = EPI == EPI_SWIGLU ? it.tn * 128 + lr : n0 + (lr >> 5) * 64 + (lr & 31); }
+  };
   auto item_setup = [&](const Item& it) {
     const Problem& q = gp.p[it.pi];
     const int m0 = it.tm * MT, n0 = it.tn * 256;
     ld2A = (uint32_t)q.lda * (MX ? 1 : 2); ld2B = (uint32_t)q.ldb * (MX ? 1 : 2);      // bytes per operand row (e4m3: one byte per value)
+    item_rows(it, rowA, rowB);
     if (A_KM) {   // (MT = 256 only) piece i: k-rows (8 i + wave) * 4 + (lane >> 4); LDS chunk (lane & 15) holds global chunk (lane & 15) ^ SWZ_K(k-row)
-      const int kr = wave * 4 + (lane >> 4), lr0 = ((lane & 15) ^ SWZ_K(kr)) * 8;
-      rowA = m0 + (lr0 >> 6) * 128 + (lr0 & 63); chkA = kr * ld2A; limA = q.M - 8;
+      const int kr = wave * 4 + (lane >> 4);
+      chkA = kr * ld2A; limA = q.M - 8;
     } else {      // piece pc = wave + 8 i: local rows 8 pc + (lane >> 3) of the half-tile = wave row lr / QR, quadrant row lr % QR
       const int lr = wave * 8 + (lane >> 3);
-      rowA = m0 + lr; chkA = ((lane & 7) ^ SWZ_R(lr)) * 16; limA = q.M - 1;
+      chkA = ((lane & 7) ^ SWZ_R(lr)) * 16; limA = q.M - 1;
     }
     if (B_KM) {
-      const int kr = wave * 4 + (lane >> 4), lr0 = ((lane & 15) ^ SWZ_K(kr)) * 8;
-      rowB = n0 + (lr0 >> 5) * 64 + (lr0 & 31); chkB = kr * ld2B; limB = q.N - 8;
+      const int kr = wave * 4 + (lane >> 4);
+      chkB = kr * ld2B; limB = q.N - 8;
     } else {
       const int lr = wave * 8 + (lane >> 3);      // piece 0: wave columns lr >> 5 (0, 1), column lr & 31; piece 1: wave columns 2, 3
       chkB = ((lane & 7) ^ SWZ_R(lr)) * 16;
-      if (EPI == EPI_SWIGLU) { rowB = it.tn * 128 + lr; swig_h = q.N >> 1; limB = q.N - 1; }   // gate / up rows of the packed weight
-      else { rowB = n0 + (lr >> 5) * 64 + (lr & 31); limB = q.N - 1; }
+      if (EPI == EPI_SWIGLU) swig_h = q.N >> 1;   // gate / up rows of the packed weight
+      limB = q.N - 1;
     }
     const int kt0 = it.h0 >> 1;
     nkt = (it.h1 - it.h0) >> 1;
@@ -802,24 +830,26 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   };
   // half-tile h of K tile (current + d), d = 0 / 1 / 2 -> buffer buf
   auto stageA = [&](int h, int d, int buf) {
-    const int dd = min(d, krem);
-    const char* src = (const char*)(uintptr_t)(curA + (uint64_t)(uint32_t)dd * stepA + (CONV && dd >= cseg_left ? cjump : 0));      // (CONV: d <= 2 < a kernel row's K tiles)
+    const bool nx = STREAM && strm && d > krem;      // (workgroup-uniform) a K tile of the next item
+    const int dd = nx ? min(d - krem - 1, nkt_n - 1) : min(d, krem);
+    const char* src = (const char*)(uintptr_t)((nx ? curA_n : curA) + (uint64_t)(uint32_t)dd * stepA + (CONV && dd >= cseg_left ? cjump : 0));      // (CONV: d <= 2 < a kernel row's K tiles)
+    const uint32_t rA = nx ? rowA_n : rowA;
     const uint32_t dst = ldsw + buf * KBUF + (h ? XA1 : XA0);
 #pragma unroll
     for (int i = 0; i < PAW; i++) {
       if (!(i < PAW - 1 || GE::PA % 8 == 0 || hiw)) continue;
       uint32_t voff;
-      if (A_KM) voff = (uint32_t)min((int)rowA + h * 64, limA) * 2 + chkA + (uint32_t)(i * 32) * ld2A;
+      if (A_KM) voff = (uint32_t)min((int)rA + h * 64, limA) * 2 + chkA + (uint32_t)(i * 32) * ld2A;
       else {      // local row 8 (wave + 8 i) + ..: wave row (lr / QR), quadrant row lr % QR -> tile row (lr / QR) * 2 QR + h QR + lr % QR
         const int lr0 = 64 * i;                                 // + wave * 8 + (lane >> 3) < 64: same wave row as long as 64 i + 63 < QR ... handled per case
         int drow;
         if (MT == 256) drow = i * 128 + h * 64;                  // QR = 64: piece i is wave row i
         else drow = 0;                                           // (320: see below)
         if (CONV) voff = cvA[h][CONV ? i : 0] + chkA;
-        else if (MT == 256) voff = (uint32_t)min((int)rowA + drow, limA) * ld2A + chkA;
+        else if (MT == 256) voff = (uint32_t)min((int)rA + drow, limA) * ld2A + chkA;
         else {
           // QR = 80: local row lr = 64 i + 8 wave + (lane >> 3) (< 160); tile row = (lr >= 80 ? 160 : 0) + h * 80 + (lr >= 80 ? lr - 80 : lr) = lr + (lr >= 80 ? 80 : 0) + h * 80
-          const int lr = lr0 + (int)rowA;                        // rowA carries m0 + 8 wave + (lane >> 3)
+          const int lr = lr0 + (int)rA;                        // rowA carries m0 + 8 wave + (lane >> 3)
           const int lrl = lr0 + wave * 8;                        // wave-uniform part: pieces never straddle the wave rows (80 = 10 pieces)
           voff = (uint32_t)min(lr + (lrl >= 80 ? 80 : 0) + h * 80, limA) * ld2A + chkA;
         }
@@ -828,15 +858,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     }
   };
   auto stageB = [&](int h, int d, int buf) {
-    const int dd = min(d, krem);
-    const char* src = (const char*)(uintptr_t)(curB + (uint64_t)(uint32_t)dd * stepB);
+    const bool nx = STREAM && strm && d > krem;
+    const int dd = nx ? min(d - krem - 1, nkt_n - 1) : min(d, krem);
+    const char* src = (const char*)(uintptr_t)((nx ? curB_n : curB) + (uint64_t)(uint32_t)dd * stepB);
+    const uint32_t rB = nx ? rowB_n : rowB;
     const uint32_t dst = ldsw + buf * KBUF + (h ? XB1 : XB0);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       uint32_t voff;
-      if (B_KM) voff = (uint32_t)min((int)rowB + h * 32, limB) * 2 + chkB + (uint32_t)(i * 32) * ld2B;
-      else if (EPI == EPI_SWIGLU) voff = (uint32_t)((int)rowB + i * 64 + h * swig_h) * ld2B + chkB;      // hidden index 128 tn + 64 i + ..: gate (h = 0) / up (h = 1)
-      else voff = (uint32_t)min((int)rowB + i * 128 + h * 32, limB) * ld2B + chkB;                       // piece i: wave columns 2 i, 2 i + 1
+      if (B_KM) voff = (uint32_t)min((int)rB + h * 32, limB) * 2 + chkB + (uint32_t)(i * 32) * ld2B;
+      else if (EPI == EPI_SWIGLU) voff = (uint32_t)((int)rB + i * 64 + h * swig_h) * ld2B + chkB;      // hidden index 128 tn + 64 i + ..: gate (h = 0) / up (h = 1)
+      else voff = (uint32_t)min((int)rB + i * 128 + h * 32, limB) * ld2B + chkB;                       // piece i: wave columns 2 i, 2 i + 1
       glds16(voff, src, dst + i * 8192);
     }
   };
@@ -1085,9 +1117,28 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 #endif
   Item item = item_at(gp, pos, end), prev = item;
   bool pending = false;
+  bool streamed = false;      // (workgroup-uniform) this item's first stagings were requested by the previous item's main loop
   while (item.valid) {
-    item_setup(item);
-    if (nkt > 0) {
+    const Item nxt = item_at(gp, item.pos + G, end);
+    if (STREAM && streamed) {      // the staging state is the one the previous item's loop has been using for its trailing requests
+      rowA = rowA_n; rowB = rowB_n; curA = curA_n; curB = curB_n; nkt = nkt_n; krem = nkt - 1;
+    } else {
+      item_setup(item);
+    }
+    if constexpr (STREAM) {
+      strm = nxt.valid && nxt.pi == item.pi && nkt >= 2 && (nkt & 1) == 0 && nxt.h1 > nxt.h0;
+#ifdef MMDIT_PROBES
+      if (gp.debug & 4096) strm = false;      // A/B: a prologue per item
+#endif
+      if (strm) {
+        const Problem& q = gp.p[nxt.pi];
+        item_rows(nxt, rowA_n, rowB_n);
+        curA_n = (uint64_t)(uintptr_t)q.A + (uint64_t)(nxt.h0 >> 1) * stepA;
+        curB_n = (uint64_t)(uintptr_t)q.B + (uint64_t)(nxt.h0 >> 1) * stepB;
+        nkt_n = (nxt.h1 - nxt.h0) >> 1;
+      }
+    }
+    if (nkt > 0 && !(STREAM && streamed)) {
       if constexpr (MX) sload(0, 0);      // (first: the scale dwords of K tile 0 are older than the stagings the first counted wait leaves in flight)
       // prologue: K tile 0 whole, three half-tiles of K tile 1 (in the order the loop continues; second argument: K tiles ahead)
       if (REREAD) { stageA(0, 0, 0); stageB(1, 0, 0); stageA(1, 0, 0); stageB(0, 0, 0); stageA(0, 1, 1); stageB(1, 1, 1); stageA(1, 1, 1); }
@@ -1107,7 +1158,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
           for (int i = 0; i < 2 * FI; i++) acc.a[a][b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (nkt > 0) {
-      wait3();                     // (DEFER: the epilogue's stores are younger than every request -- this also waits for all but a few of them)
+      if (!(STREAM && streamed)) wait3();      // (DEFER: the epilogue's stores are younger than every request -- this also waits for all but a few of them.
+                                               //  STREAM: K tile 0 has been complete since the last counted wait of the previous item's loop)
       BAR8();
       if (wr == 1) BAR8();         // group 1 runs one barrier behind from here on
       int t = 0;
@@ -1135,7 +1187,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         }
         if (t < nkt) KTILE8(0)
       }
-      VMCNT8(0);                   // the trailing (unused) requests have landed
+      if (!(STREAM && strm)) VMCNT8(0);      // the trailing (unused) requests have landed (STREAM: they are the next item's and stay in flight)
       if (wr == 0) BAR8();         // rejoin
       BAR8();                      // every wave's requests have landed and every wave has left the operand buffers
     }
@@ -1190,7 +1242,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       run_epilogue(item);
       if (MT != 256) BAR8();       // (the staging lives in the operand buffers the next prologue overwrites)
     }
-    item = item_at(gp, item.pos + G, end);
+    streamed = STREAM && strm;
+    item = nxt;
   }
   if (DEFER && pending) run_epilogue(prev);
 }
