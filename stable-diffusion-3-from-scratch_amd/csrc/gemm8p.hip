@@ -682,18 +682,19 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   // per-item prologue leaves -- so the next item's main loop starts on data that is already in LDS, with no fill latency between two tiles.
   // Needs the deferred epilogue's own staging (256-row tiles: the operand buffers belong to the next item by then), an even K tile count (the next
   // item's K tile 0 must land in buffer 0) and the same problem on both sides (the per-lane chunk / row-pitch state is shared).
-  // MEASURED (round 5, profiles/r05_gemm_stream_ab.txt; correct, all GEMM / model tests pass): forced onto 256 x 256 tiles the plain bf16 launches of
-  // MMDiT-B gain 2-4 % (N = 6144, K = 768: 300 -> 295 us, N = 2304: 118 -> 113 us, data-gradient N = 6144: 295 -> 284 us), the SwiGLU launches
-  // 0-2 % (their fill latency was already hidden under the long deferred epilogue) -- and the training step, whose plain launches run on 320-row tiles
-  // (no own staging, no streaming), is 0.13 ms SLOWER with it on the same box (27.40 / 27.51 vs 27.55 / 27.64 ms): the selects in every staging cost
-  // what the boundary saves.  NOT the product: builds with -DMMDIT_G8_STREAM only.
+  // The K tiles whose stagings stay inside the item run a loop without clamps or selects (gen = false); only an item's last two or three K tiles take
+  // the general form.  MEASURED (round 5, profiles/r05_gemm_stream_ab.txt; correct: the GEMM / model / inference tests pass with it; same box, alternating
+  // libraries): training step 27.91 / 27.97 ms without, 27.85 / 27.93 with; mxfp8 sampler 19.20 / 19.16 vs 19.23 / 19.25 img/s; the MX launches of MMDiT-L
+  // (K = 1024, 8 K tiles per item) 714 / 731 vs 705 / 710 us.  Within the noise: the launches are power-limited and the fill latency it removes
+  // was idle time the clock had been using.  NOT the product: builds with -DMMDIT_G8_STREAM only.
 #ifdef MMDIT_G8_STREAM
-  constexpr bool STREAM = MT == 256 && EPI != EPI_F32 && !CONV && !MX && !KT;
+  constexpr bool STREAM = MT == 256 && EPI != EPI_F32 && !CONV && !KT;
 #else
   constexpr bool STREAM = false;
 #endif
   uint32_t rowA_n = 0, rowB_n = 0;         // the next item's lane rows
   uint64_t curA_n = 0, curB_n = 0;         // ... and K tile 0
+  uint64_t scurA_n = 0, scurB_n = 0;       // ... and (MX) the scale bytes of its K tile 0
   int nkt_n = 0;
   bool strm = false;                       // (workgroup-uniform) the current item's trailing stagings belong to the next item
   int swig_h = 0;                          // SwiGLU: rows between the gate and the up half of the packed weight
@@ -718,10 +719,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     }
   };
   // scale dwords of K tile (current + d) into set `set` (inline asm: the compiler must neither count nor wait for these loads)
-  auto sload = [&](int set, int d) {
+  auto sload = [&](int set, int d, bool gen = true) {      // gen = false: a K tile that is known to exist in this item (no clamp, no next item)
     if constexpr (MX && !PT) {
-      const int dd = min(d, krem);
-      const uint64_t pa = scurA + (uint64_t)(uint32_t)dd * sstepA, pb = scurB + (uint64_t)(uint32_t)dd * sstepB;
+      const bool nx = gen && STREAM && strm && d > krem;
+      const int dd = !gen ? d : nx ? min(d - krem - 1, nkt_n - 1) : min(d, krem);
+      const uint64_t pa = (nx ? scurA_n : scurA) + (uint64_t)(uint32_t)dd * sstepA, pb = (nx ? scurB_n : scurB) + (uint64_t)(uint32_t)dd * sstepB;
       const uint64_t ua = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pa >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pa);
       const uint64_t ub = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pb);
       asm volatile("s_nop 4\n\tglobal_load_dword %0, %2, %3\n\tglobal_load_dword %1, %2, %3 offset:128" : "=v"(sc[set][0]), "=v"(sc[set][1]) : "v"(soffA), "s"(ua) : "memory");
@@ -829,9 +831,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     }
   };
   // half-tile h of K tile (current + d), d = 0 / 1 / 2 -> buffer buf
-  auto stageA = [&](int h, int d, int buf) {
-    const bool nx = STREAM && strm && d > krem;      // (workgroup-uniform) a K tile of the next item
-    const int dd = nx ? min(d - krem - 1, nkt_n - 1) : min(d, krem);
+  auto stageA = [&](int h, int d, int buf, bool gen = true) {
+    const bool nx = gen && STREAM && strm && d > krem;      // (workgroup-uniform) a K tile of the next item
+    const int dd = !gen ? d : nx ? min(d - krem - 1, nkt_n - 1) : min(d, krem);
     const char* src = (const char*)(uintptr_t)((nx ? curA_n : curA) + (uint64_t)(uint32_t)dd * stepA + (CONV && dd >= cseg_left ? cjump : 0));      // (CONV: d <= 2 < a kernel row's K tiles)
     const uint32_t rA = nx ? rowA_n : rowA;
     const uint32_t dst = ldsw + buf * KBUF + (h ? XA1 : XA0);
@@ -857,9 +859,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       glds16(voff, src, dst + i * 8192);
     }
   };
-  auto stageB = [&](int h, int d, int buf) {
-    const bool nx = STREAM && strm && d > krem;
-    const int dd = nx ? min(d - krem - 1, nkt_n - 1) : min(d, krem);
+  auto stageB = [&](int h, int d, int buf, bool gen = true) {
+    const bool nx = gen && STREAM && strm && d > krem;
+    const int dd = !gen ? d : nx ? min(d - krem - 1, nkt_n - 1) : min(d, krem);
     const char* src = (const char*)(uintptr_t)((nx ? curB_n : curB) + (uint64_t)(uint32_t)dd * stepB);
     const uint32_t rB = nx ? rowB_n : rowB;
     const uint32_t dst = ldsw + buf * KBUF + (h ? XB1 : XB0);
@@ -903,28 +905,28 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 #else
 #define WAIT3X() wait3()
 #endif
-#define KTILE8(cur)                                                                                          \
+#define KTILE8(cur, gen)                                                                                          \
   {                                                                                                          \
     /* P1 */                                                                                                 \
     P1_READS(cur)                                                                                            \
-    if (REREAD) stageB(0, 1, (cur) ^ 1); else stageA(1, 1, (cur) ^ 1);                           \
+    if (REREAD) stageB(0, 1, (cur) ^ 1, gen); else stageA(1, 1, (cur) ^ 1, gen);                           \
     P1_WAIT(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                    \
     mma(acc.a[0][0], fb0);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P2 */                                                                                                 \
     readB(FB1, cur, XB1);                                                                                    \
-    stageA(0, 2, cur);                                                                                 \
+    stageA(0, 2, cur, gen);                                                                                 \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
     mma(acc.a[0][1], FB1);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P3 */                                                                                                 \
     P3_READS(cur)                                                                                            \
-    if (REREAD) stageB(1, 2, cur); else stageB(0, 2, cur);                                       \
+    if (REREAD) stageB(1, 2, cur, gen); else stageB(0, 2, cur, gen);                                       \
     P3_WAIT(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                    \
     mma(acc.a[1][1], FB1);                                                                                   \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     /* P4 */                                                                                                 \
-    if (REREAD) { readB(fb0, cur, XB0); stageA(1, 2, cur); } else stageB(1, 2, cur);             \
+    if (REREAD) { readB(fb0, cur, XB0); stageA(1, 2, cur, gen); } else stageB(1, 2, cur, gen);             \
     WAIT3X();                                                                                                \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
     mma(acc.a[1][0], fb0);                                                                                   \
@@ -934,25 +936,25 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 
   // MX K tile (KEEP schedule): the phases of KTILE8 with 8-register fragments and one scaled MFMA per 16 x 16 block; P1 requests the NEXT K tile's
   // scale dwords into the other register set (older than every staging P4's counted wait leaves in flight)
-#define KTILE8X(cur)                                                                                         \
+#define KTILE8X(cur, gen)                                                                                         \
   {                                                                                                          \
     xreadB(xb0, cur, XB0); __builtin_amdgcn_sched_barrier(0); xreadA(cur, XA0);                              \
-    sload((cur) ^ 1, 1);                                                                                     \
-    stageA(1, 1, (cur) ^ 1);                                                                                 \
+    sload((cur) ^ 1, 1, gen);                                                                                     \
+    stageA(1, 1, (cur) ^ 1, gen);                                                                                 \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
     mmax(acc.a[0][0], xb0, cur, 0, 0);                                                                       \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     xreadB(xb1, cur, XB1);                                                                                   \
-    stageA(0, 2, cur);                                                                                       \
+    stageA(0, 2, cur, gen);                                                                                       \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
     mmax(acc.a[0][1], xb1, cur, 0, 1);                                                                       \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
     xreadA(cur, XA1);                                                                                        \
-    stageB(0, 2, cur);                                                                                       \
+    stageB(0, 2, cur, gen);                                                                                       \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
     mmax(acc.a[1][1], xb1, cur, 1, 1);                                                                       \
     __builtin_amdgcn_sched_barrier(0); BAR8();                                                               \
-    stageB(1, 2, cur);                                                                                       \
+    stageB(1, 2, cur, gen);                                                                                       \
     wait3();                                                                                                 \
     spin((cur) ^ 1);                                                                                         \
     LGKM0(); BAR8(); __builtin_amdgcn_sched_barrier(0);                                                      \
@@ -1119,13 +1121,14 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   bool pending = false;
   bool streamed = false;      // (workgroup-uniform) this item's first stagings were requested by the previous item's main loop
   while (item.valid) {
-    const Item nxt = item_at(gp, item.pos + G, end);
     if (STREAM && streamed) {      // the staging state is the one the previous item's loop has been using for its trailing requests
       rowA = rowA_n; rowB = rowB_n; curA = curA_n; curB = curB_n; nkt = nkt_n; krem = nkt - 1;
+      if constexpr (MX && !PT) { scurA = scurA_n; scurB = scurB_n; }
     } else {
       item_setup(item);
     }
     if constexpr (STREAM) {
+      const Item nxt = item_at(gp, item.pos + G, end);      // (found again at the bottom of the loop: not kept alive across the main loop)
       strm = nxt.valid && nxt.pi == item.pi && nkt >= 2 && (nkt & 1) == 0 && nxt.h1 > nxt.h0;
 #ifdef MMDIT_PROBES
       if (gp.debug & 4096) strm = false;      // A/B: a prologue per item
@@ -1136,6 +1139,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         curA_n = (uint64_t)(uintptr_t)q.A + (uint64_t)(nxt.h0 >> 1) * stepA;
         curB_n = (uint64_t)(uintptr_t)q.B + (uint64_t)(nxt.h0 >> 1) * stepB;
         nkt_n = (nxt.h1 - nxt.h0) >> 1;
+        if constexpr (MX && !PT) {
+          scurA_n = (uint64_t)(uintptr_t)q.scale_a + (uint64_t)(nxt.h0 >> 1) * sstepA + (uint64_t)(nxt.tm * MT) * 2;
+          scurB_n = (uint64_t)(uintptr_t)q.scale_b + (uint64_t)(nxt.h0 >> 1) * sstepB + (uint64_t)(EPI == EPI_SWIGLU ? nxt.tn * 128 : nxt.tn * 256) * 2;
+        }
       }
     }
     if (nkt > 0 && !(STREAM && streamed)) {
@@ -1167,25 +1174,39 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         KTILE8D(0)
 #pragma unroll 1
         for (t = 1; t + 1 < nkt; t += 2) {
-          KTILE8(1)
-          KTILE8(0)
+          KTILE8(1, true)
+          KTILE8(0, true)
         }
-        if (t < nkt) KTILE8(1)
+        if (t < nkt) KTILE8(1, true)
       } else if constexpr (MX) {
         spin(0);
+        if constexpr (STREAM) {      // the K tiles whose stagings stay inside the item: no clamps, no selects
+#pragma unroll 1
+          for (; t + 3 < nkt; t += 2) {
+            KTILE8X(0, false)
+            KTILE8X(1, false)
+          }
+        }
 #pragma unroll 1
         for (; t + 1 < nkt; t += 2) {
-          KTILE8X(0)
-          KTILE8X(1)
+          KTILE8X(0, true)
+          KTILE8X(1, true)
         }
-        if (t < nkt) KTILE8X(0)
+        if (t < nkt) KTILE8X(0, true)
       } else {
+        if constexpr (STREAM) {
+#pragma unroll 1
+          for (; t + 3 < nkt; t += 2) {
+            KTILE8(0, false)
+            KTILE8(1, false)
+          }
+        }
 #pragma unroll 1
         for (; t + 1 < nkt; t += 2) {
-          KTILE8(0)
-          KTILE8(1)
+          KTILE8(0, true)
+          KTILE8(1, true)
         }
-        if (t < nkt) KTILE8(0)
+        if (t < nkt) KTILE8(0, true)
       }
       if (!(STREAM && strm)) VMCNT8(0);      // the trailing (unused) requests have landed (STREAM: they are the next item's and stay in flight)
       if (wr == 0) BAR8();         // rejoin
@@ -1243,7 +1264,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       if (MT != 256) BAR8();       // (the staging lives in the operand buffers the next prologue overwrites)
     }
     streamed = STREAM && strm;
-    item = nxt;
+    item = item_at(gp, item.pos + G, end);
   }
   if (DEFER && pending) run_epilogue(prev);
 }
