@@ -66,3 +66,5 @@ python -m pytest tests -m gpu -q -s 2>&1 | grep "^\[\|passed\|failed" > gpurun_o
 python tools/stage_bench.py --stages 1,2,3 2>/dev/null | grep "^{" > gpurun_out/${R}_trained_stages.txt
 python tools/probes/fp8_bench.py 2>&1 | grep -v amdgpu > gpurun_out/${R}_fp8_bench.txt
 python tools/sampler_bench.py 2>&1 | grep sampler > gpurun_out/${R}_sampler_lines.txt
+python tools/config4_bench.py --batch 40 2>/dev/null | grep "^{" > gpurun_out/${R}_config4_b40.json
+python tools/probes/clock_under_load.py 3 2>&1 | grep -v amdgpu > gpurun_out/${R}_clock_under_load.txt
