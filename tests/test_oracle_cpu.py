@@ -336,3 +336,32 @@ def test_host_logic_scheduler_sampler_rope():
     assert torch.allclose(fr, O.axial_freqs(3, 5, O.rope_inv_freq(64)))
     x = torch.randn(2, 3, 3, 5, 64)
     assert torch.allclose(apply_rotary_emb(fr, x), O.apply_rope(fr, x), atol=1e-6)
+
+
+def test_gpu_sensor_poller_on_a_fake_sysfs_tree(tmp_path):
+    """tools/gpu_sensors.py (bench.py's `clocks` object, tools/probes/clock_under_load.py): the card is found by its PCI address, connectors and cards
+    without a hwmon directory are ignored, the poller averages MHz / W and survives unreadable values."""
+    import os
+    import time
+    from tools.gpu_sensors import GpuSensors
+    pci = tmp_path / "devices" / "0000:d9:00.0"
+    (pci / "hwmon" / "hwmon7").mkdir(parents=True)
+    (pci / "hwmon" / "hwmon7" / "freq1_input").write_text("1858000000\n")
+    (pci / "hwmon" / "hwmon7" / "power1_input").write_text("1388000000\n")
+    (pci / "gpu_busy_percent").write_text("100\n")
+    other = tmp_path / "devices" / "0000:f4:00.0"
+    other.mkdir(parents=True)                                   # a card without sensors
+    drm = tmp_path / "drm"
+    for name, target in (("card0", pci), ("card8", other)):
+        (drm / name).mkdir(parents=True)
+        os.symlink(target, drm / name / "device")
+    (drm / "card0-DP-1").mkdir()
+    s = GpuSensors(root=str(drm), bdf="0000:d9:00.0")
+    assert s.available and s.card.endswith("0000:d9:00.0") and "PCI address" in s.how
+    s.start()
+    time.sleep(0.15)
+    (pci / "hwmon" / "hwmon7" / "power1_input").write_text("garbage\n")
+    time.sleep(0.1)
+    r = s.stop()
+    assert r["samples"] >= 5 and abs(r["clock_mhz"] - 1858.0) < 1e-6 and abs(r["power_w"] - 1388.0) < 1e-6 and r["busy"] == 100.0
+    assert not GpuSensors(root=str(drm), bdf="0000:f4:00.0").available       # no hwmon: nothing to poll

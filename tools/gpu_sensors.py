@@ -15,9 +15,9 @@ def _read(path):
         return None
 
 
-def _cards():
+def _cards(root="/sys/class/drm"):
     out = {}
-    for dev in sorted(glob.glob("/sys/class/drm/card*/device")):
+    for dev in sorted(glob.glob(os.path.join(root, "card*/device"))):
         if "-" in os.path.basename(os.path.dirname(dev)):      # connectors (card0-DP-1)
             continue
         hw = glob.glob(dev + "/hwmon/hwmon*")
@@ -33,22 +33,25 @@ def _cards():
 
 
 class GpuSensors:
-    def __init__(self, device=None):
-        import torch
-        self.cards = _cards()
+    def __init__(self, device=None, root="/sys/class/drm", bdf=None):
+        """device: the torch device whose GPU to watch; bdf (tests): the PCI address directly, torch is not consulted."""
+        self.cards = _cards(root)
         self.card, self.how, self.files = None, "none", {}
-        idx = device.index if device is not None and device.index is not None else torch.cuda.current_device()
-        try:
-            pr = torch.cuda.get_device_properties(idx)
-            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
-            for path, files in self.cards.items():
-                if os.path.basename(path) == bdf:
-                    self.card, self.how, self.files = path, "PCI address " + bdf, files
-        except Exception:      # noqa: BLE001 -- an older torch without the pci_* properties
-            pass
-        if self.card is None and self.cards:
-            self._by_load(idx)
         self._rows, self._stop, self._thr = [], False, None
+        idx = None
+        if bdf is None:
+            import torch
+            idx = device.index if device is not None and device.index is not None else torch.cuda.current_device()
+            try:
+                pr = torch.cuda.get_device_properties(idx)
+                bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            except Exception:      # noqa: BLE001 -- an older torch without the pci_* properties
+                bdf = None
+        for path, files in self.cards.items():
+            if bdf is not None and os.path.basename(path) == bdf:
+                self.card, self.how, self.files = path, "PCI address " + bdf, files
+        if self.card is None and self.cards and idx is not None:
+            self._by_load(idx)
 
     def _by_load(self, idx):
         import torch
