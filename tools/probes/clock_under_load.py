@@ -20,7 +20,7 @@ sens = GpuSensors(torch.device("cuda", 0))
 print("sensors of", sens.card, "(selected by:", sens.how + ")")
 
 
-def phase(name, fn, flop=0.0):
+def phase(name, fn, flop=0.0, peak=2500.0):      # peak: dense MFMA TFLOP/s of the operand type at 2.4 GHz
     torch.cuda.synchronize()
     sens.start()
     t0 = time.time(); n = 0
@@ -35,7 +35,7 @@ def phase(name, fn, flop=0.0):
     r = sens.stop(skip=0.25)
     us = e0.elapsed_time(e1) / max(n, 1) * 1e3
     tf = f"{flop / us / 1e6:6.0f} TF" if flop else "         "
-    at = f" = {flop / us / 1e6 / (2500.0 * r['clock_mhz'] / 2400.0):.3f} of the MFMA peak at that clock" if flop and r.get("clock_mhz") else ""
+    at = f" = {flop / us / 1e6 / (peak * r['clock_mhz'] / 2400.0):.3f} of the MFMA peak at that clock" if flop and r.get("clock_mhz") else ""
     print(f"{name:44s} {us:9.1f} us/launch {tf} | clock {r.get('clock_mhz', float('nan')):5.0f} MHz [{r.get('clock_min', 0):.0f}, {r.get('clock_max', 0):.0f}]"
           f"  power {r.get('power_w', float('nan')):5.0f} W  busy {r.get('busy', float('nan')):3.0f} %  ({r.get('samples', 0)} samples){at}", flush=True)
 
@@ -48,11 +48,20 @@ o = torch.empty((8192, 8192), dtype=torch.bfloat16, device="cuda")
 phase("gemm 8192^3 bf16 (NT)", lambda: ops.gemm(A, B, out=o), 2.0 * 8192 ** 3)
 Z = torch.zeros_like(A)
 phase("  the same launch on ZERO operands", lambda: ops.gemm(Z, Z, out=o), 2.0 * 8192 ** 3)
-del A, B, Z, o
+ma, msa = ops.quant_mxfp8(A); mb, msb = ops.quant_mxfp8(B)
+phase("gemm 8192^3 MX e4m3 operands", lambda: ops.gemm(ma, mb, out=o, scale_a=msa, scale_b=msb, scale_mode=1), 2.0 * 8192 ** 3, 5000.0)
+del A, B, Z, o, ma, mb
 M = 26240
 A2, B2 = rnd(M, 768), rnd(6144, 768)
 o2 = torch.empty((M, 6144), dtype=torch.bfloat16, device="cuda")
 phase("forward Linear 26240 x 6144 x 768", lambda: ops.gemm(A2, B2, out=o2), 2.0 * M * 6144 * 768)
+Z2 = torch.zeros_like(A2)
+phase("  the same launch, zero activations", lambda: ops.gemm(Z2, B2, out=o2), 2.0 * M * 6144 * 768)
+AL, BL = rnd(75392, 1024), rnd(8192, 1024)
+mal, msal = ops.quant_mxfp8(AL); mbl, msbl = ops.quant_mxfp8(BL)
+oL = torch.empty((75392, 8192), dtype=torch.bfloat16, device="cuda")
+phase("MMDiT-L w12 75392 x 8192 x 1024, MX operands", lambda: ops.gemm(mal, mbl, out=oL, scale_a=msal, scale_b=msbl, scale_mode=1), 2.0 * 75392 * 8192 * 1024, 5000.0)
+del AL, BL, mal, mbl, oL, Z2
 # a block's weight gradients as the step launches them: one grouped stream-K launch (both token streams, 4 Linears each)
 Mx, Mc, d = 16384, 9856, 768
 probs = []
