@@ -22,6 +22,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=16)
 ap.add_argument("--steps", type=int, default=8)
 ap.add_argument("--warmup", type=int, default=3)
+ap.add_argument("--eager", action="store_true", help="host launches instead of replaying the step from a hipGraph (the encode is always launched from the host)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 PEAK = 2.5e15
@@ -35,9 +36,17 @@ def build(data_source):
                          hip_optimizer=True, data_source=data_source)
 
 
-def timed_steps(tr, first):
+LAUNCH = {}
+
+
+def timed_steps(tr, first, tag):
     for s in range(first, first + a.warmup):
         loss = tr.train_step(s)
+    LAUNCH[tag] = "eager"
+    if not a.eager and tr.capture_graph_agreed(first + a.warmup):      # the step replays from a hipGraph; a data source's batch is copied into its input slots
+        LAUNCH[tag] = "hipGraph replay"
+        for s in range(2):
+            tr.train_step(first + a.warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for s in range(first + a.warmup, first + a.warmup + a.steps):
@@ -49,7 +58,7 @@ def timed_steps(tr, first):
 # (1) end to end: synthetic 512^2 images -> in-rank VAE encode -> MMDiT-L step
 src = ImageLatentSource.synthetic(a.batch, 512, 768, dev)
 tr = build(src)
-t_e2e, loss_e2e = timed_steps(tr, 1)
+t_e2e, loss_e2e = timed_steps(tr, 1, "end_to_end")
 # the encode alone, on the same object
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -62,9 +71,11 @@ def gemm_profile(trainer):
     from sd3_amd import engine
     overlap, engine._WG_OVERLAP = engine._WG_OVERLAP, False   # serialise the side-stream weight-gradient launches: clean per-launch durations
     ops.PROFILE = []
+    graph, trainer._graph = trainer._graph, None              # (eager: every launch is bracketed individually)
     for s in range(100, 102):
         trainer.train_step(s)
     torch.cuda.synchronize()
+    trainer._graph = graph
     engine._WG_OVERLAP = overlap
     f = sum(x[1] for x in ops.PROFILE) / 2
     t = sum(x[2].elapsed_time(x[3]) for x in ops.PROFILE) * 1e-3 / 2
@@ -78,7 +89,7 @@ del tr, src
 torch.cuda.empty_cache()
 # (2) the step alone (latents already in HBM: SyntheticData)
 tr = build(None)
-t_step, _ = timed_steps(tr, 1)
+t_step, _ = timed_steps(tr, 1, "step_only")
 f_mm, t_mm = gemm_profile(tr)
 roof = lambda f, t: {"bound": "mfma", "achieved_tflops": round(f / t / 1e12, 1), "peak_tflops": PEAK / 1e12, "frac": round(f / t / PEAK, 4), "gemm_ms_per_step": round(t * 1e3, 2),
                      "gemm_tflop_per_step": round(f / 1e12, 1)}
@@ -87,4 +98,4 @@ print(json.dumps({"config": "MMDiT-L (24 blocks, d=1024, 16 heads) 512^2 images 
                   "images_per_s_step_only": round(a.batch / t_step, 1), "ms_per_step_only": round(t_step * 1e3, 2),
                   "vae_encode_ms_per_batch": round(t_enc * 1e3, 2), "loss_last": round(loss_e2e, 5),
                   "mmdit_gemm_roofline": roof(f_mm, t_mm), "vae_conv_gemm_roofline": roof(f_all - f_mm, max(1e-9, t_all - t_mm)),
-                  "mfma_roofline_frac_of_step_time": round(f_mm / t_step / PEAK, 4), "launch": "eager", "data": "synthetic", "peak_mem_gib": round(peak_mem, 1)}))
+                  "mfma_roofline_frac_of_step_time": round(f_mm / t_step / PEAK, 4), "launch": LAUNCH, "data": "synthetic", "peak_mem_gib": round(peak_mem, 1)}))
