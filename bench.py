@@ -59,6 +59,24 @@ def pmc_traffic(kernel):
     return None, None, None
 
 
+def host_cpu():
+    """(model name, physical core count) of the host from /proc/cpuinfo: distinct (physical id, core id) pairs; (None, None) when unreadable."""
+    try:
+        model, cores, phys = None, set(), None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                cores.add((phys, v))
+        return model, (len(cores) or None)
+    except OSError:
+        return None, None
+
+
 def cpu_baseline(seconds_budget=25.0):
     """fwd + bwd + clip + AdamW of the oracle on MMDiT-B, batch 8, host cores only."""
     import torch
@@ -83,7 +101,8 @@ def cpu_baseline(seconds_budget=25.0):
         tr.step(*batch())
         n += 1
     dt = time.time() - t0
-    return {"value": round(n * bs / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+    model, physical = host_cpu()
+    return {"value": round(n * bs / dt, 3), "unit": "images/s", "cores": threads, "cpu_model": model, "physical_cores": physical, "kind": "port",
             "sample": f"{n} optimizer steps of MMDiT-B (fp32 weights, reference CPU attention branch), batch {bs}, fwd+bwd+clip+AdamW, torch CPU {threads} threads"}
 
 

@@ -8,8 +8,10 @@
  * cites it (file:line into the reference's src/).  Conventions:
  *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
  *     owned by the caller (workspaces and saved-for-backward buffers included);
- *   - the library allocates nothing, keeps no mutable global state, never
- *     synchronises the device and launches only on the stream it is given;
+ *   - the library allocates nothing, never synchronises the device and launches
+ *     only on the stream it is given; its only mutable state are two per-device
+ *     registrations made by the caller: mmdit_gemm_set_workspace (a pointer) and
+ *     mmdit_set_cu_budget (an integer);
  *   - re-entrant: safe to call from the autograd worker thread;
  *   - return value: 0 on success, MMDIT_ERR_* (<0) for invalid arguments, or a
  *     positive hipError_t from the launch.
@@ -59,7 +61,7 @@ typedef void* mmdit_stream_t;   /* hipStream_t */
  * (MMDIT_LIB=...) with another layout fails loudly instead of reading past a struct.  mmdit_struct_size(which): sizeof of
  * 0 mmdit_gemm_args, 1 mmdit_ln_fwd_problem, 2 mmdit_ln_bwd_problem, 3 mmdit_qk_problem, 4 mmdit_mlp_bwd_problem,
  * 5 mmdit_adamw_tensor, 6 mmdit_cast_tensor, 7 mmdit_qk_epilogue; -1 for an unknown id. */
-#define MMDIT_ABI_VERSION 7
+#define MMDIT_ABI_VERSION 8
 int mmdit_abi_version(void);
 int mmdit_struct_size(int which);
 const char* mmdit_build_arch(void);
@@ -150,20 +152,32 @@ typedef struct mmdit_qk_epilogue {
 } mmdit_qk_epilogue;
 int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogue* qk, int count, int heads, int s_total,
                              void* Q, void* K, void* V, mmdit_stream_t stream);
-/* Optional device workspace for the weight-gradient launches (k-major x k-major, fp32 out, K-decomposed): with it the partial tiles of
- * the split tail are stored to per-slice slots and summed by the last slice to arrive (ticket counters) instead of being added with fp32
- * atomics -- faster (an atomic 256x256 partial costs ~0.6 us of launch time), deterministic, and the outputs need no zero-fill
- * (mmdit_gemm_zero_mask reports none).  Layout: 4 KiB of tickets, ZERO-FILLED by the caller once, then 256 KiB slots; a launch that
- * needs more slots than fit falls back to atomics.  One workspace per process: launches that use it must be stream-ordered.
- * ptr = NULL, bytes = 0 removes it.  The library never allocates. */
+/* Optional device workspace of the GEMM launches, owned by the caller.  Layout: bytes [0, 4096) tickets and [4096, 8192) scheduler words, both
+ * ZERO-FILLED by the caller once (every launch leaves them zero again), then 256 KiB slots for partial tiles.  With it
+ *   - the persistent 8-phase launches (256-row tiles, more tiles than compute units) CLAIM their tiles from eight per-XCD queues whose heads are the
+ *     scheduler words (one returning atomic per tile, issued a tile ahead) instead of walking them in a fixed stride: a workgroup that becomes
+ *     resident late -- another kernel, e.g. a collective's channels on the reducer's stream, holds its compute unit -- finds the queues empty and
+ *     leaves, where the fixed stride would run its whole share as a second round (measured with mmdit_debug_occupy: DESIGN.md 5).  Which tiles exist
+ *     and what each computes does not depend on who claims it: results are bit-identical to the static walk;
+ *   - the partial tiles of a weight-gradient launch's split tail (k-major x k-major, fp32 out, K-decomposed) are stored to per-slice slots and summed
+ *     in slice order by the last slice to arrive (ticket counters) instead of being added with fp32 atomics -- faster (an atomic 256x256 partial costs
+ *     ~0.6 us of launch time), deterministic, and the outputs need no zero-fill (mmdit_gemm_zero_mask reports none); a launch that needs more slots
+ *     than fit falls back to atomics.
+ * This registration and mmdit_set_cu_budget are the library's only mutable state, both per device (hipSetDevice first).  Launches that use the
+ * workspace must be stream-ordered among themselves (one workspace per device; the scheduler words are handed out in a ring of 64 launches).
+ * ptr = NULL, bytes = 0 removes it (static tile walk, atomics).  bytes >= 8192 + 262144.  The library never allocates. */
 int mmdit_gemm_set_workspace(void* ptr, long long bytes);
-/* Compute units the GEMM launches may count on (default: all 256 of an MI355X).  The persistent GEMM kernels launch ONE workgroup per CU and size
- * their rounds / tile configuration for that number; a workgroup needs a whole CU (160 KiB of LDS), so while another kernel -- RCCL's collectives on the
- * reducer's side stream -- holds C compute units, a 256-workgroup launch runs as two rounds (measured with a stand-in kernel on 8 CUs: step 28.2 -> 36.4 ms,
- * tools/probes/cu_contention.py).  With a budget of 256 - C the planner and every persistent grid use 256 - C instead and the collectives' workgroups find
- * free CUs.  The reference has no counterpart (DDP leaves the split to the CUDA scheduler, model_trainer.py:224); model_trainer sets it when gradients are
- * reduced over more than one rank.  n: a multiple of 8 in [64, 256] (the XCD round-robin stays even); per device (hipSetDevice first); takes effect with the
- * next launch -- change it only while no captured graph of earlier launches is replayed. */
+/* Test / measurement aid: `wgs` (1..256) one-wave workgroups with 1 KiB of LDS each sleep-spin for `cycles` shader cycles on `stream` -- a stand-in for a
+ * long-running kernel (a collective's channels) that keeps 160-KiB GEMM workgroups off `wgs` compute units.  tests/test_kernels_gpu.py, tools/probes/cu_contention.py. */
+int mmdit_debug_occupy(int wgs, long long cycles, mmdit_stream_t stream);
+/* Compute units the GEMM launches may count on (default: all of the device's, hipDeviceAttributeMultiprocessorCount -- 256 on an MI355X).  The persistent
+ * GEMM kernels launch ONE workgroup per CU and the planner sizes rounds / tile configurations for that number; a workgroup needs a whole CU (144 - 160 KiB of
+ * LDS).  Round 6: launches with more tiles than workgroups claim their tiles dynamically (mmdit_gemm_set_workspace), so a kernel on another stream that
+ * holds C compute units -- RCCL's collectives on the reducer's side stream -- costs them C / 256 of their rate, not a second round; a budget of 256 - C
+ * additionally makes the planner size the ONE-round launches (the N = 768 projections of MMDiT-B: 249 tiles) for 256 - C.  The reference has no counterpart
+ * (DDP leaves the split to the CUDA scheduler, model_trainer.py:224).  model_trainer sets a budget only when MMDIT_RESERVED_CUS asks for one.
+ * n: a multiple of 8 in [64, CUs of the device] (the XCD round-robin stays even); per device (hipSetDevice first); takes effect with the next launch --
+ * change it only while no captured graph of earlier launches is replayed. */
 int mmdit_set_cu_budget(int n);
 int mmdit_get_cu_budget(void);
 /* Which kernel mmdit_gemm_grouped would launch for these problems (no launch): 64 = register-staged kernel (gemm.hip);

@@ -83,6 +83,7 @@ _SIGNATURES = {
     "mmdit_gemm_grouped": ([ctypes.POINTER(GemmArgs), _i, _vp], _i),
     "mmdit_gemm_plan": ([ctypes.POINTER(GemmArgs), _i], _i),
     "mmdit_gemm_set_workspace": ([_vp, ctypes.c_longlong], _i),
+    "mmdit_debug_occupy": ([_i, ctypes.c_longlong, _vp], _i),
     "mmdit_set_cu_budget": ([_i], _i),
     "mmdit_get_cu_budget": ([], _i),
     "mmdit_gemm_qkv_norm_rope": ([ctypes.POINTER(GemmArgs), ctypes.POINTER(QkEpilogue), _i, _i, _i, _vp, _vp, _vp, _vp], _i),
@@ -137,7 +138,7 @@ _SIGNATURES = {
     "mmdit_cast_multi": ([_vp, _vp, _vp, _i, _vp], _i),
 }
 ADAMW_CHUNK = 65536   # MMDIT_ADAMW_CHUNK
-ABI_VERSION = 7       # MMDIT_ABI_VERSION of include/mmdit_hip.h this binding mirrors
+ABI_VERSION = 8       # MMDIT_ABI_VERSION of include/mmdit_hip.h this binding mirrors
 # struct ids of mmdit_struct_size() -> ctypes mirrors (None: laid out with numpy record dtypes in optim.py / ops.py: 48 / 24 bytes)
 _STRUCTS = [("mmdit_gemm_args", GemmArgs), ("mmdit_ln_fwd_problem", LnFwdProblem), ("mmdit_ln_bwd_problem", LnBwdProblem),
             ("mmdit_qk_problem", QkProblem), ("mmdit_mlp_bwd_problem", MlpBwdProblem), ("mmdit_adamw_tensor", None), ("mmdit_cast_tensor", None), ("mmdit_qk_epilogue", QkEpilogue)]

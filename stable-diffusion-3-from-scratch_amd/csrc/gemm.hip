@@ -256,12 +256,33 @@ int check_problem(const mmdit_gemm_args* a) {
 //  seen by another)
 static void* g_ws[64] = {};
 static long long g_ws_bytes[64] = {};
-// compute units the persistent launches may count on, per device (0 = not set: all 256); mmdit_set_cu_budget
+// Scheduler page of the workspace (bytes [4096, 8192): 64 slots of 16 ints, zero-filled by the caller with the tickets): a launch that claims its
+// tiles dynamically (gemm8p.hip) takes the next slot round robin and leaves it zeroed.  Launches that use the workspace are stream-ordered (header),
+// so one slot would do; the ring keeps a launch on another stream from sharing the words of its 63 predecessors.
+static unsigned g_sched_next[64] = {};
+int* mmdit_gemm_sched_slot() {
+  const int dev = mmdit_current_device();
+  if (!g_ws[dev]) return nullptr;
+  return (int*)((char*)g_ws[dev] + 4096) + (g_sched_next[dev]++ & 63u) * 16;
+}
+// compute units the persistent launches may count on, per device (0 = not set: all of the device's); mmdit_set_cu_budget
 static int g_cu_budget[64] = {};
-extern "C" int mmdit_get_cu_budget(void) { const int n = g_cu_budget[mmdit_current_device()]; return n ? n : 256; }
+// compute units of the current device (hipDeviceAttributeMultiprocessorCount, read once per device; 256 = an MI355X when no device answers: the planner
+// also runs without one, mmdit_gemm_plan in the CPU tests)
+static int device_cus() {
+  static int cus[64] = {};
+  const int dev = mmdit_current_device();
+  if (!cus[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) { (void)hipGetLastError(); n = 256; }
+    cus[dev] = n / 8 * 8;      // (the XCD round-robin stays even)
+  }
+  return cus[dev];
+}
+extern "C" int mmdit_get_cu_budget(void) { const int n = g_cu_budget[mmdit_current_device()]; return n ? n : device_cus(); }
 extern "C" int mmdit_set_cu_budget(int n) {
-  MMDIT_CHECK_ARG(n >= 64 && n <= 256 && n % 8 == 0);
-  g_cu_budget[mmdit_current_device()] = n;
+  MMDIT_CHECK_ARG(n >= 64 && n <= device_cus() && n % 8 == 0);
+  g_cu_budget[mmdit_current_device()] = n == device_cus() ? 0 : n;
   return 0;
 }
 
@@ -492,7 +513,12 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
             const double load = (double)(nk_short + extra) / nk_max, c = (load > 1.0 ? load - 1.0 : 0.0) + (S > 1 ? 0.0028 * r * S : 0.0);
             if (c < bbest) { bbest = c; bS = S; brounds = rounds; }
           }
-          if (bbest < best) { tail_split = bS; gp.tail_first = first_short; gp.tail_rounds = brounds; gp.tail_G = G; }
+          // (round 6) with the workspace registered the 8-phase kernel CLAIMS its positions (gemm8p.hip): the workgroups whose first tile is short
+          // reach the tail first by themselves -- the split of this model is kept, its static assignment is not
+          if (bbest < best) {
+            tail_split = bS;
+            if (!g_ws[mmdit_current_device()]) { gp.tail_first = first_short; gp.tail_rounds = brounds; gp.tail_G = G; }
+          }
         }
       }
     }
@@ -522,7 +548,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   }
   // ... whose split tail goes through the registered workspace (mmdit_gemm_set_workspace) instead of fp32 atomics when it is large enough:
   // 4 KiB of tickets + one 256x256 fp32 slot per (tail tile, K slice)
-  gp.ws_slots = nullptr; gp.ws_count = nullptr;
+  gp.ws_slots = nullptr; gp.ws_count = nullptr; gp.sched = nullptr;
   gp.qk_on = 0; gp.qkQ = gp.qkK = gp.qkV = nullptr; gp.qk_heads = 0; gp.qk_s_total = 0;
   if (qkr) {
     // the fused QKV epilogue exists in the wide-slot lean kernel only, for one or two streams in the caller's order, [q | k | v] columns
@@ -542,9 +568,9 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
   if (kk && gp.split_k > 1) {
     const int dev = mmdit_current_device();
     const long long tail_tiles = tiles - full_tiles;
-    if (g_ws[dev] && tail_tiles <= 1024 && 4096 + tail_tiles * gp.split_k * 65536LL * 4 <= g_ws_bytes[dev]) {
+    if (g_ws[dev] && tail_tiles <= 1024 && 8192 + tail_tiles * gp.split_k * 65536LL * 4 <= g_ws_bytes[dev]) {
       gp.ws_count = (int*)g_ws[dev];
-      gp.ws_slots = (float*)((char*)g_ws[dev] + 4096);
+      gp.ws_slots = (float*)((char*)g_ws[dev] + 8192);
     }
   }
   if (zero_mask) {
@@ -608,11 +634,28 @@ extern "C" int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit
 }
 
 extern "C" int mmdit_gemm_set_workspace(void* ptr, long long bytes) {
-  MMDIT_CHECK_ARG((ptr == nullptr && bytes == 0) || (ptr != nullptr && bytes >= 4096 + 65536 * 4 && ((uintptr_t)ptr & 15) == 0));
+  MMDIT_CHECK_ARG((ptr == nullptr && bytes == 0) || (ptr != nullptr && bytes >= 8192 + 65536 * 4 && ((uintptr_t)ptr & 15) == 0));
   const int dev = mmdit_current_device();      // registered for the CURRENT device (hipSetDevice before the call)
   g_ws[dev] = ptr;
   g_ws_bytes[dev] = bytes;
   return 0;
+}
+
+// mmdit_debug_occupy: a stand-in for a long-running kernel on another stream (a collective's channels) -- `wgs` one-wave workgroups with 1 KiB of LDS each
+// (enough that a 160 KiB GEMM workgroup cannot share their compute unit) sleep-spin for `cycles` shader cycles.  tests / tools/probes/cu_contention.py.
+namespace {
+__global__ void occupy_kernel(long long cycles, int* sink) {
+  __shared__ int pad[256];
+  pad[threadIdx.x & 255] = threadIdx.x;
+  const long long t0 = __builtin_readcyclecounter();
+  while ((long long)__builtin_readcyclecounter() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+  if (cycles < 0) sink[0] = pad[0];
+}
+}  // namespace
+extern "C" int mmdit_debug_occupy(int wgs, long long cycles, mmdit_stream_t stream) {
+  MMDIT_CHECK_ARG(wgs >= 1 && wgs <= 256 && cycles >= 0 && cycles <= (1ll << 36));
+  hipLaunchKernelGGL(occupy_kernel, dim3(wgs), dim3(64), 0, (hipStream_t)stream, cycles, (int*)nullptr);
+  return mmdit_launch_status();
 }
 
 extern "C" int mmdit_gemm_plan(const mmdit_gemm_args* args, int count) { return gemm_grouped_impl(args, count, nullptr, true); }

@@ -581,6 +581,64 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   }
   end = __builtin_amdgcn_readfirstlane(end);
 
+  // ---- dynamic tile claiming (round 6; gp.sched != nullptr: every 256-row launch with more work positions than workgroups) -------------------
+  // A persistent workgroup needs a whole CU (its 8 waves hold all 512 registers of every SIMD), so while another kernel (a collective's channels)
+  // holds C compute units C of the G workgroups of this grid become resident only when others leave.  With the static walk (workgroup b: positions
+  // b, b + G, ...) their whole share then runs as a second round.  Here the positions are CLAIMED: queue q (one per XCD, so that the L2-contiguous
+  // tile ranges survive) holds the positions q, q + 8, ... in order; a workgroup pops a queue with one returning agent-scope atomic add on its head
+  // (sched[q]) -- its own XCD's first, then whichever it last found work in -- and looks at the others' heads once that one is empty, so a late
+  // workgroup finds nothing left and leaves.  Which positions exist, and what they compute, is fixed by the planner: results do not depend on who
+  // claims what.
+  //   * the atomic is issued by one lane from inline asm (the compiler neither counts nor waits for it) at the START OF THE LAST PAIR OF K TILES of
+  //     the current item (~3 us before its end: MI355X_MICROARCH.md "dequeue" 0.3 - 1.1 us) and its return sits in one register until the main loop's
+  //     final vmcnt(0): no exposed latency, and a workgroup commits to its next position only ~3 us before it can start it;
+  //   * the first position is claimed by the kernel's first instructions and taken after the set-up arithmetic;
+  //   * the claimed position reaches the other waves through one LDS word of the (then idle) operand buffers, two barriers;
+  //   * a workgroup that finds nothing counts itself out (sched[8]) before its last epilogue; the last one to leave zeroes the nine words: the next
+  //     launch that uses this slot finds it clean (no memset node, nothing for the host to do).
+  // (320-row tiles keep the static walk: the scalars this adds to what is live across the main loop cost the <320, swiglu> kernel six scratch
+  //  reloads inside it.)
+  int* const sq = gp.sched;
+  const bool dyn = MT == 256 && sq != nullptr;      // (kernel-uniform; 320-row tiles: never -- see launch8)
+  const int xq = (int)blockIdx.x & (NXCD - 1);
+  char* const s_next = smem + 16;      // (byte 0: the split tail's ticket)
+  uint32_t claim_v = 0;                // wave 0, lane 0: what the last claim_issue returned (the word's value before the add)
+  auto claim_issue = [&](int q) {      // q (wave-uniform): a queue, or NXCD = the count of workgroups that have left
+    if (wave == 0) {
+      uint64_t sv;
+      asm volatile("s_nop 4\n\ts_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                   : "=&v"(claim_v), "=&s"(sv)
+                   : "v"((uint32_t)(q * 4)), "v"(1u), "s"(sq)
+                   : "memory");
+    }
+  };
+  auto claim_take = [&](int q) -> int {      // every thread calls it, operand buffers idle; returns a position or `end`
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim_v)::"memory");      // (behind the main loop's own vmcnt(0): free)
+    if (tid == 0) {
+      int got = (int)claim_v * NXCD + q;
+      if (got >= end) {      // queue q is empty: the others, after a look at their heads (an exhausted queue stays exhausted: it costs a load, not an atomic)
+        got = end;
+        int hd[NXCD];
+#pragma unroll
+        for (int t = 1; t < NXCD; t++) hd[t] = __hip_atomic_load(sq + ((q + t) & (NXCD - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int t = 1; t < NXCD; t++) {
+          const int qq = (q + t) & (NXCD - 1);
+          if (got == end && hd[t] * NXCD + qq < end) {
+            const int p = atomicAdd(sq + qq, 1) * NXCD + qq;
+            if (p < end) got = p;
+          }
+        }
+      }
+      *LDS_PTR(int, s_next) = got;
+    }
+    LGKM0(); BAR8();
+    const int r = *LDS_PTR(const volatile int, s_next);
+    LGKM0(); BAR8();
+    return __builtin_amdgcn_readfirstlane(r);
+  };
+  if (dyn) claim_issue(xq);            // the first position: its latency lies under the set-up arithmetic below
+
   // ---- fragment read offsets inside a half-tile (bytes) ---------------------------------------------------------------------------------
   // row-major: fragment (16 rows x 32 k) = row (lane & 15), 16 B at k chunk 4 ks + (lane >> 4): one ds_read_b128.  The chunk permutation only
   //            involves the row's low four bits, so fragment i of a quadrant is fragment 0 + i * 2048: ONE address register per k step.
@@ -1117,6 +1175,8 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     while ((long long)__builtin_readcyclecounter() < until) __builtin_amdgcn_s_sleep(8);
   }
 #endif
+  if (dyn) pos = claim_take(xq);
+  bool left = false;      // (workgroup-uniform) this workgroup has counted itself out
   Item item = item_at(gp, pos, end), prev = item;
   bool pending = false;
   bool streamed = false;      // (workgroup-uniform) this item's first stagings were requested by the previous item's main loop
@@ -1129,7 +1189,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
     }
     if constexpr (STREAM) {
       const Item nxt = item_at(gp, item.pos + G, end);      // (found again at the bottom of the loop: not kept alive across the main loop)
-      strm = nxt.valid && nxt.pi == item.pi && nkt >= 2 && (nkt & 1) == 0 && nxt.h1 > nxt.h0;
+      strm = !dyn && nxt.valid && nxt.pi == item.pi && nkt >= 2 && (nkt & 1) == 0 && nxt.h1 > nxt.h0;
 #ifdef MMDIT_PROBES
       if (gp.debug & 4096) strm = false;      // A/B: a prologue per item
 #endif
@@ -1145,6 +1205,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         }
       }
     }
+    // (dynamic claiming) the next position is claimed at the start of the item's last pair of K tiles (pair index tcl), from the queue this item came from
+    constexpr bool LATE = !DRAIN && !STREAM;      // (the experiment builds' loops have no claim point: they claim at the item's start)
+    const int qcl = item.pos & (NXCD - 1), tcl = dyn ? (LATE && nkt >= 2 ? (nkt - 2) & ~1 : -1) : -2;      // (workgroup-uniform; -2: never)
+    if (tcl == -1) claim_issue(qcl);      // (an item of fewer than two K tiles: now)
     if (nkt > 0 && !(STREAM && streamed)) {
       if constexpr (MX) sload(0, 0);      // (first: the scale dwords of K tile 0 are older than the stagings the first counted wait leaves in flight)
       // prologue: K tile 0 whole, three half-tiles of K tile 1 (in the order the loop continues; second argument: K tiles ahead)
@@ -1189,6 +1253,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         }
 #pragma unroll 1
         for (; t + 1 < nkt; t += 2) {
+          if (t == tcl) claim_issue(qcl);
           KTILE8X(0, true)
           KTILE8X(1, true)
         }
@@ -1203,6 +1268,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         }
 #pragma unroll 1
         for (; t + 1 < nkt; t += 2) {
+          if (t == tcl) claim_issue(qcl);
           KTILE8(0, true)
           KTILE8(1, true)
         }
@@ -1242,6 +1308,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
         __syncthreads();             // every wave has left the buffers (epilogue staging / the next prologue reuse them)
       }
     }
+    // (dynamic claiming) the next position -- before the epilogue: a workgroup that finds none counts itself out now, under its last epilogue
+    int npos = item.pos + G;
+    if (dyn) {
+      npos = claim_take(qcl);
+      if (npos == end) { claim_issue(NXCD); left = true; }
+    }
     if (DEFER) {
       prev = item; pending = true;
       if constexpr (DRAIN) {
@@ -1264,9 +1336,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       if (MT != 256) BAR8();       // (the staging lives in the operand buffers the next prologue overwrites)
     }
     streamed = STREAM && strm;
-    item = item_at(gp, item.pos + G, end);
+    item = item_at(gp, npos, end);
   }
   if (DEFER && pending) run_epilogue(prev);
+  if (dyn) {      // the last workgroup to leave resets the queues (every other one has made its last claim before it counted itself out)
+    if (!left) claim_issue(NXCD);      // (a workgroup that never found a position)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(claim_v)::"memory");
+    if (tid == 0 && (int)claim_v == G - 1) {
+#pragma unroll
+      for (int q = 0; q <= NXCD; q++) atomicExch(sq + q, 0);
+    }
+  }
 }
 
 template <int MT, bool A_KM, bool B_KM, int EPI, bool KT = false, bool MX = false, bool CONV = false, bool PT = false>
@@ -1281,7 +1361,14 @@ int launch8(const GroupParams& gp, hipStream_t s) {
   }
   const int work = total_work(gp);
   const int cu = mmdit_get_cu_budget();
-  const int grid = gp.persistent && work > cu ? cu : work;   // one persistent workgroup per CU (of the budget)
+  const bool persistent = gp.persistent && work > cu;
+  const int grid = persistent ? cu : work;   // one persistent workgroup per CU (of the budget)
+  if (MT == 256 && persistent && gp.tail_first < 0) {     // more positions than workgroups: claimed dynamically when the workspace is registered (mmdit_gemm_set_workspace)
+    GroupParams gq = gp;
+    gq.sched = mmdit_gemm_sched_slot();
+    hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gq);
+    return mmdit_launch_status();
+  }
   hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gp);
   return mmdit_launch_status();
 }

@@ -44,6 +44,10 @@ struct GroupParams {
   // sums the slots in slice order and writes C (deterministic; C needs no zero-fill).  nullptr: atomics.
   float* ws_slots;
   int* ws_count;
+  // Dynamic tile claiming (gemm8p.hip; round 6): 16 ints of the registered workspace -- [0, 8) the heads of the per-XCD queues (queue q holds the
+  // work positions q, q + 8, q + 16, ... < total_work in that order), [8] the count of workgroups that have left the launch (the last one zeroes all
+  // nine words: no memset node, nothing for the host to do between launches).  nullptr: the static walk (workgroup b takes b, b + G, b + 2 G, ...).
+  int* sched;
   // QKV epilogue (qk_on): problems 0 / 1 = image / text stream, C = the raw projection [q | k | v] as always, plus Q / K / V (batch, heads,
   // s_total, 64) bf16 written from the rounded raw values (Attention.py:130-135, 178-194, 258-261)
   QkEpi qk[2];

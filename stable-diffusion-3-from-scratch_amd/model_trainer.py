@@ -426,7 +426,7 @@ class model_trainer:
                 if self.grad_scaler is not None:
                     self.grad_scaler.update()
                 self._write_loss(loss)
-                self._graph_loss = loss      # (the capture-time tensor in the graph's private pool: diagnostics only, see tools/probes/graph_loss_probe*.py)
+                self._graph_loss = loss      # (the capture-time tensor in the graph's private pool: diagnostics only, see tools/probes/graph_loss_probe.py)
         except BaseException:
             self._abandon_capture()
             raise

@@ -180,11 +180,13 @@ def _variant(arr, n, outs):
     return f"gemm_dma_kernel<{_CFG[plan & 15]},{km},{tc},{ta}>" + ("+streamK" if plan & 16 else "") + ("+ktail" if plan & 32 else "") + ("+swiglu" if a.act == ACT_SWIGLU else "")
 
 
-# Workspace of the weight-gradient launches' split tail (mmdit_gemm_set_workspace): 4 KiB of zeroed tickets + 256 slots of 256 KiB, one per
-# DEVICE, allocated at the first K-decomposed launch on that GPU and kept for the life of the process (a captured hipGraph holds its address).
-# MMDIT_GEMM_WS=0: fp32 atomics instead (the round-2 path).
+# Workspace of the GEMM launches (mmdit_gemm_set_workspace): 4 KiB of zeroed tickets (split tails), 4 KiB of zeroed scheduler words (the heads of the
+# per-XCD tile queues the persistent 8-phase launches claim their tiles from -- csrc/gemm8p.hip "dynamic tile claiming"), then 512 slots of 256 KiB for
+# partial tiles: one per DEVICE, allocated at the first GEMM launch on that GPU and kept for the life of the process (a captured hipGraph holds its
+# address).  MMDIT_GEMM_WS=0: none -- static tile walk, fp32 atomics for the split tail (the round-2 path).
 _GEMM_WS = {}
 _GEMM_WS_ON = _lib.experiment("MMDIT_GEMM_WS", "1") != "0" and _lib.experiment("MMDIT_WGRAD_STREAM", "0") != "1"   # (one workspace: its launches must be stream-ordered -- not with the weight-gradient side stream)
+GEMM_WS_BYTES = 8192 + 512 * 65536 * 4
 
 
 def _ensure_gemm_workspace(device):
@@ -192,7 +194,7 @@ def _ensure_gemm_workspace(device):
         return
     if torch.cuda.is_current_stream_capturing():
         return          # (never allocate the workspace inside a capture: the eager warm-up steps do it)
-    ws = torch.zeros(4096 + 256 * 65536 * 4, dtype=torch.uint8, device=device)
+    ws = torch.zeros(GEMM_WS_BYTES, dtype=torch.uint8, device=device)
     with torch.cuda.device(device):       # the library keys the registration by the CURRENT device
         check(_lib.lib().mmdit_gemm_set_workspace(ws.data_ptr(), ws.numel()), "mmdit_gemm_set_workspace")
     _GEMM_WS[device] = ws
@@ -202,7 +204,7 @@ def gemm_grouped(problems):
     """problems: list of dicts of gemm() keyword arguments (plus 'A', 'B'), all of one kernel variant.
     One launch; returns the list of outputs."""
     n = len(problems)
-    if problems[0]["A"].is_cuda and (problems[0].get("stream_k") or problems[0].get("split_k", 1) > 1):
+    if problems[0]["A"].is_cuda:
         _ensure_gemm_workspace(problems[0]["A"].device)
     arr = (GemmArgs * n)()
     outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
@@ -251,6 +253,7 @@ def gemm_swiglu_bwd(problems):
         aux, out = q["aux"], q.get("out")
         if aux.data_ptr() % 16 or aux.stride(0) % 8 or aux.shape[-1] % 16 or (out is not None and (out.data_ptr() % 16 or out.stride(0) % 8)):
             return None
+    _ensure_gemm_workspace(problems[0]["A"].device)
     arr = (GemmArgs * n)()
     outs = [_fill_gemm(arr[i], **dict(problems[i], b_kmajor=True, act=ACT_SWIGLU_BWD)) for i in range(n)]
     if PROFILE is not None:
@@ -272,6 +275,7 @@ def gemm_qkv_norm_rope(problems, streams, heads, s_total, Q, K, V):
     streams[i] = (wq, wk, rope_cos | None, rope_sin | None, tokens per sample, joint position of token 0).  Returns the raw projections
     (kept for backward: q and k columns; the v columns are not written, V holds them) or None when the planner would not run these problems on the lean wide-slot kernel (caller: GEMM + row kernel)."""
     n = len(problems)
+    _ensure_gemm_workspace(problems[0]["A"].device)
     arr = (GemmArgs * n)()
     outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
     qk = (_lib.QkEpilogue * n)()

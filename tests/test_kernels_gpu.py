@@ -897,6 +897,76 @@ def test_gemm_cu_budget(ops, budget):
         assert L.mmdit_set_cu_budget(256) == 0
 
 
+def _claiming_cases(ops):
+    """The persistent launches of a block at MMDiT-B batch 64 (more tiles than compute units): forward Linear, SwiGLU up-projection, SwiGLU-backward data
+    gradient, a data gradient, and the block's eight weight gradients as one grouped launch.  Returns name -> thunk returning the launch's outputs."""
+    M, d, h = 26240, 768, 3072
+    A, W, W12, b12 = rnd(M, d, seed=1, dtype=torch.bfloat16), rnd(3 * d, d, seed=2, dtype=torch.bfloat16), rnd(2 * h, d, seed=3, scale=0.05, dtype=torch.bfloat16), rnd(2 * h, seed=4)
+    dY, W3, GU = rnd(M, d, seed=5, dtype=torch.bfloat16), rnd(d, h, seed=6, scale=0.05, dtype=torch.bfloat16), rnd(M, 2 * h, seed=7, dtype=torch.bfloat16)
+    dH = rnd(M, 2 * h, seed=8, dtype=torch.bfloat16)
+    probs = []
+    for i, (N, K) in enumerate([(3 * d, d), (d, d), (2 * h, d), (d, h)]):
+        for Mr in (16384, 9856):
+            probs.append(dict(A=rnd(Mr, N, seed=60 + 2 * i + (Mr == 9856), dtype=torch.bfloat16), B=rnd(Mr, K, seed=80 + 2 * i + (Mr == 9856), dtype=torch.bfloat16),
+                              a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
+    return {
+        "linear": lambda: [ops.gemm(A, W, out_dtype=torch.bfloat16)],
+        "swiglu": lambda: [ops.gemm(A, W12, bias=b12, act=ops.ACT_SWIGLU)],
+        "swiglu_bwd": lambda: ops.gemm_swiglu_bwd([dict(A=dY, B=W3, aux=GU)]),
+        "dgrad": lambda: [ops.gemm(dH, W12, b_kmajor=True, out_dtype=torch.bfloat16)],
+        "wgrad": lambda: ops.gemm_grouped(probs),
+    }
+
+
+def test_gemm_dynamic_tile_claiming_equals_the_static_walk(ops):
+    """csrc/gemm8p.hip "dynamic tile claiming": with the workspace registered the persistent 8-phase launches pop their tiles from per-XCD queues instead of
+    walking them in a fixed stride.  Which tiles exist and what each computes is the planner's: the bf16 outputs are BIT-IDENTICAL to the static walk
+    (no workspace), the weight gradients (whose split tail goes through fp32 atomics without the workspace) equal to rounding; launch after launch (the
+    queue heads are reset by the last workgroup to leave: thirty launches in a row through one scheduler-slot ring) the results do not change."""
+    from sd3_amd import _lib
+    L = _lib.lib()
+    cases = _claiming_cases(ops)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    dyn = {k: f() for k, f in cases.items()}            # (ops registers the workspace at its first launch)
+    ws = ops._GEMM_WS[dev]
+    assert int(ws[:8192].view(torch.int32).abs().sum()) == 0, "tickets / queue heads are left zero by every launch"
+    for _ in range(30):
+        for k, f in cases.items():
+            for a, b in zip(f(), dyn[k]):
+                assert torch.equal(a, b), k
+    assert int(ws[:8192].view(torch.int32).abs().sum()) == 0
+    torch.cuda.synchronize()
+    assert L.mmdit_gemm_set_workspace(None, 0) == 0
+    try:
+        for k, f in cases.items():      # (ops does not register again: it has done so once for this device)
+            for a, b in zip(f(), dyn[k]):
+                assert (torch.equal(a, b) if k != "wgrad" else rel(a, b) < 1e-5), k
+    finally:
+        torch.cuda.synchronize()
+        assert L.mmdit_gemm_set_workspace(ws.data_ptr(), ws.numel()) == 0
+
+
+@pytest.mark.parametrize("held", [8, 32])
+def test_gemm_dynamic_tile_claiming_beside_an_occupant_kernel(ops, held):
+    """A kernel on another stream holds `held` compute units (mmdit_debug_occupy: one-wave workgroups with a little LDS, the stand-in for a collective's
+    channels) while the persistent launches run: the workgroups that cannot become resident find the queues empty when they finally start.  Results are
+    bit-identical to the undisturbed launches (weight gradients included: their split tail is summed in slice order), and the heads are clean afterwards."""
+    from sd3_amd import _lib
+    L = _lib.lib()
+    cases = _claiming_cases(ops)
+    ref = {k: f() for k, f in cases.items()}
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k, f in cases.items():
+        assert L.mmdit_debug_occupy(held, int(3e-3 * 2.0e9), side.cuda_stream) == 0      # ~3 ms at ~2 GHz: longer than any of these launches
+        out = f()
+        torch.cuda.synchronize()
+        for a, b in zip(out, ref[k]):
+            assert torch.equal(a, b), k
+    dev = torch.device("cuda", torch.cuda.current_device())
+    assert int(ops._GEMM_WS[dev][:8192].view(torch.int32).abs().sum()) == 0
+
+
 @pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16),
                                              (9000, 1304, 256, torch.bfloat16)])     # (the last: ragged M and N tiles of the 8-phase kernel's per-tensor form)
 def test_gemm_fp8_operands(ops, M, N, K, out_dtype):
@@ -925,7 +995,7 @@ def test_gemm_zero_mask_marks_exactly_the_outputs_that_receive_atomics(ops, work
     per-slice slots, the last slice to arrive sums them) NO output needs a zero-fill, the result is the same and it is deterministic."""
     import ctypes
     from sd3_amd import _lib
-    ws = torch.zeros(4096 + 256 * 65536 * 4, dtype=torch.uint8, device="cuda") if workspace else None
+    ws = torch.zeros(8192 + 256 * 65536 * 4, dtype=torch.uint8, device="cuda") if workspace else None
     prev = ops._GEMM_WS.get(torch.device("cuda", torch.cuda.current_device()))
     assert _lib.lib().mmdit_gemm_set_workspace(ws.data_ptr() if workspace else None, ws.numel() if workspace else 0) == 0
     try:

@@ -31,6 +31,14 @@ CASES = [
 ]
 
 
+# fast (bf16) mode, measured: rel-L2 of the HIP forward vs the rounding-matched oracle, vs the fp32 reference golden (profiles/r06_parity_numbers.txt)
+FAST_MEASURED = {
+    "micro_plain": (2.897e-3, 6.902e-3), "micro_nulls": (2.163e-3, 6.362e-3), "micro_nonsquare": (3.284e-3, 7.316e-3),
+    "xs_plain": (2.386e-3, 5.603e-3), "xs_gemma30_nulls": (1.830e-3, 4.725e-3), "xs_nonsquare": (1.442e-3, 4.312e-3),
+    "b_plain": (4.584e-3, 8.670e-3),
+}
+
+
 def rel(a, b):
     a, b = a.double().cpu(), b.double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
@@ -105,10 +113,12 @@ def test_forward_fast_mode_vs_rounding_matched_oracle(case, golden_dir):
         ref = O.forward(sd, O.OracleConfig(**CONFIGS[case[1]], attn_core="flash_bf16", gemm="bf16"), x.clone(), t, c.clone(), cp.clone(), *nl)
     r, r_ref = rel(v, ref), rel(v, torch.from_numpy(gold["v"]))
     print(f"[fast] {case[0]}: rel-L2 vs rounding-matched oracle = {r:.3e}; vs fp32 reference golden = {r_ref:.3e}")
-    # bf16 rounding decisions flip chaotically under ~1e-6 perturbations, so two bf16 pipelines with
-    # identical rounding POINTS still differ at the few-1e-3 level through depth; the bar below is the
-    # distance of either of them to the fp32 reference.
-    assert r < 6e-3 and r_ref < 1.5e-2
+    # bf16 rounding decisions flip chaotically under ~1e-6 perturbations, so two bf16 pipelines with identical rounding POINTS still differ at the
+    # few-1e-3 level through depth.  Per-case bars = 1.5 x the measured distances (FAST_MEASURED: this round's GPU run, printed above on every run), so
+    # that a regression of one case is not hidden by the widest one; the per-stage / per-block tests (test_trained_shape_gpu.py) pin the rounding points.
+    m, m_ref = FAST_MEASURED[case[0]]
+    print(f"[fast] {case[0]}: bars {1.5 * m:.2e} / {1.5 * m_ref:.2e}")
+    assert r < 1.5 * m and r_ref < 1.5 * m_ref
 
 
 def test_b_depth_parity_at_the_reference_noise_floor(golden_dir):

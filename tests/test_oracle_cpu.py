@@ -221,11 +221,11 @@ def test_library_exports_every_declared_symbol():
     import sd3_amd  # noqa: F401
     from sd3_amd import _lib
     declared = _lib.declared_symbols()
-    assert len(declared) >= 59 and set(declared) == set(_lib._SIGNATURES)
+    assert len(declared) >= 60 and set(declared) == set(_lib._SIGNATURES)
     L = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s
-    assert _lib.lib().mmdit_abi_version() == _lib.ABI_VERSION == 7 and _lib.lib().mmdit_struct_size(0) == ctypes.sizeof(_lib.GemmArgs) and _lib.lib().mmdit_build_arch() == b"gfx950"
+    assert _lib.lib().mmdit_abi_version() == _lib.ABI_VERSION == 8 and _lib.lib().mmdit_struct_size(0) == ctypes.sizeof(_lib.GemmArgs) and _lib.lib().mmdit_build_arch() == b"gfx950"
 
 
 def test_8_phase_gemm_kernels_have_no_scratch_access_in_their_k_loop():

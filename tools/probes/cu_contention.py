@@ -1,5 +1,5 @@
 """What a long-running kernel that holds C compute units (a collective's channels) does to the training step, whose persistent GEMM launches assume all 256.
-An `occupy` kernel (tools/probes/occupy.hip: C one-wave workgroups with a little LDS, spinning) runs on a side stream for the whole step; the step is timed
+An `occupy` kernel (mmdit_debug_occupy, formerly tools/probes/occupy.hip: C one-wave workgroups with a little LDS, spinning) runs on a side stream for the whole step; the step is timed
 (hipGraph replay) for C = 0 / 8 / 16 / 32, and -- with MMDIT_CU_BUDGET support -- again with the GEMM grids capped at 256 - C.
 python tools/probes/cu_contention.py"""
 import ctypes
@@ -17,8 +17,15 @@ from sd3_amd import _lib  # noqa: E402
 from sd3_amd.model_trainer import model_trainer  # noqa: E402
 from sd3_amd.models.diff_model import diff_model  # noqa: E402
 
-occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "liboccupy.so"))
-occ.occupy.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+if hasattr(_lib.lib(), "mmdit_debug_occupy"):      # (round 6: the occupant kernel is a library entry point)
+    def occupy(wgs, cycles, stream):
+        return _lib.lib().mmdit_debug_occupy(wgs, cycles, stream)
+else:
+    occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "liboccupy.so"))
+    occ.occupy.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+
+    def occupy(wgs, cycles, stream):
+        return occ.occupy(wgs, cycles, stream)
 dev = torch.device("cuda:0")
 torch.manual_seed(1234)
 net = diff_model(inCh=16, class_dim=768, patch_size=2, hidden_scale=4.0, attn_type="softmax_flash", MLP_type="swiglu", device=dev, positional_encoding="RoPE2d",
@@ -48,16 +55,17 @@ def run(C, budget, steps=6):
     t0 = time.perf_counter()
     for _ in range(steps):
         if C:
-            occ.occupy(C, int(26e-3 * 2.0e9), ctypes.c_void_p(side.cuda_stream))      # ~26 ms at ~2 GHz: the whole step
+            occupy(C, int(26e-3 * 2.0e9), ctypes.c_void_p(side.cuda_stream))      # ~26 ms at ~2 GHz: the whole step
         step[0] += 1
         tr.train_step(step[0])
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
 
-for C in (0, 8, 16, 32):
+only = [int(a) for a in sys.argv[1:] if a.isdigit()]      # e.g. `cu_contention.py 8` under rocprofv3: that occupancy only, no budget leg
+for C in (only or (0, 8, 16, 32)):
     line = f"occupied CUs {C:2d}: step {run(C, 256):7.2f} ms with 256-workgroup persistent grids"
-    if has_budget and C:
+    if has_budget and C and not only:
         line += f", {run(C, 256 - C):7.2f} ms with the grids capped at {256 - C}"
     print(line, flush=True)
 if has_budget:

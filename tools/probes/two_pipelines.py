@@ -68,8 +68,8 @@ del one
 torch.cuda.empty_cache()
 
 L.mmdit_set_cu_budget(budget)
-wsA = torch.zeros(4096 + 256 * 65536 * 4, dtype=torch.uint8, device=dev)
-wsB = torch.zeros(4096 + 256 * 65536 * 4, dtype=torch.uint8, device=dev)
+wsA = torch.zeros(8192 + 256 * 65536 * 4, dtype=torch.uint8, device=dev)
+wsB = torch.zeros(8192 + 256 * 65536 * 4, dtype=torch.uint8, device=dev)
 a, b = build(32, 2), build(32, 3)
 warm_and_capture(a, wsA)
 warm_and_capture(b, wsB)
