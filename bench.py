@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--torch-optimizer", action="store_true", help="development A/B: torch's multi-tensor unscale/clip/AdamW kernels instead of the three HIP launches")
+    ap.add_argument("--no-autotune", action="store_true", help="N > 1: keep the reducer's default settings instead of the voted warm-up A/B")
     ap.add_argument("--force-dist", action="store_true", help="development: run the N>1 code path (RCCL group + gradient reducer) with one rank")
     ap.add_argument("--graph", action="store_true", help="(default) replay the optimizer step from a hipGraph captured after the warm-up; with this flag a failed capture is an error instead of an eager fallback")
     ap.add_argument("--eager", action="store_true", help="issue every launch of every step from the host")
@@ -222,6 +223,11 @@ def main():
     for _ in range(args.warmup):
         step += 1
         trainer.train_step(step)
+    # data parallel: the first N > 1 run tunes itself -- bucket algorithm and CU reserve by a voted A/B over eager warm-up steps (model_trainer.autotune_reducer);
+    # the table goes into the JSON line (`reducer_autotune`).  --no-autotune keeps the defaults (allreduce, fp32 wire, 32 reserved CUs).
+    autotune = None
+    if trainer.reducer.enabled and not args.no_autotune:
+        step, autotune = trainer.autotune_reducer(step)
     # The timed steps replay a hipGraph of the whole optimizer step (forward + backward + per-block gradient all-reduce on its side
     # stream + clip + AdamW, ~430 launches, one host call per step): the eager step needs ~26 ms of host enqueue per 30 ms of GPU
     # work, so any host jitter stalls the GPU -- and with N ranks every stall is propagated to all of them by the next collective.
@@ -376,6 +382,11 @@ def main():
             out["roofline"] = roofline
         if clocks is not None:
             out["clocks"] = clocks
+        if trainer.reducer.enabled:
+            out["reducer"] = {"algorithm": trainer.reducer.algorithm, "wire": "bf16" if trainer.reducer.wire_dtype == torch.bfloat16 else "fp32",
+                              "reserved_cus": trainer.reserved_cus}
+        if autotune is not None:
+            out["reducer_autotune"] = autotune
         if allreduce is not None:
             out.update(allreduce)      # allreduce_total_ms / allreduce_exposed_ms / buckets_per_step (eager steps, per step)
         if world == 1 and not args.no_cpu_baseline:

@@ -155,6 +155,7 @@ __device__ __forceinline__ s16x4 lds_tr16(const void* p) { return __builtin_amdg
 #define MMDIT_PRIO(x) do { } while (0)
 #endif
 
+int mmdit_device_cus();                         // gemm.hip: compute units of the current device (a multiple of 8; 256 when no device answers)
 int* mmdit_gemm_sched_slot();                   // gemm.hip: the next 16-int slot of the registered workspace's scheduler page (nullptr: no workspace -> static tile walk)
 extern "C" int mmdit_get_cu_budget(void);      // compute units the persistent GEMM launches may count on (gemm.hip; include/mmdit_hip.h mmdit_set_cu_budget)
 static inline int mmdit_launch_status() {

@@ -269,7 +269,7 @@ int* mmdit_gemm_sched_slot() {
 static int g_cu_budget[64] = {};
 // compute units of the current device (hipDeviceAttributeMultiprocessorCount, read once per device; 256 = an MI355X when no device answers: the planner
 // also runs without one, mmdit_gemm_plan in the CPU tests)
-static int device_cus() {
+int mmdit_device_cus() {
   static int cus[64] = {};
   const int dev = mmdit_current_device();
   if (!cus[dev]) {
@@ -279,10 +279,10 @@ static int device_cus() {
   }
   return cus[dev];
 }
-extern "C" int mmdit_get_cu_budget(void) { const int n = g_cu_budget[mmdit_current_device()]; return n ? n : device_cus(); }
+extern "C" int mmdit_get_cu_budget(void) { const int n = g_cu_budget[mmdit_current_device()]; return n ? n : mmdit_device_cus(); }
 extern "C" int mmdit_set_cu_budget(int n) {
-  MMDIT_CHECK_ARG(n >= 64 && n <= device_cus() && n % 8 == 0);
-  g_cu_budget[mmdit_current_device()] = n == device_cus() ? 0 : n;
+  MMDIT_CHECK_ARG(n >= 64 && n <= mmdit_device_cus() && n % 8 == 0);
+  g_cu_budget[mmdit_current_device()] = n == mmdit_device_cus() ? 0 : n;
   return 0;
 }
 

@@ -1360,16 +1360,18 @@ int launch8(const GroupParams& gp, hipStream_t s) {
     mmdit_device_mark(attr_done);
   }
   const int work = total_work(gp);
-  const int cu = mmdit_get_cu_budget();
+  const int cu = mmdit_get_cu_budget();      // what the planner counted on
   const bool persistent = gp.persistent && work > cu;
-  const int grid = persistent ? cu : work;   // one persistent workgroup per CU (of the budget)
-  if (MT == 256 && persistent && gp.tail_first < 0) {     // more positions than workgroups: claimed dynamically when the workspace is registered (mmdit_gemm_set_workspace)
+  if (MT == 256 && persistent && gp.tail_first < 0) {
+    // more positions than the budget's workgroups: claimed dynamically when the workspace is registered (mmdit_gemm_set_workspace) -- on the WHOLE device:
+    // a workgroup whose compute unit is taken starts late, finds the queues empty and leaves; one whose compute unit is free does its share
     GroupParams gq = gp;
     gq.sched = mmdit_gemm_sched_slot();
+    const int all = mmdit_device_cus(), grid = gq.sched ? (work < all ? work : all) : cu;
     hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gq);
     return mmdit_launch_status();
   }
-  hipLaunchKernelGGL(k, dim3(grid), dim3(512), smem, s, gp);
+  hipLaunchKernelGGL(k, dim3(persistent ? cu : work), dim3(512), smem, s, gp);
   return mmdit_launch_status();
 }
 

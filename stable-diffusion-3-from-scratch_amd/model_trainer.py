@@ -87,6 +87,19 @@ def loss_is_plausible(loss, window=LOSS_WINDOW):
     return math.isfinite(v) and window[0] < v < window[1]
 
 
+def vote_fastest(local_ms, group=None, device=None):
+    """The collective half of a warm-up A/B: every rank brings its own timings of the same candidates (local_ms[i], milliseconds), the ranks take
+    the element-wise MAX (a step is as slow as its slowest rank), and every rank returns the same (index of the smallest maximum -- the first one
+    on ties --, list of the maxima).  One all-reduce; without a process group the local timings decide."""
+    t = torch.tensor([float(x) for x in local_ms], dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "nccl":
+            t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    worst = [float(x) for x in t.cpu()]
+    return min(range(len(worst)), key=lambda i: (worst[i], i)), worst
+
+
 class SyntheticData:
     """Synthetic (x0, text, pooled) batches shaped like the loader-GPU wire format (model_trainer.py:353-355):
     bf16 latents (B,16,res/8,res/8), bf16 text (B,154,2304) with Gemma-like large variance on tokens 0..76 and
@@ -134,7 +147,7 @@ class model_trainer:
                  bucket_indices_path=None, data_parquet_folder=None, max_res=256,
                  data_source=None, device_rng=False, use_ema=True, fused_optimizer=True, log_file=None, force_reducer=False,
                  fused_unscale_clip=True, ema_on_gpu=True, hip_optimizer=True, async_checkpoint=True, inf_padded_latents=False, loss_scaling=True,
-                 graph_after=None, hip_loss=True):
+                 graph_after=None, hip_loss=True, reserved_cus=None, autotune=None):
         self.batchSize, self.accumulation_steps, self.totalSteps = batchSize, accumulation_steps, totalSteps
         self.ema_update_freq, self.ema_decay = ema_update_freq, ema_decay
         self.saveDir, self.numSaveSteps, self.log_steps = saveDir, numSaveSteps, log_steps
@@ -161,17 +174,23 @@ class model_trainer:
         self.dev = self.model.dev
         broadcast_parameters(self.model)
         self.reducer = GradReducer(self.subgroup, force=force_reducer)
+        self.reserved_cus, self.autotune_table = 0, None
+        self.autotune = (os.environ.get("MMDIT_REDUCE_AUTOTUNE", "1") != "0") if autotune is None else bool(autotune)      # train(): warm-up A/B of the reducer settings (world > 1)
         if self.reducer.enabled:
-            # Compute units left to the collectives' kernels (MMDIT_RESERVED_CUS, default 0 = none): the persistent GEMM launches assume one
-            # workgroup per CU on all 256 and a workgroup needs a whole CU, so while RCCL's channels hold C of them such a launch runs as TWO
-            # rounds.  Measured with a stand-in kernel that holds C CUs for the whole step (tools/probes/cu_contention.py, MMDiT-B batch 64):
-            # C = 8: 27.1 -> 34.8 ms, 30.7 ms with the GEMM grids capped at 248; C = 16: 33.7 / 31.6; C = 32: 33.7 / 32.2.  How many CUs RCCL's
-            # all-reduce takes on an 8-GPU xGMI node (and for how much of the backward) could not be measured here -- set it together with
-            # NCCL_MAX_NCHANNELS on real hardware.  Takes effect with the next launch; must not change once a step has been captured.
-            reserved = int(os.environ.get("MMDIT_RESERVED_CUS", "0"))
-            if reserved > 0 and self.device.type == "cuda":
+            # Compute units the backward's GEMM planner leaves to the collectives' kernels (constructor `reserved_cus`, else MMDIT_RESERVED_CUS, default 32
+            # when gradients are reduced, 0 = plan for the whole chip).  A persistent GEMM workgroup needs a whole CU, so while RCCL's channels hold C of them
+            # C workgroups of a launch start late.  Round 6: the multi-round launches CLAIM their tiles (csrc/gemm8p.hip), so late workgroups cost C / 256 of
+            # the rate instead of a second round; what the reserve changes is the DECOMPOSITION of the backward's launches (diff_model._MMDiTFn.backward sets
+            # the planner's budget to CUs - reserve around engine.model_bwd): the weight gradients' split tail and the one-round data gradients are cut so that
+            # any number of workgroups between the budget and the whole chip stays busy.  The grids still cover every CU.  How many CUs RCCL's all-reduce
+            # takes on an 8-GPU xGMI node could not be measured here (tools/probes/cu_contention.py measures a stand-in); frozen with a captured step.
+            if reserved_cus is None:
+                reserved_cus = int(os.environ.get("MMDIT_RESERVED_CUS", "32"))
+            self.reserved_cus = max(0, int(reserved_cus)) // 8 * 8
+            if self.reserved_cus > 0 and self.device.type == "cuda":
                 from . import _lib
-                _lib.check(_lib.lib().mmdit_set_cu_budget(max(64, (256 - reserved) // 8 * 8)), "mmdit_set_cu_budget")
+                cus = _lib.lib().mmdit_get_cu_budget()
+                self.model.bwd_cu_budget = max(64, cus - self.reserved_cus)
             if hasattr(self.model, "grad_reducer"):
                 self.model.grad_reducer = self.reducer           # overlapped: fired from the backward schedule
             else:
@@ -468,6 +487,69 @@ class model_trainer:
             raise err
         return ok_all
 
+    def autotune_reducer(self, step, steps_each=2, candidates=None, run_step=None):
+        """Warm-up A/B of the data-parallel settings nobody could measure in advance (no multi-GPU node was available to the builder): the bucket
+        algorithm of the reducer (allreduce / rs_ag / direct; + direct with a bf16 wire only when MMDIT_REDUCE_TUNE_WIRE=1 -- it rounds the averaged
+        gradients) and the compute units the weight-gradient planner leaves to the collectives (reserved_cus in {0, 16, 32}).  Every candidate runs
+        `steps_each` EAGER optimizer steps -- real training steps on fresh batches, nothing is thrown away -- timed on the host between device
+        synchronisations; the ranks vote (vote_fastest: MAX over ranks per candidate, then the minimum) so that all of them continue with the same
+        setting.  Two rounds: algorithms at the current reserve, then reserves at the winning algorithm.  Call before capture_graph (the choice is frozen
+        into the captured step).  Returns (next step, table) with table = {"algorithm": {...ms}, "reserved_cus": {...ms}, "chosen": {...}}; a no-op
+        (step, None) when gradients are not reduced."""
+        import sys
+        if not self.reducer.enabled:
+            return step, None
+        if self._graph is not None:
+            raise RuntimeError("autotune_reducer: call it before the step is captured")
+        run = run_step or self.train_step
+        cuda = self.device.type == "cuda"
+
+        def time_candidate(apply):
+            nonlocal step
+            apply()
+            step += 1
+            run(step)                      # (first step with a new setting: buffers of that algorithm are allocated here)
+            if cuda:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps_each):
+                step += 1
+                run(step)
+            if cuda:
+                torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps_each * 1e3
+
+        def set_algo(a, w):
+            def f():
+                self.reducer.algorithm, self.reducer.wire_dtype = a, w
+            return f
+
+        def set_reserve(r):
+            def f():
+                self.reserved_cus = r
+                if cuda and hasattr(self.model, "bwd_cu_budget"):
+                    from . import _lib
+                    self.model.bwd_cu_budget = max(64, _lib.lib().mmdit_get_cu_budget() - r) if r > 0 else None
+            return f
+
+        algos = candidates or [("allreduce", None), ("rs_ag", None), ("direct", None)]
+        if candidates is None and os.environ.get("MMDIT_REDUCE_TUNE_WIRE", "") == "1":
+            algos.append(("direct", torch.bfloat16))
+        name = lambda a, w: a + ("+bf16" if w == torch.bfloat16 else "")
+        ms = [time_candidate(set_algo(a, w)) for a, w in algos]
+        best, worst = vote_fastest(ms, self.subgroup, self.device)
+        set_algo(*algos[best])()
+        table = {"algorithm": {name(a, w): round(t, 3) for (a, w), t in zip(algos, worst)}}
+        reserves = sorted({0, 16, 32, int(self.reserved_cus)})
+        ms = [time_candidate(set_reserve(r)) for r in reserves]
+        rbest, rworst = vote_fastest(ms, self.subgroup, self.device)
+        set_reserve(reserves[rbest])()
+        table["reserved_cus"] = {str(r): round(t, 3) for r, t in zip(reserves, rworst)}
+        table["chosen"] = {"algorithm": name(*algos[best]), "reserved_cus": reserves[rbest], "steps_each": steps_each}
+        print(f"[model_trainer rank {self.rank}/{self.world}] reducer auto-tune (ms per eager step, max over ranks): {json.dumps(table)}", file=sys.stderr, flush=True)
+        self.autotune_table = table
+        return step, table
+
     def _drop_graph(self):
         """Back to eager launches.  Batches drawn into the static slots that no replay has trained on yet (a capture that the ranks
         then voted down) are not thrown away: the next eager step trains on them."""
@@ -638,8 +720,22 @@ class model_trainer:
         batch_loss, t0 = 0.0, time.time()
         replay_checks = 0
         opt_steps = self.start_step // self.accumulation_steps
-        for step in range(opt_steps, self.totalSteps):
-            if self.graph_after is not None and self._graph is None and step - opt_steps == max(3, self.graph_after):
+        tuned = not (self.autotune and self.reducer.enabled and self.world > 1)
+        capture_tried = False
+        step = opt_steps
+        while step < self.totalSteps:
+            if not tuned and step - opt_steps >= 1:
+                # data parallel, after one step (allocations done): which bucket algorithm / CU reserve is fastest HERE -- a collective decision over real
+                # training steps (autotune_reducer: ~16 of them, counted; logging / checkpoint hooks resume behind them)
+                tuned = True
+                if self.totalSteps - step > 40:
+                    before = step
+                    step, _ = self.autotune_reducer(step)
+                    if self.ema_model_cpu is not None and step // self.ema_update_freq > before // self.ema_update_freq:
+                        self.update_ema()
+                    continue
+            if self.graph_after is not None and self._graph is None and not capture_tried and tuned and step - opt_steps >= max(3, self.graph_after):
+                capture_tried = True
                 if self.capture_graph_agreed(step + 1):      # (every rank reaches this line at the same step: the decision is collective)
                     replay_checks = 2
             loss = self.train_step(step + 1)
@@ -665,5 +761,6 @@ class model_trainer:
             if n % self.numSaveSteps == 0 and is_main_process():
                 self.save_checkpoint(n)
                 print("Saving model")
+            step += 1
         if self.ckpt_stream is not None:
             self.ckpt_stream.wait()

@@ -20,6 +20,7 @@ from ..blocks.Norm import Norm
 from ..blocks.PositionalEncoding import PositionalEncoding
 from ..blocks.Transformer_Block_Dual import Transformer_Block_Dual
 from ..packing import Pack
+from .. import ops
 
 
 class _MMDiTFn(torch.autograd.Function):
@@ -40,7 +41,17 @@ class _MMDiTFn(torch.autograd.Function):
         net, m = ctx.net, ctx.m
         W = net.weights(m)
         red = net.grad_reducer
-        g = engine.model_bwd(m, W, ctx.sv, dv, ctx.rope, on_grads=red.add_bucket if red is not None else None)
+        # Data parallel: the collectives of the reducer's side stream run beside THIS pass and hold compute units the GEMMs cannot share.  The weight-gradient
+        # launches (a block's eight, grouped: one round of whole-K tiles + a split tail) are then PLANNED for fewer compute units (net.bwd_cu_budget, set by
+        # model_trainer: ops.WGRAD_CU_BUDGET -> mmdit_set_cu_budget around those launches) while their grids still cover the device and claim their tiles
+        # (csrc/gemm8p.hip): measured beside an occupant of 8 CUs 7.05 -> 5.61 ms per step, alone 5.60 -> 5.92 (profiles/r06_robust_split_ab.txt).  Every
+        # other launch keeps the whole-chip plan: the same treatment of the one-round data gradients measured slower in both cases.  Frozen with a capture.
+        budget = getattr(net, "bwd_cu_budget", None)
+        before, ops.WGRAD_CU_BUDGET = ops.WGRAD_CU_BUDGET, (int(budget) if budget else None)
+        try:
+            g = engine.model_bwd(m, W, ctx.sv, dv, ctx.rope, on_grads=red.add_bucket if red is not None else None)
+        finally:
+            ops.WGRAD_CU_BUDGET = before
         ctx.sv = None
         out = {}
         net.scatter_grads(g, out)
@@ -129,6 +140,7 @@ class diff_model(nn.Module):
         self.precision = "fast"
         self._keep_saved = True
         self.grad_reducer = None   # set by model_trainer for data-parallel runs (sd3_amd.reducer.GradReducer)
+        self.bwd_cu_budget = None      # data parallel: compute units the backward's weight-gradient planner counts on (model_trainer reserved_cus)
         self._packs = NS(Wt=Pack([self.t_emb2.weight]), Wcond=Pack([self.cond_MLP.weight]), Wc1=Pack([self.c_proj.weight]),
                          Wc2=Pack([self.c_proj2.weight]), Wpatch=Pack([self.pos_enc.proj.weight]), Wpe=Pack([self.patch_emb.weight]),
                          Wmod_out=Pack([self.out_norm.c_shift.weight, self.out_norm.c_scale.weight]), Wout=Pack([self.out_proj.weight]))

@@ -200,7 +200,11 @@ def _ensure_gemm_workspace(device):
     _GEMM_WS[device] = ws
 
 
-def gemm_grouped(problems):
+# Data parallel (diff_model._MMDiTFn.backward): compute units the K-decomposed (weight-gradient) launches are planned for, None = the device's
+WGRAD_CU_BUDGET = None
+
+
+def _gemm_grouped(problems):
     """problems: list of dicts of gemm() keyword arguments (plus 'A', 'B'), all of one kernel variant.
     One launch; returns the list of outputs."""
     n = len(problems)
@@ -239,6 +243,21 @@ def gemm_grouped(problems):
         return outs
     check(_lib.lib().mmdit_gemm_grouped(arr, n, _s()), "mmdit_gemm_grouped")
     return outs
+
+
+def gemm_grouped(problems):
+    """problems: list of dicts of gemm() keyword arguments (plus 'A', 'B'), all of one kernel variant.  One launch; returns the list of outputs.
+    K-decomposed launches (stream_k: the weight gradients) are planned for WGRAD_CU_BUDGET compute units when that is set (zero mask and launch alike)."""
+    planned = WGRAD_CU_BUDGET if (WGRAD_CU_BUDGET and problems[0].get("stream_k") and problems[0]["A"].is_cuda) else None
+    if not planned:
+        return _gemm_grouped(problems)
+    L = _lib.lib()
+    whole = L.mmdit_get_cu_budget()
+    check(L.mmdit_set_cu_budget(min(planned, whole)), "mmdit_set_cu_budget")
+    try:
+        return _gemm_grouped(problems)
+    finally:
+        check(L.mmdit_set_cu_budget(whole), "mmdit_set_cu_budget")
 
 
 def gemm_swiglu_bwd(problems):

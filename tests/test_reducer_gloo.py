@@ -498,3 +498,75 @@ def test_launch_mode_is_agreed_across_ranks_and_falls_back_to_eager(fail_rank):
         assert all(l == l for l in losses)
     for a, b in zip(res[0][4], res[1][4]):
         assert (a == b).all(), "ranks diverged after the fallback"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The data-parallel settings nobody could measure in advance are chosen by a warm-up A/B whose result is a COLLECTIVE decision
+# (model_trainer.vote_fastest / autotune_reducer; bench.py and train() call it before the step is captured).
+def _autotune_worker(rank, world, port, q):
+    import time
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sd3_amd  # noqa: F401
+    from sd3_amd.model_trainer import vote_fastest
+    # the vote alone: rank r finds candidate (r mod 3) fastest, but candidate 1 has the smallest WORST time over the ranks
+    local = [10.0 + 5.0 * ((rank + k) % 3) for k in range(3)]
+    local[1] = 12.0 + 0.1 * rank
+    best, worst = vote_fastest(local)
+    net = _EngineLike()
+    tr = _make_trainer(net, 1, 3)
+    micro = [0]
+
+    def source():
+        x, t = _trainer_data(micro[0], rank, world, 3)
+        tr._t = t
+        micro[0] += 1
+        return x, torch.zeros(3, 154, 4), torch.zeros(3, 8)
+
+    tr.data_source = source
+    tr._sample_conditioning = lambda n: (tr._t, None, None, None)
+    tr.train_step(1)
+    # the whole A/B on the CPU trainer: every step is a real optimizer step; a rank- and setting-dependent sleep stands in for the link / CU effects.
+    # rs_ag is slowest on rank 0 only, direct is uniformly middling, allreduce is fastest on most ranks but very slow on rank 5 -> direct must win;
+    # reserves: 16 is best by the max over ranks although rank 2 prefers 0
+    algo_ms = {"allreduce": 2.0 + (30.0 if rank == 5 else 0.0), "rs_ag": 6.0 + (40.0 if rank == 0 else 0.0), "direct": 12.0}
+    res_ms = {0: 9.0 - (6.0 if rank == 2 else 0.0), 16: 4.0, 32: 8.0}
+
+    def run(step):
+        loss = tr.train_step(step)
+        time.sleep((algo_ms[tr.reducer.algorithm] + res_ms[tr.reserved_cus]) * 1e-3)
+        return loss
+
+    tr.reserved_cus = 32
+    step, table = tr.autotune_reducer(1, steps_each=2, run_step=run)
+    losses = [float(tr.train_step(s)) for s in (step + 1, step + 2)]      # the ranks go on in step with the chosen setting
+    q.put((rank, best, worst, step, table, tr.reducer.algorithm, tr.reserved_cus, losses, [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_reducer_autotune_is_a_collective_decision():
+    """world_size 8: vote_fastest returns the same winner (the smallest maximum over the ranks, not anybody's local favourite) and the same table on every
+    rank; autotune_reducer -- two timed optimizer steps per candidate on the CPU trainer, three algorithms then three reserves -- leaves all eight ranks on
+    the same algorithm and reserve, counts the steps it ran, and the replicas stay bit-identical through and after it."""
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_autotune_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    best0, worst0, step0, table0 = res[0][:4]
+    assert best0 == 1 and abs(worst0[1] - 12.7) < 1e-9 and worst0[0] == 20.0 and worst0[2] == 20.0
+    for r in range(world):
+        best, worst, step, table, algo, reserve, losses, params = res[r]
+        assert (best, worst, step, table) == (best0, worst0, step0, table0), "every rank holds the same table and winner"
+        assert algo == "direct" and reserve == 16 and table["chosen"] == {"algorithm": "direct", "reserved_cus": 16, "steps_each": 2}
+        assert step == 1 + 3 * 3 + 3 * 3                  # (1 settling + 2 timed steps for each of 3 algorithms and 3 reserves)
+        assert all(l == l for l in losses)
+        for a, b in zip(params, res[0][7]):
+            assert (a == b).all(), "ranks diverged"

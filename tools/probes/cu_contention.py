@@ -63,10 +63,16 @@ def run(C, budget, steps=6):
 
 
 only = [int(a) for a in sys.argv[1:] if a.isdigit()]      # e.g. `cu_contention.py 8` under rocprofv3: that occupancy only, no budget leg
+robust = "--robust" in sys.argv or not only                # (round 6) + the data-parallel trainer's setting: the BACKWARD planned for 224 CUs, whatever C is
 for C in (only or (0, 8, 16, 32)):
-    line = f"occupied CUs {C:2d}: step {run(C, 256):7.2f} ms with 256-workgroup persistent grids"
+    net.bwd_cu_budget = None
+    line = f"occupied CUs {C:2d}: step {run(C, 256):7.2f} ms with the whole-chip plan"
+    if robust and hasattr(_lib.lib(), "mmdit_debug_occupy"):
+        net.bwd_cu_budget = 224
+        line += f", {run(C, 256):7.2f} ms with the weight gradients planned for 224 CUs (model_trainer reserved_cus = 32: the data-parallel setting, no knowledge of C)"
+        net.bwd_cu_budget = None
     if has_budget and C and not only:
-        line += f", {run(C, 256 - C):7.2f} ms with the grids capped at {256 - C}"
+        line += f", {run(C, 256 - C):7.2f} ms with every launch planned AND capped at {256 - C}"
     print(line, flush=True)
 if has_budget:
     _lib.lib().mmdit_set_cu_budget(256)
