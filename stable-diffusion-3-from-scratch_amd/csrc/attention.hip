@@ -148,6 +148,18 @@ __device__ __forceinline__ void acc_to_lds(const f32x16 (&acc)[2], float* tile, 
       *LDS_PTR(f32x4, p + db * 32 + 8 * g) = (f32x4){acc[db][g * 4], acc[db][g * 4 + 1], acc[db][g * 4 + 2], acc[db][g * 4 + 3]};
   __builtin_amdgcn_wave_barrier();
 }
+// rows 16 half .. 16 half + 15 of the accumulator tile only, parked as rows 0 .. 15 of `tile16` (16 x QK_ROW_F floats)
+__device__ __forceinline__ void acc_to_lds_half(const f32x16 (&acc)[2], float* tile16, int lane, int half) {
+  if (((lane & 31) >> 4) == half) {
+    float* p = tile16 + (lane & 15) * QK_ROW_F + 4 * (lane >> 5);
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int g = 0; g < 4; g++)
+        *LDS_PTR(f32x4, p + db * 32 + 8 * g) = (f32x4){acc[db][g * 4], acc[db][g * 4 + 1], acc[db][g * 4 + 2], acc[db][g * 4 + 3]};
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ void lds_row8(const float* tile, int r, int c, float (&v)[8]) {
   const f32x4 a = *LDS_PTR(const f32x4, tile + r * QK_ROW_F + 8 * c), b = *LDS_PTR(const f32x4, tile + r * QK_ROW_F + 8 * c + 4);
 #pragma unroll
@@ -168,6 +180,7 @@ __device__ __forceinline__ float sum8(float x) {
 // features / output slot of the wave's row 0 (this head, this part), `pitch` elements between rows; nvalid rows of the 32 exist.
 // cs0 / sn0: RoPE factors of row 0's token (image rows; rows are consecutive tokens), nullptr for text rows.  Adds this wave's
 // norm-weight gradient into sdw[64] (LDS atomics from 8 lanes).
+template <int IT0 = 0, int IT1 = 4>      // passes [IT0, IT1) of 8 rows each (the one-pass backward parks 16 rows at a time: `tile` then points 16 * (IT0 / 2) rows in front of the parked ones)
 __device__ __forceinline__ void qk_bwd_tile(const float* tile, float mul, int lane, int nvalid, const bf16_t* x0, bf16_t* o0, int64_t pitch,
                                             const float* w, const float* cs0, const float* sn0, float* sdw) {
   const int c = lane & 7, rsub = lane >> 3;
@@ -178,9 +191,9 @@ __device__ __forceinline__ void qk_bwd_tile(const float* tile, float mul, int la
   // the four passes' raw rows are requested up front (16 registers as packed bf16): their latency overlaps the first pass
   u32x4 xr[4];
 #pragma unroll
-  for (int it = 0; it < 4; it++) xr[it] = __builtin_nontemporal_load((const u32x4*)(x0 + min(it * 8 + rsub, nvalid - 1) * pitch + 8 * c));   // (last use of the saved projection)
+  for (int it = IT0; it < IT1; it++) xr[it] = __builtin_nontemporal_load((const u32x4*)(x0 + min(it * 8 + rsub, nvalid - 1) * pitch + 8 * c));   // (last use of the saved projection)
 #pragma unroll
-  for (int it = 0; it < 4; it++) {
+  for (int it = IT0; it < IT1; it++) {
     const int r = it * 8 + rsub;
     const bool valid = r < nvalid;
     const int rc = valid ? r : nvalid - 1;
@@ -230,10 +243,11 @@ __device__ __forceinline__ void qk_bwd_tile(const float* tile, float mul, int la
   }
 }
 // dV rows: no arithmetic, the LDS round trip only makes the stores whole 128-byte rows
+template <int IT0 = 0, int IT1 = 4>
 __device__ __forceinline__ void rows_from_tile(const float* tile, int lane, int nvalid, bf16_t* o0, int64_t pitch) {
   const int c = lane & 7, rsub = lane >> 3;
 #pragma unroll
-  for (int it = 0; it < 4; it++) {
+  for (int it = IT0; it < IT1; it++) {
     const int r = it * 8 + rsub;
     float v[8];
     lds_row8(tile, r, c, v);
@@ -1031,6 +1045,246 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
 
 #ifdef MMDIT_PROBES
 // ------------------------------------------------------------------------------------------------
+// backward in ONE pass per (batch, head) for S <= 416 (round 6; MMDiT-B at 256^2: S = 410): one workgroup owns the whole problem.
+// EXPERIMENT (probes build, MMDIT_ATTN_ONEPASS=1) -- built, correct (tests/test_kernels_gpu.py::test_attention_bwd_with_fused_qk_norm_rope_backward passes on
+// it at S = 94 and 410, closer to autograd than the two kernels), and SLOWER: profiles/r06_attn_onepass_ab.txt.  MMDiT-B batch 64 (768 problems), one box:
+//     two kernels (dQ 110 + dK/dV 153)                           264 us
+//     this kernel                                                1508 us
+//     ... without the 32 ds_add_f32 per wave and 32-query block   237 us      (MMDIT_OP_DBG=1: the reduction of the eight waves' dQ partials is the whole loss)
+//     ... without dS^T park / transposed read / dQ MFMAs too      227 us      (MMDIT_OP_DBG=2)
+// LDS float atomics retire ~1 lane per 2 clocks on gfx950 (7168 wave instructions per workgroup = 423 us: ~140 clocks each), so the in-LDS reduction the
+// design rests on costs 5 x the kernel.  And the ceiling without ANY reduction is 237 us: 5 instead of 7 GEMM units buys 27 us of 264 once the dQ
+// epilogue, delta and the second pass's idle waves (13 key blocks on 8 waves) are paid -- every non-atomic reduction (partials staged through LDS and
+// added by owners: 150 KB of LDS traffic per 32-query step; full-K dQ by four owner waves from exchanged dS: +14 us and 32 KB of K tiles that do not
+// fit beside the accumulator) gives that back.  The two kernels stay the product.
+// Key-stationary like the dK/dV kernel above (a wave owns 32 keys: S / dP with lane = key, P / dS packed straight from the accumulators into the
+// dV^T / dK^T MFMAs), in two passes over the query tiles (13 key blocks on 8 waves) -- and dQ from the SAME dS instead of a second kernel that
+// recomputes S and dP: the wave parks its dS block transposed in a private LDS tile ([key][query], 80-byte rows), reads it back with
+// ds_read_b64_tr_b16 as the A operand of dQ[q][d] += dS[q][key] K[key][d] (B = the wave's K rows, transposed fragments held in registers), and adds
+// the 32 x 64 partial -- lane = feature, so an instruction covers 32 consecutive floats of two rows: conflict-free -- into an fp32 accumulator of the
+// whole dQ in LDS (416 x 68 floats, the layout qk_bwd_tile reads) with ds_add_f32.  No S / dP recomputation (5 instead of 7 GEMM units), Q / K / V /
+// dO / O are read once per pass from L2 instead of twice from HBM, delta = rowsum(dO O) is formed where the dO tile is parked.  The QK-norm / RoPE
+// backward epilogues are those of the two kernels above: dK / dV per pass (parked 16 rows at a time: the LDS left beside the dQ accumulator), dQ at the end
+// straight out of the accumulator.
+// ------------------------------------------------------------------------------------------------
+constexpr int OP_MAXB = 13;                                    // 32-row blocks of S
+constexpr int OP_DST = 80;                                     // byte pitch of a wave's dS^T tile (32 queries x 2 B + 16)
+constexpr int OP_DQ_BYTES = OP_MAXB * QK_WAVE_BYTES;           // 113152: the dQ accumulator
+constexpr int OP_R_DST0 = 2 * KT * 128 + 2 * KT * 4;           // 16896: Q tile, dO tile, lse, delta in front of the dS^T tiles
+constexpr int OP_R_BYTES = OP_R_DST0 + 8 * 32 * OP_DST;        // 37376 (>= 8 x 4 KB of K rows, >= 8 x 16 parked rows)
+constexpr int OP_LDS = OP_DQ_BYTES + OP_R_BYTES + 256 * 4;     // 151552
+
+__global__ __launch_bounds__(512) void attn_bwd_onepass_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K, const bf16_t* __restrict__ V,
+                                                               const bf16_t* __restrict__ Ox, const bf16_t* __restrict__ Oc,
+                                                               const bf16_t* __restrict__ dOx, const bf16_t* __restrict__ dOc, const float* __restrict__ lse,
+                                                               int BH, int H, int S, int n_img, float scale, QkFuse F, int dbg) {
+  constexpr int NT = 512;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  float* dqa = (float*)smem_dyn;
+  char* R = smem_dyn + OP_DQ_BYTES;
+  char* qtile = R;
+  char* dotile = R + KT * 128;
+  float* lse_s = (float*)(R + 2 * KT * 128);
+  float* del_s = lse_s + KT;
+  float* sdw = (float*)(smem_dyn + OP_DQ_BYTES + OP_R_BYTES);      // [q: image | text][64], [k: image | text][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  char* dst_w = R + OP_R_DST0 + wave * (32 * OP_DST);
+  int tile0, bh;
+  map_block(1, BH, tile0, bh);
+  const int h = bh % H;
+  const int64_t b = bh / H;
+  const bf16_t* Qb = Q + (int64_t)bh * S * HD;
+  const bf16_t* Kb = K + (int64_t)bh * S * HD;
+  const bf16_t* Vb = V + (int64_t)bh * S * HD;
+  const int n_txt = S - n_img, D = H * HD;
+  const int64_t pitch = 3 * (int64_t)D;
+  const int nkb = (S + 31) >> 5, nq = (S + KT - 1) / KT;
+
+  for (int i = tid; i < OP_DQ_BYTES / 16; i += NT) *LDS_PTR(f32x4, dqa + 4 * i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (tid < 256) sdw[tid] = 0.f;
+
+  u32x4 sq[1], sd[1], so[1];
+  float lv = 0.f;
+  auto request = [&](int jq) {
+    tile_g2r<NT>(sq, Qb, jq * KT, S, tid);
+    const int row = tid >> 3, kc = tid & 7, sidx = jq * KT + row;
+    const bf16_t* pd = sidx < S ? tok_ptr(dOx, dOc, b, sidx, n_img, n_txt, D, h) : nullptr;
+    const bf16_t* po = sidx < S ? tok_ptr(Ox, Oc, b, sidx, n_img, n_txt, D, h) : nullptr;
+    sd[0] = pd ? *(const u32x4*)(pd + kc * 8) : (u32x4){0, 0, 0, 0};
+    so[0] = (pd && po) ? *(const u32x4*)(po + kc * 8) : (u32x4){0, 0, 0, 0};
+    lv = 0.f;
+    if (tid < KT && jq * KT + tid < S) lv = lse[(int64_t)bh * S + jq * KT + tid];
+  };
+
+#pragma unroll 1
+  for (int pass = 0; pass * 8 < nkb; pass++) {
+    const int kblk = pass * 8 + wave;
+    const bool active = kblk < nkb;                                  // (wave-uniform)
+    const int key = kblk * 32 + (lane & 31), keyc = min(key, S - 1);
+    const bool ragged_keys = kblk * 32 + 32 > S;                     // (wave-uniform) this wave's block holds padding keys
+    __syncthreads();                                                 // R is free: the zero fill / the previous pass's epilogue is done
+    bf16x8 kf[4], vf[4], kt[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      kf[ks] = *(const bf16x8*)(Kb + (int64_t)keyc * HD + ks * 16 + (lane >> 5) * 8);
+      vf[ks] = *(const bf16x8*)(Vb + (int64_t)keyc * HD + ks * 16 + (lane >> 5) * 8);
+    }
+    {   // the wave's 32 K rows as a (swizzled) tile: its transposed fragments are the B operand of the dQ MFMAs
+      char* kw = R + wave * 4096;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int c = lane + 64 * i, row = c >> 3, kc = c & 7;
+        const u32x4 v = *(const u32x4*)(Kb + (int64_t)min(kblk * 32 + row, S - 1) * HD + kc * 8);
+        *LDS_PTR(u32x4, kw + row * 128 + ((kc ^ sw2(row)) << 4)) = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int h8 = 0; h8 < 2; h8++)
+#pragma unroll
+        for (int db = 0; db < 2; db++) kt[h8][db] = tr_frag_d(kw, 0, h8, db, lane);
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int db = 0; db < 2; db++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
+    request(0);
+#pragma unroll 1
+    for (int jq = 0; jq < nq; jq++) {
+      __syncthreads();                                               // everyone has left the previous tile (jq = 0: has taken its K fragments out of R)
+      tile_r2s_sw<NT>(sq, qtile, tid);
+      tile_r2s_sw<NT>(sd, dotile, tid);
+      {   // delta = rowsum(dO * O): 8 lanes hold a row
+        float dl = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          dl += __builtin_bit_cast(float, so[0][e] << 16) * __builtin_bit_cast(float, sd[0][e] << 16) +
+                __builtin_bit_cast(float, so[0][e] & 0xffff0000u) * __builtin_bit_cast(float, sd[0][e] & 0xffff0000u);
+        dl = sum8(dl);
+        if ((tid & 7) == 0) del_s[tid >> 3] = dl;
+      }
+      if (tid < KT) lse_s[tid] = lv * LOG2E;
+      __syncthreads();
+      if (jq + 1 < nq) request(jq + 1);
+      if (active) {
+#pragma unroll 1
+        for (int qb = 0; qb < 2; qb++) {
+          if (jq * KT + qb * 32 >= S) continue;                      // (wave-uniform) 32 padding queries contribute nothing
+          f32x16 sacc, dp;
+#pragma unroll
+          for (int r = 0; r < 16; r++) { sacc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+          for (int ks = 0; ks < 4; ks++) {
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(qtile, qb * 32, ks, lane), kf[ks], sacc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag_d(dotile, qb * 32, ks, lane), vf[ks], dp, 0, 0, 0);
+          }
+          f32x16 ds;
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const int r0 = qb * 32 + 8 * g + 4 * (lane >> 5);
+            const f32x4 l4 = *LDS_PTR(const f32x4, lse_s + r0);
+            const f32x4 d4 = *LDS_PTR(const f32x4, del_s + r0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+              const int r = g * 4 + e;
+              const float pe = fast_exp2(fmaf(sacc[r], scale * LOG2E, -l4[e]));
+              sacc[r] = pe;
+              ds[r] = pe * (dp[r] - d4[e]);
+            }
+          }
+          if ((jq + 1) * KT > S) {                                   // padding queries: the last tile only
+#pragma unroll
+            for (int g = 0; g < 4; g++)
+#pragma unroll
+              for (int e = 0; e < 4; e++)
+                if (jq * KT + qb * 32 + 8 * g + 4 * (lane >> 5) + e >= S) { sacc[g * 4 + e] = 0.f; ds[g * 4 + e] = 0.f; }
+          }
+          if (ragged_keys && key >= S) {                             // padding keys must not reach dQ (their dK / dV columns are simply not stored)
+#pragma unroll
+            for (int r = 0; r < 16; r++) ds[r] = 0.f;
+          }
+          // dS^T into the wave's tile: row = key, 4 consecutive queries per 8-byte write
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const u32x2 w2 = {pack_bf2(ds[g * 4], ds[g * 4 + 1]), pack_bf2(ds[g * 4 + 2], ds[g * 4 + 3])};
+            *LDS_PTR(u32x2, dst_w + (lane & 31) * OP_DST + (8 * g + 4 * (lane >> 5)) * 2) = w2;
+          }
+#pragma unroll
+          for (int h8 = 0; h8 < 2; h8++) {
+            const bf16x8 pf = pack_frag(sacc, h8), dsf = pack_frag(ds, h8);
+#pragma unroll
+            for (int db = 0; db < 2; db++) {
+              dv[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_d(dotile, qb * 32, h8, db, lane), pf, dv[db], 0, 0, 0);
+              dk[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag_d(qtile, qb * 32, h8, db, lane), dsf, dk[db], 0, 0, 0);
+            }
+          }
+          __builtin_amdgcn_wave_barrier();
+          if (dbg & 2) continue;
+          const bf16x8 a0 = tr_frag(dst_w, OP_DST, 0, 0, 0, lane), a1 = tr_frag(dst_w, OP_DST, 0, 1, 0, lane);      // lane = query, k-slots = this wave's keys
+          // dq: lane = feature 32 db + (lane & 31), register r = query acc_row(r, lane) of the block
+          float* dst = dqa + (jq * KT + qb * 32 + 4 * (lane >> 5)) * QK_ROW_F + (lane & 31);
+#pragma unroll
+          for (int db = 0; db < 2; db++) {
+            f32x16 dq;
+#pragma unroll
+            for (int r = 0; r < 16; r++) dq[r] = 0.f;
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, kt[0][db], dq, 0, 0, 0);
+            dq = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, kt[1][db], dq, 0, 0, 0);
+            if (dbg & 1) { asm volatile("" ::"v"(dq[0]), "v"(dq[5]), "v"(dq[15])); continue; }
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+              __hip_atomic_fetch_add(LDS_PTR(float, dst + ((r & 3) + 8 * (r >> 2)) * QK_ROW_F + 32 * db), dq[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          __builtin_amdgcn_wave_barrier();                           // (the dS^T tile is rewritten by the next block)
+        }
+      }
+    }
+    // ---- dK / dV of this pass: QK-norm / RoPE backward from 16 parked rows at a time ------------------------------------------------------
+    __syncthreads();                                                 // every wave has left the last Q / dO tile: R is free
+    if (active) {
+      float* t16 = (float*)(R + wave * (16 * QK_ROW_F * 4));
+      const int k0 = kblk * 32;
+      const bool img = k0 < n_img;                                   // wave-uniform: n_img % 32 == 0
+      const int tok0 = img ? k0 : k0 - n_img, nvalid = min(32, (img ? n_img : S) - k0);
+      const int64_t off = (img ? b * n_img + tok0 : b * n_txt + tok0) * pitch + D + h * HD;
+      const bf16_t* xb = (img ? F.qkv_x : F.qkv_c) + off;
+      bf16_t* ob = (img ? F.dqkv_x : F.dqkv_c) + off;
+      const float* wk = img ? F.wk_x : F.wk_c;
+      const float* cs = img ? F.rcos + (int64_t)tok0 * 64 : nullptr;
+      const float* sn = img ? F.rsin + (int64_t)tok0 * 64 : nullptr;
+      float* sk = sdw + 128 + (img ? 0 : 64);
+      acc_to_lds_half(dk, t16, lane, 0);
+      qk_bwd_tile<0, 2>(t16, scale, lane, nvalid, xb, ob, pitch, wk, cs, sn, sk);
+      __builtin_amdgcn_wave_barrier();
+      acc_to_lds_half(dk, t16, lane, 1);
+      qk_bwd_tile<2, 4>(t16 - 16 * QK_ROW_F, scale, lane, nvalid, xb, ob, pitch, wk, cs, sn, sk);
+      __builtin_amdgcn_wave_barrier();
+      acc_to_lds_half(dv, t16, lane, 0);
+      rows_from_tile<0, 2>(t16, lane, nvalid, ob + D, pitch);
+      __builtin_amdgcn_wave_barrier();
+      acc_to_lds_half(dv, t16, lane, 1);
+      rows_from_tile<2, 4>(t16 - 16 * QK_ROW_F, lane, nvalid, ob + D, pitch);
+    }
+  }
+  // ---- dQ: straight out of the accumulator -----------------------------------------------------------------------------------------------
+  __syncthreads();
+#pragma unroll 1
+  for (int blk = wave; blk < nkb; blk += 8) {
+    const int q0 = blk * 32;
+    const bool img = q0 < n_img;
+    const int tok0 = img ? q0 : q0 - n_img, nvalid = min(32, (img ? n_img : S) - q0);
+    const int64_t off = (img ? b * n_img + tok0 : b * n_txt + tok0) * pitch + h * HD;
+    qk_bwd_tile(dqa + q0 * QK_ROW_F, scale, lane, nvalid, (img ? F.qkv_x : F.qkv_c) + off, (img ? F.dqkv_x : F.dqkv_c) + off, pitch, img ? F.wq_x : F.wq_c,
+                img ? F.rcos + (int64_t)tok0 * 64 : nullptr, img ? F.rsin + (int64_t)tok0 * 64 : nullptr, sdw + (img ? 0 : 64));
+  }
+  __syncthreads();
+  if (tid < 256 && sdw[tid] != 0.f) atomicAdd(F.dw + ((tid >> 6) & 1) * 128 + (tid >> 7) * 64 + (tid & 63), sdw[tid]);      // [wq_x | wk_x | wq_c | wk_c]
+}
+
+#endif
+
+#ifdef MMDIT_PROBES
+// ------------------------------------------------------------------------------------------------
 // backward dK/dV, DE-PHASED (round 4 experiment, probes build only: MMDIT_ATTN_DKV_DP=1).  Same arithmetic and fragment conventions as
 // attn_bwd_dkv_kernel above, another schedule.  MEASURED SLOWER than that kernel (backward of one block, S = 410, 64 x 12 heads, same box:
 // 264.9 vs 248.5 us; correct: the attention tests pass with it), so it is not the product path.  Ablations of this kernel (same box, backward =
@@ -1483,6 +1737,20 @@ extern "C" int mmdit_attn_bwd_qk(const void* Q, const void* K, const void* V, co
     if (e != hipSuccess) return (int)e;             // (positive: a HIP error code, as from mmdit_launch_status)
     mmdit_device_mark(raised);
   }
+#ifdef MMDIT_PROBES      // experiment (MMDIT_ATTN_ONEPASS=1): one pass per (batch, head), S <= 416 -- measured slower, see attn_bwd_onepass_kernel
+  if (S <= 32 * OP_MAXB && mmdit_exp_env("MMDIT_ATTN_ONEPASS") && atoi(mmdit_exp_env("MMDIT_ATTN_ONEPASS")) == 1) {
+    static unsigned long long raised1 = 0;
+    if (!mmdit_device_once(raised1)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_onepass_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OP_LDS);
+      if (e != hipSuccess) return (int)e;
+      mmdit_device_mark(raised1);
+    }
+    hipLaunchKernelGGL(attn_bwd_onepass_kernel, dim3(batch * heads), dim3(512), OP_LDS, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Ox,
+                       (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, batch * heads, heads, S, n_img, scale, F,
+                       mmdit_exp_env("MMDIT_OP_DBG") ? atoi(mmdit_exp_env("MMDIT_OP_DBG")) : 0);
+    return mmdit_launch_status();
+  }
+#endif
   hipLaunchKernelGGL((attn_bwd_dq_kernel<8, bf16_t, true>), grid, dim3(512), lds, s, (const bf16_t*)Q, (const bf16_t*)K, (const bf16_t*)V, (const bf16_t*)Ox,
                      (const bf16_t*)Oc, (const bf16_t*)dOx, (const bf16_t*)dOc, lse, delta, batch * heads, heads, S, n_img, scale, (bf16_t*)nullptr, F);
 #ifdef MMDIT_PROBES      // experiment: the de-phased dK/dV kernel (MMDIT_ATTN_DKV_DP=1; needs a text output gradient when there are text tokens)
