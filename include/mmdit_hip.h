@@ -9,9 +9,9 @@
  *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers
  *     owned by the caller (workspaces and saved-for-backward buffers included);
  *   - the library allocates nothing, never synchronises the device and launches
- *     only on the stream it is given; its only mutable state are two per-device
- *     registrations made by the caller: mmdit_gemm_set_workspace (a pointer) and
- *     mmdit_set_cu_budget (an integer);
+ *     only on the stream it is given; its only mutable state are three per-device
+ *     settings made by the caller: mmdit_gemm_set_workspace (a pointer),
+ *     mmdit_gemm_set_claiming (a flag) and mmdit_set_cu_budget (an integer);
  *   - re-entrant: safe to call from the autograd worker thread;
  *   - return value: 0 on success, MMDIT_ERR_* (<0) for invalid arguments, or a
  *     positive hipError_t from the launch.
@@ -154,7 +154,7 @@ int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogu
                              void* Q, void* K, void* V, mmdit_stream_t stream);
 /* Optional device workspace of the GEMM launches, owned by the caller.  Layout: bytes [0, 4096) tickets and [4096, 8192) scheduler words, both
  * ZERO-FILLED by the caller once (every launch leaves them zero again), then 256 KiB slots for partial tiles.  With it
- *   - the persistent 8-phase launches (256-row tiles, more tiles than compute units) CLAIM their tiles from eight per-XCD queues whose heads are the
+ *   - (with mmdit_gemm_set_claiming(1)) the persistent 8-phase launches (256-row tiles, more tiles than compute units) CLAIM their tiles from eight per-XCD queues whose heads are the
  *     scheduler words (one returning atomic per tile, issued a tile ahead) instead of walking them in a fixed stride: a workgroup that becomes
  *     resident late -- another kernel, e.g. a collective's channels on the reducer's stream, holds its compute unit -- finds the queues empty and
  *     leaves, where the fixed stride would run its whole share as a second round (measured with mmdit_debug_occupy: DESIGN.md 5).  Which tiles exist
@@ -163,10 +163,15 @@ int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogu
  *     in slice order by the last slice to arrive (ticket counters) instead of being added with fp32 atomics -- faster (an atomic 256x256 partial costs
  *     ~0.6 us of launch time), deterministic, and the outputs need no zero-fill (mmdit_gemm_zero_mask reports none); a launch that needs more slots
  *     than fit falls back to atomics.
- * This registration and mmdit_set_cu_budget are the library's only mutable state, both per device (hipSetDevice first).  Launches that use the
+ * This registration, mmdit_gemm_set_claiming and mmdit_set_cu_budget are the library's only mutable state, all per device (hipSetDevice first).  Launches that use the
  * workspace must be stream-ordered among themselves (one workspace per device; the scheduler words are handed out in a ring of 64 launches).
  * ptr = NULL, bytes = 0 removes it (static tile walk, atomics).  bytes >= 8192 + 262144.  The library never allocates. */
 int mmdit_gemm_set_workspace(void* ptr, long long bytes);
+/* Dynamic tile claiming of the persistent 8-phase launches (above) on / off, per device, default OFF: it costs a launch ~3 us (the first claim, the LDS
+ * hand-over of each claimed position, one look at the other queues at the end: +0.5 % on the MMDiT-B step) and pays when another kernel holds compute units
+ * while the GEMMs run -- model_trainer turns it on when gradients are reduced (RCCL's channels on the reducer's stream).  Needs the workspace. */
+int mmdit_gemm_set_claiming(int on);
+int mmdit_gemm_get_claiming(void);
 /* Test / measurement aid: `wgs` (1..256) one-wave workgroups with 1 KiB of LDS each sleep-spin for `cycles` shader cycles on `stream` -- a stand-in for a
  * long-running kernel (a collective's channels) that keeps 160-KiB GEMM workgroups off `wgs` compute units.  tests/test_kernels_gpu.py, tools/probes/cu_contention.py. */
 int mmdit_debug_occupy(int wgs, long long cycles, mmdit_stream_t stream);

@@ -84,6 +84,8 @@ _SIGNATURES = {
     "mmdit_gemm_plan": ([ctypes.POINTER(GemmArgs), _i], _i),
     "mmdit_gemm_set_workspace": ([_vp, ctypes.c_longlong], _i),
     "mmdit_debug_occupy": ([_i, ctypes.c_longlong, _vp], _i),
+    "mmdit_gemm_set_claiming": ([_i], _i),
+    "mmdit_gemm_get_claiming": ([], _i),
     "mmdit_set_cu_budget": ([_i], _i),
     "mmdit_get_cu_budget": ([], _i),
     "mmdit_gemm_qkv_norm_rope": ([ctypes.POINTER(GemmArgs), ctypes.POINTER(QkEpilogue), _i, _i, _i, _vp, _vp, _vp, _vp], _i),

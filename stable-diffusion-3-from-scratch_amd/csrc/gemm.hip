@@ -260,9 +260,12 @@ static long long g_ws_bytes[64] = {};
 // tiles dynamically (gemm8p.hip) takes the next slot round robin and leaves it zeroed.  Launches that use the workspace are stream-ordered (header),
 // so one slot would do; the ring keeps a launch on another stream from sharing the words of its 63 predecessors.
 static unsigned g_sched_next[64] = {};
+static int g_claiming[64] = {};      // mmdit_gemm_set_claiming
+extern "C" int mmdit_gemm_set_claiming(int on) { g_claiming[mmdit_current_device()] = on != 0; return 0; }
+extern "C" int mmdit_gemm_get_claiming(void) { return g_claiming[mmdit_current_device()]; }
 int* mmdit_gemm_sched_slot() {
   const int dev = mmdit_current_device();
-  if (!g_ws[dev]) return nullptr;
+  if (!g_ws[dev] || !g_claiming[dev]) return nullptr;
   return (int*)((char*)g_ws[dev] + 4096) + (g_sched_next[dev]++ & 63u) * 16;
 }
 // compute units the persistent launches may count on, per device (0 = not set: all of the device's); mmdit_set_cu_budget
@@ -513,11 +516,11 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
             const double load = (double)(nk_short + extra) / nk_max, c = (load > 1.0 ? load - 1.0 : 0.0) + (S > 1 ? 0.0028 * r * S : 0.0);
             if (c < bbest) { bbest = c; bS = S; brounds = rounds; }
           }
-          // (round 6) with the workspace registered the 8-phase kernel CLAIMS its positions (gemm8p.hip): the workgroups whose first tile is short
-          // reach the tail first by themselves -- the split of this model is kept, its static assignment is not
+          // (round 6) with tile claiming on (mmdit_gemm_set_claiming + the workspace) the 8-phase kernel CLAIMS its positions (gemm8p.hip): the workgroups
+          // whose first tile is short reach the tail first by themselves -- the split of this model is kept, its static assignment is not
           if (bbest < best) {
             tail_split = bS;
-            if (!g_ws[mmdit_current_device()]) { gp.tail_first = first_short; gp.tail_rounds = brounds; gp.tail_G = G; }
+            if (!(g_ws[mmdit_current_device()] && g_claiming[mmdit_current_device()])) { gp.tail_first = first_short; gp.tail_rounds = brounds; gp.tail_G = G; }
           }
         }
       }

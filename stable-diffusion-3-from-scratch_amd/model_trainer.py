@@ -184,6 +184,10 @@ class model_trainer:
             # the planner's budget to CUs - reserve around engine.model_bwd): the weight gradients' split tail and the one-round data gradients are cut so that
             # any number of workgroups between the budget and the whole chip stays busy.  The grids still cover every CU.  How many CUs RCCL's all-reduce
             # takes on an 8-GPU xGMI node could not be measured here (tools/probes/cu_contention.py measures a stand-in); frozen with a captured step.
+            if self.device.type == "cuda" and os.environ.get("MMDIT_GEMM_CLAIMING", "1") != "0":
+                from . import _lib
+                with torch.cuda.device(self.device):
+                    _lib.check(_lib.lib().mmdit_gemm_set_claiming(1), "mmdit_gemm_set_claiming")      # (per device; off by default: it costs ~3 us per launch and pays beside the collectives)
             if reserved_cus is None:
                 reserved_cus = int(os.environ.get("MMDIT_RESERVED_CUS", "32"))
             self.reserved_cus = max(0, int(reserved_cus)) // 8 * 8

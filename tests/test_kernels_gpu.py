@@ -927,7 +927,20 @@ def test_gemm_dynamic_tile_claiming_equals_the_static_walk(ops):
     L = _lib.lib()
     cases = _claiming_cases(ops)
     dev = torch.device("cuda", torch.cuda.current_device())
-    dyn = {k: f() for k, f in cases.items()}            # (ops registers the workspace at its first launch)
+    static = {k: f() for k, f in cases.items() if k != "wgrad"}      # claiming is off by default: the static walk (ops registers the workspace at its first launch)
+    assert L.mmdit_gemm_get_claiming() == 0 and L.mmdit_gemm_set_claiming(1) == 0
+    try:
+        _claiming_equals_static(ops, L, cases, dev, static)
+    finally:
+        torch.cuda.synchronize()
+        assert L.mmdit_gemm_set_claiming(0) == 0
+
+
+def _claiming_equals_static(ops, L, cases, dev, static):
+    dyn = {k: f() for k, f in cases.items()}
+    for k, outs in static.items():
+        for a, b in zip(outs, dyn[k]):
+            assert torch.equal(a, b), k
     ws = ops._GEMM_WS[dev]
     assert int(ws[:8192].view(torch.int32).abs().sum()) == 0, "tickets / queue heads are left zero by every launch"
     for _ in range(30):
@@ -954,17 +967,22 @@ def test_gemm_dynamic_tile_claiming_beside_an_occupant_kernel(ops, held):
     from sd3_amd import _lib
     L = _lib.lib()
     cases = _claiming_cases(ops)
-    ref = {k: f() for k, f in cases.items()}
-    side = torch.cuda.Stream()
-    torch.cuda.synchronize()
-    for k, f in cases.items():
-        assert L.mmdit_debug_occupy(held, int(3e-3 * 2.0e9), side.cuda_stream) == 0      # ~3 ms at ~2 GHz: longer than any of these launches
-        out = f()
+    assert L.mmdit_gemm_set_claiming(1) == 0
+    try:
+        ref = {k: f() for k, f in cases.items()}
+        side = torch.cuda.Stream()
         torch.cuda.synchronize()
-        for a, b in zip(out, ref[k]):
-            assert torch.equal(a, b), k
-    dev = torch.device("cuda", torch.cuda.current_device())
-    assert int(ops._GEMM_WS[dev][:8192].view(torch.int32).abs().sum()) == 0
+        for k, f in cases.items():
+            assert L.mmdit_debug_occupy(held, int(3e-3 * 2.0e9), side.cuda_stream) == 0      # ~3 ms at ~2 GHz: longer than any of these launches
+            out = f()
+            torch.cuda.synchronize()
+            for a, b in zip(out, ref[k]):
+                assert torch.equal(a, b), k
+        dev = torch.device("cuda", torch.cuda.current_device())
+        assert int(ops._GEMM_WS[dev][:8192].view(torch.int32).abs().sum()) == 0
+    finally:
+        torch.cuda.synchronize()
+        assert L.mmdit_gemm_set_claiming(0) == 0
 
 
 @pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16),

@@ -221,7 +221,7 @@ def test_library_exports_every_declared_symbol():
     import sd3_amd  # noqa: F401
     from sd3_amd import _lib
     declared = _lib.declared_symbols()
-    assert len(declared) >= 60 and set(declared) == set(_lib._SIGNATURES)
+    assert len(declared) >= 62 and set(declared) == set(_lib._SIGNATURES)
     L = ctypes.CDLL(_lib.LIB_PATH)
     for s in declared:
         assert hasattr(L, s), s

@@ -34,6 +34,8 @@ with contextlib.redirect_stdout(sys.stderr):
     tr = model_trainer(net, batchSize=64, accumulation_steps=1, totalSteps=10 ** 9, lr=1e-4, ema_update_freq=10 ** 9, ema_decay=0.999, warmup_steps=1000, use_lr_scheduler=False,
                        device=dev, saveDir="/tmp/_cc", numSaveSteps=10 ** 9, max_res=256, device_rng=True, use_ema=False, hip_optimizer=True)
 net.train()
+if hasattr(_lib.lib(), "mmdit_gemm_set_claiming"):
+    _lib.lib().mmdit_gemm_set_claiming(0 if "--static" in sys.argv else 1)      # (round 6) tile claiming: what model_trainer turns on when gradients are reduced
 side = torch.cuda.Stream()
 has_budget = hasattr(_lib.lib(), "mmdit_set_cu_budget")
 
