@@ -927,13 +927,15 @@ def test_gemm_dynamic_tile_claiming_equals_the_static_walk(ops):
     L = _lib.lib()
     cases = _claiming_cases(ops)
     dev = torch.device("cuda", torch.cuda.current_device())
-    static = {k: f() for k, f in cases.items() if k != "wgrad"}      # claiming is off by default: the static walk (ops registers the workspace at its first launch)
-    assert L.mmdit_gemm_get_claiming() == 0 and L.mmdit_gemm_set_claiming(1) == 0
+    before = L.mmdit_gemm_get_claiming()      # (per-device setting: a data-parallel trainer of an earlier test leaves it on)
+    assert L.mmdit_gemm_set_claiming(0) == 0 and L.mmdit_gemm_get_claiming() == 0
+    static = {k: f() for k, f in cases.items() if k != "wgrad"}      # claiming off: the static walk (ops registers the workspace at its first launch)
+    assert L.mmdit_gemm_set_claiming(1) == 0 and L.mmdit_gemm_get_claiming() == 1
     try:
         _claiming_equals_static(ops, L, cases, dev, static)
     finally:
         torch.cuda.synchronize()
-        assert L.mmdit_gemm_set_claiming(0) == 0
+        assert L.mmdit_gemm_set_claiming(before) == 0
 
 
 def _claiming_equals_static(ops, L, cases, dev, static):
@@ -967,6 +969,7 @@ def test_gemm_dynamic_tile_claiming_beside_an_occupant_kernel(ops, held):
     from sd3_amd import _lib
     L = _lib.lib()
     cases = _claiming_cases(ops)
+    before = L.mmdit_gemm_get_claiming()
     assert L.mmdit_gemm_set_claiming(1) == 0
     try:
         ref = {k: f() for k, f in cases.items()}
@@ -982,7 +985,7 @@ def test_gemm_dynamic_tile_claiming_beside_an_occupant_kernel(ops, held):
         assert int(ops._GEMM_WS[dev][:8192].view(torch.int32).abs().sum()) == 0
     finally:
         torch.cuda.synchronize()
-        assert L.mmdit_gemm_set_claiming(0) == 0
+        assert L.mmdit_gemm_set_claiming(before) == 0
 
 
 @pytest.mark.parametrize("M,N,K,out_dtype", [(256, 256, 128, torch.float32), (1000, 768, 768, torch.bfloat16), (16384, 2304, 768, torch.bfloat16),
