@@ -266,7 +266,7 @@ extern "C" int mmdit_gemm_get_claiming(void) { return g_claiming[mmdit_current_d
 int* mmdit_gemm_sched_slot() {
   const int dev = mmdit_current_device();
   if (!g_ws[dev] || !g_claiming[dev]) return nullptr;
-  return (int*)((char*)g_ws[dev] + 4096) + (g_sched_next[dev]++ & 63u) * 16;
+  return (int*)((char*)g_ws[dev] + 4096) + (__atomic_fetch_add(&g_sched_next[dev], 1u, __ATOMIC_RELAXED) & 63u) * 16;      // (launchers may run on several host threads)
 }
 // compute units the persistent launches may count on, per device (0 = not set: all of the device's); mmdit_set_cu_budget
 static int g_cu_budget[64] = {};

@@ -505,7 +505,14 @@ class model_trainer:
             return step, None
         if self._graph is not None:
             raise RuntimeError("autotune_reducer: call it before the step is captured")
-        run = run_step or self.train_step
+        step_fn = run_step or self.train_step
+        self.autotune_losses = []      # the losses of the steps run here, in order (train() files them with the others)
+
+        def run(n):
+            loss = step_fn(n)
+            self.autotune_losses.append(loss)
+            return loss
+
         cuda = self.device.type == "cuda"
 
         def time_candidate(apply):
@@ -735,6 +742,8 @@ class model_trainer:
                 if self.totalSteps - step > 40:
                     before = step
                     step, _ = self.autotune_reducer(step)
+                    if self.keep_losses:
+                        self.loss_history.extend(self.autotune_losses)
                     if self.ema_model_cpu is not None and step // self.ema_update_freq > before // self.ema_update_freq:
                         self.update_ema()
                     continue

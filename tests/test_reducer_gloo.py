@@ -570,3 +570,56 @@ def test_eight_rank_gloo_reducer_autotune_is_a_collective_decision():
         assert all(l == l for l in losses)
         for a, b in zip(params, res[0][7]):
             assert (a == b).all(), "ranks diverged"
+
+
+def _train_loop_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sd3_amd  # noqa: F401
+    from sd3_amd.model_trainer import model_trainer
+    net = _EngineLike()
+    tr = model_trainer(net, batchSize=3, accumulation_steps=1, totalSteps=64, lr=1e-2, ema_update_freq=1000, ema_decay=0.9, warmup_steps=0, use_lr_scheduler=False,
+                       device=torch.device("cpu"), saveDir="/tmp/_gl_train", numSaveSteps=10 ** 6, use_amp=False, max_res=32, use_ema=False, hip_optimizer=False,
+                       async_checkpoint=False, log_steps=10 ** 6)
+    assert tr.autotune and tr.reducer.enabled
+    micro = [0]
+
+    def source():
+        x, t = _trainer_data(micro[0], rank, world, 3)
+        tr._t = t
+        micro[0] += 1
+        return x, torch.zeros(3, 154, 4), torch.zeros(3, 8)
+
+    tr.data_source = source
+    tr._sample_conditioning = lambda n: (tr._t, None, None, None)
+    tr.keep_losses = True
+    tr.train()
+    q.put((rank, micro[0], len(tr.loss_history), tr.autotune_table, tr.reducer.algorithm, tr.reserved_cus, [float(l) for l in tr.loss_history[-3:]],
+           [p.detach().numpy().copy() for p in net.parameters()]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_train_loop_with_the_reducer_autotune():
+    """model_trainer.train() on 2 gloo ranks (the CPU trainer): after its first step the loop runs autotune_reducer -- (1 + 2) optimizer steps for each of three bucket
+    algorithms and three reserves, real training steps on fresh batches -- and goes on; exactly totalSteps batches are consumed and totalSteps losses recorded, both ranks
+    hold the same table and setting, and the replicas end bit-identical."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_loop_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=240) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        batches, nloss, table, algo, reserve, last, params = res[r]
+        assert batches == 64 and nloss == 64, (batches, nloss)
+        assert table is not None and table == res[0][2] and set(table["algorithm"]) == {"allreduce", "rs_ag", "direct"} and set(table["reserved_cus"]) == {"0", "16", "32"}
+        assert table["chosen"]["algorithm"] == algo and table["chosen"]["reserved_cus"] == reserve and (algo, reserve) == (res[0][3], res[0][4])
+        assert all(l == l for l in last)
+        for a, b in zip(params, res[0][6]):
+            assert (a == b).all(), "ranks diverged"
