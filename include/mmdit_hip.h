@@ -168,19 +168,20 @@ int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogu
  * ptr = NULL, bytes = 0 removes it (static tile walk, atomics).  bytes >= 8192 + 262144.  The library never allocates. */
 int mmdit_gemm_set_workspace(void* ptr, long long bytes);
 /* Dynamic tile claiming of the persistent 8-phase launches (above) on / off, per device, default OFF: it costs a launch ~3 us (the first claim, the LDS
- * hand-over of each claimed position, one look at the other queues at the end: +0.5 % on the MMDiT-B step) and pays when another kernel holds compute units
+ * hand-over of each claimed position, one look at the other queues at the end: +0.12 ms = +0.4 % on the MMDiT-B step) and pays when another kernel holds compute units
  * while the GEMMs run -- model_trainer turns it on when gradients are reduced (RCCL's channels on the reducer's stream).  Needs the workspace. */
 int mmdit_gemm_set_claiming(int on);
 int mmdit_gemm_get_claiming(void);
 /* Test / measurement aid: `wgs` (1..256) one-wave workgroups with 1 KiB of LDS each sleep-spin for `cycles` shader cycles on `stream` -- a stand-in for a
  * long-running kernel (a collective's channels) that keeps 160-KiB GEMM workgroups off `wgs` compute units.  tests/test_kernels_gpu.py, tools/probes/cu_contention.py. */
 int mmdit_debug_occupy(int wgs, long long cycles, mmdit_stream_t stream);
-/* Compute units the GEMM launches may count on (default: all of the device's, hipDeviceAttributeMultiprocessorCount -- 256 on an MI355X).  The persistent
- * GEMM kernels launch ONE workgroup per CU and the planner sizes rounds / tile configurations for that number; a workgroup needs a whole CU (144 - 160 KiB of
- * LDS).  Round 6: launches with more tiles than workgroups claim their tiles dynamically (mmdit_gemm_set_workspace), so a kernel on another stream that
- * holds C compute units -- RCCL's collectives on the reducer's side stream -- costs them C / 256 of their rate, not a second round; a budget of 256 - C
- * additionally makes the planner size the ONE-round launches (the N = 768 projections of MMDiT-B: 249 tiles) for 256 - C.  The reference has no counterpart
- * (DDP leaves the split to the CUDA scheduler, model_trainer.py:224).  model_trainer sets a budget only when MMDIT_RESERVED_CUS asks for one.
+/* Compute units the GEMM PLANNER counts on (default: all of the device's, hipDeviceAttributeMultiprocessorCount -- 256 on an MI355X): rounds, tile
+ * configurations and split tails are sized for that number, and a launch that is not claimed (see above) also limits its persistent grid to it.  A claimed
+ * launch covers the whole device whatever the budget: a workgroup whose compute unit is taken by another kernel starts late and finds nothing, one whose
+ * compute unit is free does its share.  The data-parallel trainer uses exactly that for the block weight-gradient launches (budget = CUs - reserved_cus
+ * around those launches only: ops.WGRAD_CU_BUDGET; measured beside a stand-in occupant in DESIGN.md 5); every other launch keeps the whole-chip plan -- a
+ * smaller budget makes the one-round launches (the N = 768 projections of MMDiT-B: 249 tiles of 320 x 256) two rounds of smaller tiles.  The reference has
+ * no counterpart (DDP leaves the split to the CUDA scheduler, model_trainer.py:224).
  * n: a multiple of 8 in [64, CUs of the device] (the XCD round-robin stays even); per device (hipSetDevice first); takes effect with the next launch --
  * change it only while no captured graph of earlier launches is replayed. */
 int mmdit_set_cu_budget(int n);
