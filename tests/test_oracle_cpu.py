@@ -365,3 +365,25 @@ def test_gpu_sensor_poller_on_a_fake_sysfs_tree(tmp_path):
     r = s.stop()
     assert r["samples"] >= 5 and abs(r["clock_mhz"] - 1858.0) < 1e-6 and abs(r["power_w"] - 1388.0) < 1e-6 and r["busy"] == 100.0
     assert not GpuSensors(root=str(drm), bdf="0000:f4:00.0").available       # no hwmon: nothing to poll
+
+
+def test_per_device_settings_of_the_library_and_the_bench_host_description():
+    """The library's three per-device settings (include/mmdit_hip.h conventions) without a GPU: tile claiming is off until asked for and reads back; the planner's CU
+    budget defaults to a whole MI355X when no device answers, takes multiples of 8 in [64, CUs] and reads back; a workspace must hold the tickets, the scheduler
+    words and at least one slot.  bench.host_cpu(): a model string and a positive physical core count from /proc/cpuinfo (cpu_baseline carries both)."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd import _lib
+    L = _lib.lib()
+    assert L.mmdit_gemm_get_claiming() == 0
+    assert L.mmdit_gemm_set_claiming(1) == 0 and L.mmdit_gemm_get_claiming() == 1
+    assert L.mmdit_gemm_set_claiming(0) == 0 and L.mmdit_gemm_get_claiming() == 0
+    assert L.mmdit_get_cu_budget() == 256
+    assert L.mmdit_set_cu_budget(250) != 0 and L.mmdit_set_cu_budget(32) != 0 and L.mmdit_set_cu_budget(264) != 0
+    assert L.mmdit_set_cu_budget(224) == 0 and L.mmdit_get_cu_budget() == 224
+    assert L.mmdit_set_cu_budget(256) == 0 and L.mmdit_get_cu_budget() == 256
+    assert L.mmdit_gemm_set_workspace(ctypes.c_void_p(4096), 8192) != 0            # (no room for a slot)
+    assert L.mmdit_gemm_set_workspace(ctypes.c_void_p(4100), 1 << 20) != 0         # (misaligned)
+    assert L.mmdit_gemm_set_workspace(None, 0) == 0
+    import bench
+    model, cores = bench.host_cpu()
+    assert isinstance(model, str) and model and isinstance(cores, int) and cores >= 1
