@@ -165,6 +165,25 @@ def test_b_size_replay_burst():
     check(l0, l1, p0, p1, "B burst")
 
 
+def test_b_size_replay_with_tile_claiming():
+    """The bench's step with dynamic tile claiming on (csrc/gemm8p.hip; what model_trainer switches on when gradients are reduced): ~50 claimed launches per step are
+    captured with their scheduler slots and replayed; eager and replayed steps agree as they do with the static walk, and the workspace's ticket / scheduler words are
+    zero after the last replay (every launch leaves its queue heads clean)."""
+    import sd3_amd  # noqa: F401
+    from sd3_amd import _lib, ops
+    L = _lib.lib()
+    before = L.mmdit_gemm_get_claiming()
+    assert L.mmdit_gemm_set_claiming(1) == 0
+    try:
+        l0, l1, p0, p1, _ = graph_vs_eager("b", 64, 256, n_steps=3, pattern="burst", lr=1e-4)
+        check(l0, l1, p0, p1, "B burst, tile claiming")
+        torch.cuda.synchronize()
+        ws = ops._GEMM_WS[torch.device("cuda", 0)]
+        assert int(ws[:8192].view(torch.int32).abs().sum()) == 0
+    finally:
+        assert L.mmdit_gemm_set_claiming(before) == 0
+
+
 def test_replay_with_static_input_slots_and_cpu_conditioning():
     """Any data source + the reference's CPU draw of t / null masks (device_rng=False): inputs are copied into static slots before
     every replay; two accumulation micro-steps per optimizer step."""
