@@ -497,7 +497,8 @@ class model_trainer:
         gradients) and the compute units the weight-gradient planner leaves to the collectives (reserved_cus in {0, 16, 32}).  Every candidate runs
         `steps_each` EAGER optimizer steps -- real training steps on fresh batches, nothing is thrown away -- timed on the host between device
         synchronisations; the ranks vote (vote_fastest: MAX over ranks per candidate, then the minimum) so that all of them continue with the same
-        setting.  Two rounds: algorithms at the current reserve, then reserves at the winning algorithm.  Call before capture_graph (the choice is frozen
+        setting.  Three rounds: algorithms at the current reserve, reserves at the winning algorithm, then how many blocks' buckets are handed to the side stream per fork
+        (reducer.blocks_per_fork in {1, 2, 3}).  Call before capture_graph (the choice is frozen
         into the captured step).  Returns (next step, table) with table = {"algorithm": {...ms}, "reserved_cus": {...ms}, "chosen": {...}}; a no-op
         (step, None) when gradients are not reduced."""
         import sys
@@ -556,7 +557,18 @@ class model_trainer:
         rbest, rworst = vote_fastest(ms, self.subgroup, self.device)
         set_reserve(reserves[rbest])()
         table["reserved_cus"] = {str(r): round(t, 3) for r, t in zip(reserves, rworst)}
-        table["chosen"] = {"algorithm": name(*algos[best]), "reserved_cus": reserves[rbest], "steps_each": steps_each}
+
+        def set_fork(k):
+            def f():
+                self.reducer.blocks_per_fork = k
+            return f
+
+        forks = sorted({1, 2, 3, int(self.reducer.blocks_per_fork)})
+        ms = [time_candidate(set_fork(k)) for k in forks]
+        fbest, fworst = vote_fastest(ms, self.subgroup, self.device)
+        set_fork(forks[fbest])()
+        table["blocks_per_fork"] = {str(k): round(t, 3) for k, t in zip(forks, fworst)}
+        table["chosen"] = {"algorithm": name(*algos[best]), "reserved_cus": reserves[rbest], "blocks_per_fork": forks[fbest], "steps_each": steps_each}
         print(f"[model_trainer rank {self.rank}/{self.world}] reducer auto-tune (ms per eager step, max over ranks): {json.dumps(table)}", file=sys.stderr, flush=True)
         self.autotune_table = table
         return step, table

@@ -27,8 +27,13 @@ ALGORITHMS = ("allreduce", "rs_ag", "direct")
 
 
 class GradReducer:
-    def __init__(self, group=None, bucket_bytes=32 << 20, force=False, algorithm=None, wire_dtype=None):
+    def __init__(self, group=None, bucket_bytes=32 << 20, force=False, algorithm=None, wire_dtype=None, blocks_per_fork=None):
         self.group = group
+        # engine path: how many blocks' arenas are handed to the side stream at once.  Every hand-over is a fork of the captured step (the side stream waits for the
+        # main stream's last kernel, and on replay the main stream's next kernel starts ~17 us late: profiles/r06_claiming_forcedist_contention.txt); k blocks per fork
+        # mean 1 / k as many forks and the first collective of a group starting up to k - 1 blocks later.  The collectives themselves stay one per arena.
+        self.blocks_per_fork = max(1, int(blocks_per_fork if blocks_per_fork is not None else os.environ.get("MMDIT_REDUCE_BLOCKS_PER_FORK", "1")))
+        self._held, self._held_blocks = [], 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bucket_bytes = bucket_bytes
         self.enabled = self.world > 1 or (force and dist.is_initialized())   # force: exercise the path with one rank (tests)
@@ -63,7 +68,7 @@ class GradReducer:
         """One line for the logs: what this rank's reducer will do."""
         backend = dist.get_backend(self.group) if dist.is_initialized() else "none"
         wire = "bf16" if self.wire_dtype == torch.bfloat16 else "fp32"
-        return f"GradReducer(world={self.world}, enabled={self.enabled}, backend={backend}, algorithm={self.algorithm}, wire={wire})"
+        return f"GradReducer(world={self.world}, enabled={self.enabled}, backend={backend}, algorithm={self.algorithm}, wire={wire}, blocks_per_fork={self.blocks_per_fork})"
 
     def _buf(self, role, n, dtype, device):
         key = (role, n, dtype, device)
@@ -174,8 +179,12 @@ class GradReducer:
         if arenas:
             # the producer guarantees that `tensors` are exactly the contents of these flat buffers (engine.block_bwd):
             # average them where they are -- no gather copy, no replacement
-            self._reduce_in_place(arenas)
+            self._held.extend(arenas)
+            self._held_blocks += 1
+            if self._held_blocks >= self.blocks_per_fork:
+                self._flush_held()
             return None
+        self._flush_held()
         self._pending, self._pending_bytes = tensors, 1
         self._views_wanted = True
         self.flush()
@@ -186,6 +195,11 @@ class GradReducer:
             views.append(flat[off:off + n].view(t.shape))
             off += n
         return views
+
+    def _flush_held(self):
+        if self._held:
+            held, self._held, self._held_blocks = self._held, [], 0
+            self._reduce_in_place(held)
 
     def add(self, tensors, after=None):
         """tensors: gradients that are final once the current stream (and `after`, the stream that produced
@@ -232,6 +246,7 @@ class GradReducer:
     def finish(self):
         if not self.enabled or self.skip:
             return
+        self._flush_held()
         self.flush()
         for work, flat in self._works:
             work.wait()
@@ -260,6 +275,7 @@ class GradReducer:
     def reset(self):
         """Forget everything queued or in flight (a graph capture that raised: its collectives were never launched)."""
         self._pending, self._pending_bytes, self._inflight, self._views_wanted, self._works = [], 0, [], False, []
+        self._held, self._held_blocks = [], 0
 
     def attach_hooks(self, params):
         """Fallback for modules without an engine callback: reduce each parameter's gradient as soon as

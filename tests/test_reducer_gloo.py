@@ -565,8 +565,9 @@ def test_eight_rank_gloo_reducer_autotune_is_a_collective_decision():
     for r in range(world):
         best, worst, step, table, algo, reserve, losses, params = res[r]
         assert (best, worst, step, table) == (best0, worst0, step0, table0), "every rank holds the same table and winner"
-        assert algo == "direct" and reserve == 16 and table["chosen"] == {"algorithm": "direct", "reserved_cus": 16, "steps_each": 2}
-        assert step == 1 + 3 * 3 + 3 * 3                  # (1 settling + 2 timed steps for each of 3 algorithms and 3 reserves)
+        assert algo == "direct" and reserve == 16 and table["chosen"] == {"algorithm": "direct", "reserved_cus": 16, "blocks_per_fork": table["chosen"]["blocks_per_fork"], "steps_each": 2}
+        assert table["chosen"]["blocks_per_fork"] in (1, 2, 3) and set(table["blocks_per_fork"]) == {"1", "2", "3"}
+        assert step == 1 + 3 * 3 + 3 * 3 + 3 * 3          # (1 settling + 2 timed steps for each of 3 algorithms, 3 reserves and 3 fork widths)
         assert all(l == l for l in losses)
         for a, b in zip(params, res[0][7]):
             assert (a == b).all(), "ranks diverged"
@@ -603,7 +604,7 @@ def _train_loop_worker(rank, world, port, q):
 
 def test_two_rank_gloo_train_loop_with_the_reducer_autotune():
     """model_trainer.train() on 2 gloo ranks (the CPU trainer): after its first step the loop runs autotune_reducer -- (1 + 2) optimizer steps for each of three bucket
-    algorithms and three reserves, real training steps on fresh batches -- and goes on; exactly totalSteps batches are consumed and totalSteps losses recorded, both ranks
+    algorithms, three reserves and three fork widths, real training steps on fresh batches -- and goes on; exactly totalSteps batches are consumed and totalSteps losses recorded, both ranks
     hold the same table and setting, and the replicas end bit-identical."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -623,3 +624,50 @@ def test_two_rank_gloo_train_loop_with_the_reducer_autotune():
         assert all(l == l for l in last)
         for a, b in zip(params, res[0][6]):
             assert (a == b).all(), "ranks diverged"
+
+
+def _fork_worker(rank, world, port, k, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sd3_amd  # noqa: F401
+    from sd3_amd.reducer import GradReducer
+    red = GradReducer(blocks_per_fork=k)
+    g = torch.Generator().manual_seed(40 + rank)
+    arenas = [torch.randn(2048, generator=g) for _ in range(5)]
+    launched = []
+    for i, a in enumerate(arenas):
+        assert red.add_bucket([a[:1024], a[1024:]], arenas=[a]) is None
+        launched.append(red.buckets)                     # collectives issued so far: held buckets are not
+    tail = torch.randn(333, generator=g)
+    views = red.add_bucket([tail])                        # the last, gathered bucket: everything held goes first
+    red.finish()
+    q.put((rank, launched, red.buckets, [a.clone() for a in arenas], views[0].clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [1, 2, 3])
+def test_two_rank_gloo_blocks_per_fork(k):
+    """GradReducer(blocks_per_fork=k): block arenas are handed to the collective stream k at a time (one fork of the captured step per hand-over instead of one per
+    block); whatever is still held goes out before a gathered bucket and at finish().  Same averages for every k, every bucket reduced exactly once."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fork_worker, args=(r, world, port, k, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in range(world))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want_launched = [(i + 1) // k * k for i in range(5)]
+    gens = [torch.Generator().manual_seed(40 + r) for r in range(world)]
+    local = [[torch.randn(2048, generator=g) for _ in range(5)] + [torch.randn(333, generator=g)] for g in gens]
+    mean = [(local[0][i].double() + local[1][i].double()) / 2 for i in range(6)]
+    for r in range(world):
+        launched, total, arenas, tail = res[r]
+        assert launched == want_launched and total == 6
+        for a, m in zip(arenas, mean[:5]):
+            assert float((a.double() - m).abs().max()) <= 1e-6
+        assert float((tail.double() - mean[5]).abs().max()) <= 1e-6
