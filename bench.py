@@ -190,7 +190,11 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=torch.device(f"cuda:{local_rank}"))
+        from importlib import import_module
+        import sd3_amd  # noqa: F401
+        opts = import_module("sd3_amd.model_trainer").rccl_options()      # MMDIT_RCCL_MAX_CTAS: workgroups a collective may use (see there)
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=torch.device(f"cuda:{local_rank}"),
+                                **({"pg_options": opts} if opts is not None else {}))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
 
     import sd3_amd  # noqa: F401

@@ -61,7 +61,21 @@ def init_distributed():
     # the watchdog has retired every eager collective (_wait_for_watchdog); it only exists while the recorder is on
     os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "2000")
     backend = "nccl" if torch.cuda.is_available() else "gloo"
-    dist.init_process_group(backend, init_method="env://", world_size=int(os.environ["WORLD_SIZE"]), rank=int(os.environ["RANK"]))
+    dist.init_process_group(backend, init_method="env://", world_size=int(os.environ["WORLD_SIZE"]), rank=int(os.environ["RANK"]),
+                            **({"pg_options": rccl_options()} if backend == "nccl" and rccl_options() is not None else {}))
+
+
+def rccl_options():
+    """ProcessGroupNCCL options of the gradient process group: MMDIT_RCCL_MAX_CTAS = n limits a collective to n workgroups (ncclConfig maxCTAs).  A persistent GEMM
+    workgroup cannot share a compute unit with anything, and the one-round launches of the backward (249 tiles on 256 CUs) stay one round only while a collective holds
+    at most 7 of them: on xGMI links that n workgroups saturate, a small n costs no bandwidth and the GEMMs nothing.  None when the variable is not set."""
+    n = os.environ.get("MMDIT_RCCL_MAX_CTAS", "")
+    if not n:
+        return None
+    opts = dist.ProcessGroupNCCL.Options()
+    opts.config.max_ctas = max(1, int(n))
+    opts.config.min_ctas = 1
+    return opts
 
 
 def _watchdog_status():
@@ -569,6 +583,31 @@ class model_trainer:
         set_fork(forks[fbest])()
         table["blocks_per_fork"] = {str(k): round(t, 3) for k, t in zip(forks, fworst)}
         table["chosen"] = {"algorithm": name(*algos[best]), "reserved_cus": reserves[rbest], "blocks_per_fork": forks[fbest], "steps_each": steps_each}
+        # Fourth round (RCCL only): the workgroups a collective may use (ncclConfig maxCTAs).  The one-round GEMM launches of the backward are 249 tiles on 256 compute
+        # units: they stay ONE round while the collectives hold at most 7 CUs, so a communicator limited to 7 workgroups costs the GEMMs nothing -- if 7 workgroups
+        # still saturate the xGMI links, which only the real node can tell.  A second communicator (dist.new_group with the limit) is created here, on every rank in the
+        # same order, and the reducer keeps whichever the vote prefers.  MMDIT_REDUCE_TUNE_CTAS=0 skips the round; a failure to create the group skips it on the rank
+        # that saw it (the next collective of the default group would then show a disagreement as a time-out rather than as silence).
+        nccl = dist.is_initialized() and dist.get_backend(self.subgroup) == "nccl"
+        if nccl and os.environ.get("MMDIT_REDUCE_TUNE_CTAS", "1") != "0" and (self.world > 1 or os.environ.get("MMDIT_REDUCE_TUNE_CTAS") == "force"):
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.config.max_ctas, opts.config.min_ctas = 7, 1
+                limited = dist.new_group(ranks=None, pg_options=opts)
+                groups = [("default", self.reducer.group), ("7", limited)]
+
+                def set_group(g):
+                    def f():
+                        self.reducer.group = g
+                    return f
+
+                ms = [time_candidate(set_group(g)) for _, g in groups]
+                gbest, gworst = vote_fastest(ms, self.subgroup, self.device)
+                set_group(groups[gbest][1])()
+                table["max_ctas"] = {n: round(t, 3) for (n, _), t in zip(groups, gworst)}
+                table["chosen"]["max_ctas"] = groups[gbest][0]
+            except Exception as e:      # (an RCCL build without communicator configs: keep the default group)
+                print(f"[model_trainer rank {self.rank}/{self.world}] reducer auto-tune: no CTA-limited communicator ({type(e).__name__}: {e})", file=sys.stderr, flush=True)
         print(f"[model_trainer rank {self.rank}/{self.world}] reducer auto-tune (ms per eager step, max over ranks): {json.dumps(table)}", file=sys.stderr, flush=True)
         self.autotune_table = table
         return step, table
