@@ -37,6 +37,7 @@ net.train()
 if hasattr(_lib.lib(), "mmdit_gemm_set_claiming"):
     _lib.lib().mmdit_gemm_set_claiming(0 if "--static" in sys.argv else 1)      # (round 6) tile claiming: what model_trainer turns on when gradients are reduced
 side = torch.cuda.Stream()
+BWD_ONLY = "--bwd-only" in sys.argv
 has_budget = hasattr(_lib.lib(), "mmdit_set_cu_budget")
 
 
@@ -56,14 +57,20 @@ def run(C, budget, steps=6):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        if C:
+        if C and not BWD_ONLY:
             occupy(C, int(26e-3 * 2.0e9), ctypes.c_void_p(side.cuda_stream))      # ~26 ms at ~2 GHz: the whole step
         step[0] += 1
         tr.train_step(step[0])
+        if C and BWD_ONLY:
+            # (--bwd-only) what a reducer does: nothing beside the forward (~8.5 ms), collectives beside the backward.  The replay is one asynchronous host
+            # call; the occupant is launched from the host 8.5 ms later and holds its CUs for ~19 ms (to the end of the step)
+            time.sleep(8.5e-3)
+            occupy(C, int(19e-3 * 2.0e9), ctypes.c_void_p(side.cuda_stream))
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e3
 
 
+BWD_ONLY = "--bwd-only" in sys.argv
 only = [int(a) for a in sys.argv[1:] if a.isdigit()]      # e.g. `cu_contention.py 8` under rocprofv3: that occupancy only, no budget leg
 robust = "--robust" in sys.argv or not only                # (round 6) + the data-parallel trainer's setting: the BACKWARD planned for 224 CUs, whatever C is
 for C in (only or (0, 8, 16, 32)):
