@@ -915,7 +915,16 @@ def _claiming_cases(ops):
         "swiglu_bwd": lambda: ops.gemm_swiglu_bwd([dict(A=dY, B=W3, aux=GU)]),
         "dgrad": lambda: [ops.gemm(dH, W12, b_kmajor=True, out_dtype=torch.bfloat16)],
         "wgrad": lambda: ops.gemm_grouped(probs),
+        "wgrad224": lambda: _with_wgrad_budget(ops, 224, probs),      # the data-parallel plan: 224 whole-K tiles + 64 split tail tiles on the whole-device grid
     }
+
+
+def _with_wgrad_budget(ops, budget, probs):
+    before, ops.WGRAD_CU_BUDGET = ops.WGRAD_CU_BUDGET, budget
+    try:
+        return ops.gemm_grouped(probs)
+    finally:
+        ops.WGRAD_CU_BUDGET = before
 
 
 def test_gemm_dynamic_tile_claiming_equals_the_static_walk(ops):
@@ -929,7 +938,7 @@ def test_gemm_dynamic_tile_claiming_equals_the_static_walk(ops):
     dev = torch.device("cuda", torch.cuda.current_device())
     before = L.mmdit_gemm_get_claiming()      # (per-device setting: a data-parallel trainer of an earlier test leaves it on)
     assert L.mmdit_gemm_set_claiming(0) == 0 and L.mmdit_gemm_get_claiming() == 0
-    static = {k: f() for k, f in cases.items() if k != "wgrad"}      # claiming off: the static walk (ops registers the workspace at its first launch)
+    static = {k: f() for k, f in cases.items() if not k.startswith("wgrad")}      # claiming off: the static walk (ops registers the workspace at its first launch)
     assert L.mmdit_gemm_set_claiming(1) == 0 and L.mmdit_gemm_get_claiming() == 1
     try:
         _claiming_equals_static(ops, L, cases, dev, static)
@@ -940,6 +949,8 @@ def test_gemm_dynamic_tile_claiming_equals_the_static_walk(ops):
 
 def _claiming_equals_static(ops, L, cases, dev, static):
     dyn = {k: f() for k, f in cases.items()}
+    for a, b in zip(dyn["wgrad"], dyn["wgrad224"]):      # two decompositions of the same weight gradients (288 = 256 + 32 x S and 224 + 64 x S tiles)
+        assert rel(a, b) < 1e-5
     for k, outs in static.items():
         for a, b in zip(outs, dyn[k]):
             assert torch.equal(a, b), k
@@ -955,7 +966,7 @@ def _claiming_equals_static(ops, L, cases, dev, static):
     try:
         for k, f in cases.items():      # (ops does not register again: it has done so once for this device)
             for a, b in zip(f(), dyn[k]):
-                assert (torch.equal(a, b) if k != "wgrad" else rel(a, b) < 1e-5), k
+                assert (torch.equal(a, b) if not k.startswith("wgrad") else rel(a, b) < 1e-5), k
     finally:
         torch.cuda.synchronize()
         assert L.mmdit_gemm_set_workspace(ws.data_ptr(), ws.numel()) == 0
