@@ -114,6 +114,9 @@ __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const
 #endif
 #pragma unroll
   for (int i = 0; i < Geo<MT>::NB32; i++) {
+    int ln = lane;
+    if constexpr (SC) asm volatile("" : "+v"(ln));      // (per-block address VALU instead of spilled offsets: see epi8_swiglu)
+    const int wr = ln & 15, wq = ln >> 4, rr = ln >> 3, rc = ln & 7;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const f32x4& a = grp(acc, i, q);
@@ -237,22 +240,49 @@ __device__ __forceinline__ void epi8_swiglu_bwd(AccT<MT>& acc, const Problem& p,
   }
 }
 
-// QKV projection: the raw q / k columns + Q / K / V in the joint attention layout (gemm_tile.h epilogue_bf16_qk: same read-back side)
+// QKV projection: the raw q / k columns + Q / K / V in the joint attention layout (gemm_tile.h epilogue_bf16_qk: same read-back side, same arithmetic).
+// Round 6: the RoPE factors of a pass (8 rows x 128 B; 16 passes per wave and tile) are REQUESTED ONE PASS AHEAD, before the previous pass's stores.
+// Loads and stores of a wave retire through one in-order counter on gfx9 (vmcnt): a load issued behind a store is not back before that store has
+// been acknowledged.  For the compiler to emit the exact count, the loop must contain neither a store inside a conditional region (the number in
+// flight at the join is then unknown and the wait degrades to "everything but the newest request" -- the stores included) nor a conditional load
+// (a merge of old and new registers = copies that wait where the load was issued): FULL tiles are a compile-time variant, the factor loads are
+// unconditional (rows beyond M read the table's last row; a stream without rotation reads the norm weights -- 64 valid floats -- and ignores
+// them), the v columns have their own loop.  MX operands, MMDiT-L QKV (75392 x 3072 x 1024): 455 -> 420 us; bf16, MMDiT-B: 153 -> 131 us, the
+// wide-slot kernel's time (profiles/r06_epilogue_waits.txt).  What remains is the compute unit's memory path: per tile 512 KB of operands, 213 KB
+// of stores and 341 KB of factors (the four waves of a row block read the same table rows).
 template <int MT>
 __device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const GroupParams& gp, const QkEpi& e, int m0, int n0, int wm, int wn, int lane, char* stage) {
   bf16_t* C = (bf16_t*)p.C;
-  const int wr = lane & 15, wq = lane >> 4;
-  const int rr = lane >> 3, rc = lane & 7;
   const int colw = n0 + wn * 64;
   const int D = gp.qk_heads * 64, part = colw / D, head = (colw - part * D) >> 6;
-  const bool live = colw < p.N;
-  float w8[8], c8[8], s8[8];
+  if (colw >= p.N) return;      // (wave-uniform; the staging is wave-private and the epilogue has no barrier)
+  bf16_t* obase = part == 0 ? gp.qkQ : part == 1 ? gp.qkK : gp.qkV;
+  const int rowt = m0 + wm * (MT / 2);
+  const bool rope = e.rcos != nullptr;
+  const float* tc = rope ? e.rcos : e.wq;
+  const float* ts = rope ? e.rsin : e.wq;
+  float w8[8], cb[2][8], sb[2][8];      // the factors of two passes: one in use, one on its way (indices are constants once the loops are unrolled: no copies)
 #pragma unroll
   for (int q = 0; q < 8; q++) w8[q] = 0.f;
-  if (live && part < 2) ld8((part == 0 ? e.wq : e.wk) + rc * 8, w8);
-  bf16_t* obase = part == 0 ? gp.qkQ : part == 1 ? gp.qkK : gp.qkV;
-#pragma unroll
-  for (int i = 0; i < Geo<MT>::NB32; i++) {
+  if (part < 2) ld8((part == 0 ? e.wq : e.wk) + (lane & 7) * 8, w8);
+  // (sample, token) of a row: the block's first row by ONE wave-uniform division; its 32 rows are consecutive and a sample has more than 32 tokens or
+  // the rows wrap more than once -- the per-row division then
+  auto token_of = [&](int rowb, int b0, int r, int& b, int& n) __attribute__((always_inline)) {
+    b = b0; n = rowb - b0 * e.tokens + r;
+    if (e.tokens >= 32) { if (n >= e.tokens) { n -= e.tokens; b++; } }
+    else { b = (rowb + r) / e.tokens; n = rowb + r - b * e.tokens; }
+  };
+  auto request = [&](int i, int it, int ln, float (&cn)[8], float (&sn)[8]) __attribute__((always_inline)) {
+    const int rowb = rowt + i * 32;
+    const int b0 = __builtin_amdgcn_readfirstlane(rowb / e.tokens);
+    int b, n;
+    token_of(rowb, b0, it * 8 + (ln >> 3), b, n);
+    n = rope ? min(n, e.tokens - 1) : 0;
+    ld8(tc + (int64_t)n * 64 + (ln & 7) * 8, cn);
+    ld8(ts + (int64_t)n * 64 + (ln & 7) * 8, sn);
+  };
+  auto stage_block = [&](int i, int ln) __attribute__((always_inline)) {
+    const int wr = ln & 15, wq = ln >> 4;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       const f32x4& a = grp(acc, i, q);
@@ -260,50 +290,81 @@ __device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const G
       *LDS_PTR(u32x2, stage + row * 128 + ((chunk ^ (row & 7)) << 4) + (wq & 1) * 8) = (u32x2){pack_bf2(a[0], a[1]), pack_bf2(a[2], a[3])};
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int col = colw + rc * 8;
-    const int rowb = m0 + wm * (MT / 2) + i * 32;
-    const int b0 = __builtin_amdgcn_readfirstlane(rowb / e.tokens), n0r = rowb - b0 * e.tokens;
+  };
+  if (part == 2) {      // v: the attention operand IS the raw projection -- one store per pass (backward never reads the v columns of C)
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-      const int r = it * 8 + rr;
-      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
-      const int row = rowb + r;
-      if (!live || row >= p.M) continue;
-      int b = b0, n = n0r + r;
-      if (e.tokens >= 32) { if (n >= e.tokens) { n -= e.tokens; b++; } }
-      else { b = row / e.tokens; n = row - b * e.tokens; }
-      bf16_t* dst = obase + (((int64_t)b * gp.qk_heads + head) * gp.qk_s_total + e.tok0 + n) * 64 + rc * 8;
-      if (part == 2) {
-        *(u32x4*)dst = t;
-        continue;
+    for (int i = 0; i < Geo<MT>::NB32; i++) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));      // (per-block address VALU instead of spilled offsets: see epi8_swiglu)
+      stage_block(i, ln);
+      const int rr = ln >> 3, rc = ln & 7;
+      const int rowb = rowt + i * 32;
+      const int b0 = __builtin_amdgcn_readfirstlane(rowb / e.tokens);
+#pragma unroll
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        int b, n;
+        token_of(rowb, b0, r, b, n);
+        if (rowb + r < p.M) *(u32x4*)(obase + (((int64_t)b * gp.qk_heads + head) * gp.qk_s_total + e.tok0 + n) * 64 + rc * 8) = t;
       }
-      *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
-      float x[8];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    return;
+  }
+  auto qk_loop = [&](auto full_t) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_t)::value;
+    request(0, 0, lane, cb[0], sb[0]);
 #pragma unroll
-      for (int q = 0; q < 4; q++) { x[2 * q] = __builtin_bit_cast(float, t[q] << 16); x[2 * q + 1] = __builtin_bit_cast(float, t[q] & 0xffff0000u); }
-      if (e.rcos) {
-        ld8(e.rcos + (int64_t)n * 64 + rc * 8, c8);
-        ld8(e.rsin + (int64_t)n * 64 + rc * 8, s8);
-      }
-      float ss = 0.f;
+    for (int i = 0; i < Geo<MT>::NB32; i++) {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      stage_block(i, ln);
+      const int rr = ln >> 3, rc = ln & 7;
+      const int col = colw + rc * 8;
+      const int rowb = rowt + i * 32;
+      const int b0 = __builtin_amdgcn_readfirstlane(rowb / e.tokens);
 #pragma unroll
-      for (int q = 0; q < 8; q++) ss += x[q] * x[q];
-      ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
-      const float rinv = rsqrtf(ss * (1.f / 64.f) + 1.1920929e-07f);
+      for (int it = 0; it < 4; it++) {
+        const int r = it * 8 + rr;
+        const u32x4 t = *LDS_PTR(const u32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+        const int row = rowb + r;
+        int b, n;
+        token_of(rowb, b0, r, b, n);
+        bf16_t* dst = obase + (((int64_t)b * gp.qk_heads + head) * gp.qk_s_total + e.tok0 + n) * 64 + rc * 8;
+        const int cur = (i * 4 + it) & 1;
+        float (&c8)[8] = cb[cur];
+        float (&s8)[8] = sb[cur];
+        if (it < 3) request(i, it + 1, ln, cb[cur ^ 1], sb[cur ^ 1]);
+        else if (i + 1 < Geo<MT>::NB32) request(i + 1, 0, ln, cb[cur ^ 1], sb[cur ^ 1]);
+        float x[8];
 #pragma unroll
-      for (int q = 0; q < 8; q++) x[q] = x[q] * rinv * w8[q];
-      if (e.rcos) {
+        for (int q = 0; q < 4; q++) { x[2 * q] = __builtin_bit_cast(float, t[q] << 16); x[2 * q + 1] = __builtin_bit_cast(float, t[q] & 0xffff0000u); }
+        float ss = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const float a = x[2 * q], bb = x[2 * q + 1];
-          x[2 * q] = a * c8[2 * q] - bb * s8[2 * q];
-          x[2 * q + 1] = bb * c8[2 * q + 1] + a * s8[2 * q + 1];
+        for (int q = 0; q < 8; q++) ss += x[q] * x[q];
+        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        const float rinv = rsqrtf(ss * (1.f / 64.f) + 1.1920929e-07f);
+#pragma unroll
+        for (int q = 0; q < 8; q++) x[q] = x[q] * rinv * w8[q];
+        if (rope) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float a = x[2 * q], bb = x[2 * q + 1];
+            x[2 * q] = a * c8[2 * q] - bb * s8[2 * q];
+            x[2 * q + 1] = bb * c8[2 * q + 1] + a * s8[2 * q + 1];
+          }
+        }
+        if (FULL || row < p.M) {
+          *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
+          st8(dst, x);
         }
       }
-      st8(dst, x);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
+  };
+  if (m0 + MT <= p.M) qk_loop(std::integral_constant<bool, true>{});
+  else qk_loop(std::integral_constant<bool, false>{});
 }
 
 // SwiGLU-fused w12 GEMM: the wave's columns 0..31 are gate rows, 32..63 up rows of the SAME 32 hidden indices 128 tn + 32 wn + c (the DMA
@@ -328,6 +389,12 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
 #pragma unroll
   for (int i = 0; i < Geo<MT>::NB32; i++) {
     u32x2 pa[2][2];
+    // (MX kernels sit at 256 VGPRs with the next item's prologue state live: the per-lane staging offsets / row indices of this loop, hoisted, are
+    // SPILLED, and every reload is followed by s_waitcnt vmcnt(0) -- which waits for the stores just issued and for the next item's operand requests.
+    // The lane id is laundered per block so that the handful of address VALU is redone instead: tools/check_spills.py counts the epilogue too.)
+    int ln = lane;
+    if constexpr (MXOUT) asm volatile("" : "+v"(ln));
+    const int wr = ln & 15, wq = ln >> 4;
 #pragma unroll
     for (int il = 0; il < 2; il++)
 #pragma unroll
@@ -361,7 +428,7 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (GU) {
-      const int rr = lane >> 3, rc = lane & 7;
+      const int rr = ln >> 3, rc = ln & 7;
       const int col = (rc & 4 ? h : 0) + hc + (rc & 3) * 8;
 #pragma unroll
       for (int it = 0; it < 4; it++) {
@@ -398,9 +465,9 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
         if (wq == 0 && myrow < p.M) p.c_scales[mx_scale_index(myrow, hc >> 5, p.M)] = (unsigned char)(ex + 127);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const int r = lane >> 1, row = m0 + wm * (MT / 2) + i * 32 + r;
-      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 32 + (lane & 1) * 16);
-      if (row < p.M) *(u32x4*)((unsigned char*)p.C + (int64_t)row * p.ldc + hc + (lane & 1) * 16) = t;
+      const int r = ln >> 1, row = m0 + wm * (MT / 2) + i * 32 + r;
+      const u32x4 t = *LDS_PTR(const u32x4, stage + r * 32 + (ln & 1) * 16);
+      if (row < p.M) *(u32x4*)((unsigned char*)p.C + (int64_t)row * p.ldc + hc + (ln & 1) * 16) = t;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       continue;
     }
@@ -414,7 +481,7 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
-      const int rr = lane >> 2, rc = lane & 3;
+      const int rr = ln >> 2, rc = ln & 3;
 #pragma unroll
       for (int it = 0; it < 2; it++) {
         const int r = it * 16 + rr;
@@ -1096,7 +1163,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
       *(u32x4*)(pq + (int64_t)(i * 16) * dr_ld) = (u32x4){x[0], y[0], x[1], y[1]};
     }
   };
-  auto run_epilogue = [&](const Item& it) {
+  auto run_epilogue = [&](const Item& it) __attribute__((always_inline)) {
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------------
   const Problem& q = gp.p[it.pi];
   const int m0 = it.tm * MT, n0 = it.tn * 256;

@@ -909,7 +909,25 @@ def _claiming_cases(ops):
         for Mr in (16384, 9856):
             probs.append(dict(A=rnd(Mr, N, seed=60 + 2 * i + (Mr == 9856), dtype=torch.bfloat16), B=rnd(Mr, K, seed=80 + 2 * i + (Mr == 9856), dtype=torch.bfloat16),
                               a_kmajor=True, b_kmajor=True, out_dtype=torch.float32, stream_k=True))
+    # the fused QKV launch (QK-norm + RoPE + joint-layout store in the epilogue), image + text rows: with claiming on the planner gives it to the
+    # 8-phase kernel (927 claimed tiles), with claiming off to the wide-slot kernel
+    B, Ni, Mt, H = 64, 256, 154, 12
+    Ac = rnd(B * Mt, d, seed=9, dtype=torch.bfloat16)
+    Wc = rnd(3 * d, d, seed=10, dtype=torch.bfloat16)
+    wqk = [rnd(64, seed=11 + i).abs() + 0.5 for i in range(4)]
+    ang = rnd(Ni, 64, seed=15)
+    rc, rs = torch.cos(ang).contiguous(), torch.sin(ang).contiguous()
+
+    def qkv():
+        Q = torch.zeros((B, H, Ni + Mt, 64), dtype=torch.bfloat16, device="cuda")
+        K, V = torch.zeros_like(Q), torch.zeros_like(Q)
+        raw = ops.gemm_qkv_norm_rope([dict(A=A[:B * Ni], B=W, out_dtype=torch.bfloat16), dict(A=Ac, B=Wc, out_dtype=torch.bfloat16)],
+                                     [(wqk[0], wqk[1], rc, rs, Ni, 0), (wqk[2], wqk[3], None, None, Mt, Ni)], H, Ni + Mt, Q, K, V)
+        assert raw is not None
+        return [raw[0][:, :2 * d], raw[1][:, :2 * d], Q, K, V]      # (the v columns of the raw projection are not written)
+
     return {
+        "qkv": qkv,
         "linear": lambda: [ops.gemm(A, W, out_dtype=torch.bfloat16)],
         "swiglu": lambda: [ops.gemm(A, W12, bias=b12, act=ops.ACT_SWIGLU)],
         "swiglu_bwd": lambda: ops.gemm_swiglu_bwd([dict(A=dY, B=W3, aux=GU)]),
@@ -952,8 +970,8 @@ def _claiming_equals_static(ops, L, cases, dev, static):
     for a, b in zip(dyn["wgrad"], dyn["wgrad224"]):      # two decompositions of the same weight gradients (288 = 256 + 32 x S and 224 + 64 x S tiles)
         assert rel(a, b) < 1e-5
     for k, outs in static.items():
-        for a, b in zip(outs, dyn[k]):
-            assert torch.equal(a, b), k
+        for a, b in zip(outs, dyn[k]):      # (the fused QKV launch changes KERNEL with the switch -- wide-slot vs 8-phase: equal to bf16 rounding, not bit for bit)
+            assert (torch.equal(a, b) if k != "qkv" else rel(a.float(), b.float()) < 4e-3), k
     ws = ops._GEMM_WS[dev]
     assert int(ws[:8192].view(torch.int32).abs().sum()) == 0, "tickets / queue heads are left zero by every launch"
     for _ in range(30):

@@ -548,7 +548,7 @@ def _autotune_worker(rank, world, port, q):
 
 def test_eight_rank_gloo_reducer_autotune_is_a_collective_decision():
     """world_size 8: vote_fastest returns the same winner (the smallest maximum over the ranks, not anybody's local favourite) and the same table on every
-    rank; autotune_reducer -- two timed optimizer steps per candidate on the CPU trainer, three algorithms then three reserves -- leaves all eight ranks on
+    rank; autotune_reducer -- two timed blocks of two optimizer steps per candidate (the faster block counts) on the CPU trainer, three algorithms then three reserves -- leaves all eight ranks on
     the same algorithm and reserve, counts the steps it ran, and the replicas stay bit-identical through and after it."""
     world, port = 8, _free_port()
     ctx = mp.get_context("spawn")
@@ -567,7 +567,7 @@ def test_eight_rank_gloo_reducer_autotune_is_a_collective_decision():
         assert (best, worst, step, table) == (best0, worst0, step0, table0), "every rank holds the same table and winner"
         assert algo == "direct" and reserve == 16 and table["chosen"] == {"algorithm": "direct", "reserved_cus": 16, "blocks_per_fork": table["chosen"]["blocks_per_fork"], "steps_each": 2}
         assert table["chosen"]["blocks_per_fork"] in (1, 2, 3) and set(table["blocks_per_fork"]) == {"1", "2", "3"}
-        assert step == 1 + 3 * 3 + 3 * 3 + 3 * 3          # (1 settling + 2 timed steps for each of 3 algorithms, 3 reserves and 3 fork widths)
+        assert step == 1 + 3 * 5 + 3 * 5 + 3 * 5          # (1 settling + 2 blocks of 2 timed steps for each of 3 algorithms, 3 reserves and 3 fork widths)
         assert all(l == l for l in losses)
         for a, b in zip(params, res[0][7]):
             assert (a == b).all(), "ranks diverged"
@@ -603,7 +603,7 @@ def _train_loop_worker(rank, world, port, q):
 
 
 def test_two_rank_gloo_train_loop_with_the_reducer_autotune():
-    """model_trainer.train() on 2 gloo ranks (the CPU trainer): after its first step the loop runs autotune_reducer -- (1 + 2) optimizer steps for each of three bucket
+    """model_trainer.train() on 2 gloo ranks (the CPU trainer): after its first step the loop runs autotune_reducer -- (1 + 2 + 2) optimizer steps for each of three bucket
     algorithms, three reserves and three fork widths, real training steps on fresh batches -- and goes on; exactly totalSteps batches are consumed and totalSteps losses recorded, both ranks
     hold the same table and setting, and the replicas end bit-identical."""
     world, port = 2, _free_port()

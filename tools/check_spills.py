@@ -1,7 +1,10 @@
 """Build-time guard for the 8-phase GEMM kernels (csrc/gemm8p.hip): they live at the 256-VGPR edge, and a scratch access INSIDE the K loop is a
 catastrophe there -- a scratch_load is a VMEM load, the compiler follows it with s_waitcnt vmcnt(0), and that drains the LDS-DMA queue the loop
 keeps two K tiles deep (measured: the 320-row forward kernel 1.58 -> 1.91 ms per step from TWO such reloads).  Compiles the file with -save-temps
-and fails if any gemm8 kernel has a scratch instruction between its K-loop header and the loop's backward branch.
+and fails if any gemm8 kernel has a scratch instruction between its K-loop header and the loop's backward branch -- or, round 6, if a 256-row
+forward kernel without per-tensor scales (plain / SwiGLU / QKV / MX epilogues: the ones whose epilogue makes a pass per 8 or 32 rows) has ANY scratch
+access: a reload inside such a pass is followed by s_waitcnt vmcnt(0), i.e. by a wait for the stores the pass has just issued (the MX SwiGLU launch of
+the mxfp8 sampler: 863 -> 755 us when its 64 reloads went away, profiles/r06_epilogue_waits.txt).
     python tools/check_spills.py [extra hipcc flags]           (needs hipcc; ~10 s; run by tests/test_oracle_cpu.py)"""
 import os
 import re
@@ -42,6 +45,11 @@ def main():
             j += 1
         body = asm[i:j]
         kernels += 1
+        # <256 rows, !WGRAD, !KMAJOR-B, epilogue, ..., per-tensor scales = false>: no scratch at all
+        if re.search(r"gemm8_kernelILi256ELb0ELb0ELi\d+ELb0ELb[01]ELb[01]ELb0EEE", name):
+            n = sum("scratch_" in l for l in body)
+            if n:
+                bad.append((name, f"{n} scratch accesses in a kernel that must have none"))
         # the K loop: the innermost loop (Depth=2) of the item loop; from its header label to the conditional branch back to that label
         for k, line in enumerate(body):
             if "Inner Loop Header: Depth=2" in line:
@@ -60,7 +68,7 @@ def main():
                 if n and any("v_mfma" in l for l in body[k:end]):
                     bad.append((name, n))
         i = j
-    print(f"{kernels} gemm8 kernels checked; in-loop scratch instructions: {bad if bad else 'none'}")
+    print(f"{kernels} gemm8 kernels checked; in-loop scratch instructions / scratch in the no-scratch kernels: {bad if bad else 'none'}")
     return 1 if bad or not kernels else 0
 
 
