@@ -59,6 +59,17 @@ __device__ __forceinline__ f32x4& grp(AccT<MT>& acc, int i32, int q) {
   return acc.a[f16 / FI][j16 >> 1][(f16 % FI) * 2 + (j16 & 1)];
 }
 
+// A 16-byte global store the compiler does NOT count (inline asm).  gfx9 retires loads and stores of a wave through one in-order counter (vmcnt) and
+// the compiler keeps its model of that queue exact only along straight-line code: a store inside `if (row < M)` makes the number of requests in
+// flight unknown at the join, and every later wait for a LOAD then degrades to vmcnt(0) -- it waits for the stores just issued.  With the stores
+// of an epilogue pass hidden, the compiler counts the (unconditional) loads alone: vmcnt(n) with n = the loads issued since can only wait for MORE
+// than the load it is after (the hidden stores sit in the same queue), never for less -- safe -- and in practice it waits for stores that are at
+// least a pass old.  Store data is read from the registers when the instruction issues (no wait before they are overwritten on gfx9).
+__device__ __forceinline__ void st16_uncounted(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8_uncounted(bf16_t* p, const float (&v)[8]) {
+  st16_uncounted(p, (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
+}
+
 // ---- epilogues (the arithmetic and the read-back / store side are those of gemm_tile.h; only the write side knows the fragment layout) ------
 // bf16 output (+ bias, + SiLU): the wave's 32 x 64 block is converted first, staged as 32 rows x 128 B (chunk c of row r at c ^ (r & 7)) and
 // leaves as 8 rows x 128 B per wave instruction
@@ -173,17 +184,17 @@ __device__ __forceinline__ void epi8_swiglu_bwd(AccT<MT>& acc, const Problem& p,
   // The pre-activation rows of the next 32-row block are requested before the current block is converted (double buffer: 2 x 8 quads).
   // (Requesting all four blocks up front -- 32 KB per wave in flight, the retired blocks parked in packed form -- measured SLOWER, 246 vs 225 us
   //  per launch at MMDiT-B: 30 spilled registers, and the epilogue phases are HBM-bound anyway: 256 CUs x 512 KB per round.)
+  // Round 6: the loads are UNCONDITIONAL (rows beyond M read row M - 1, columns beyond N the last 8: values nobody uses) and the stores of the
+  // passes are not counted (st8_uncounted): before, every pass ended in s_waitcnt vmcnt(0) (profiles/r06_epilogue_waits.txt).
   u32x4 gq[2][4], uq[2][4];
-  auto request = [&](int i, int b) {
+  const int colc = cok ? col : p.N - 8;
+  auto request = [&](int i, int b) __attribute__((always_inline)) {
 #pragma unroll
     for (int it = 0; it < 4; it++) {
-      const int row = row0 + i * 32 + it * 8;
-      gq[b][it] = uq[b][it] = (u32x4){0u, 0u, 0u, 0u};
-      if (row < p.M && cok) {                          // (saved pre-activations at their last use: streaming loads)
-        const bf16_t* src = GU + (int64_t)row * p.ld_aux + col;
-        gq[b][it] = __builtin_nontemporal_load((const u32x4*)src);
-        uq[b][it] = __builtin_nontemporal_load((const u32x4*)(src + p.N));
-      }
+      const int row = min(row0 + i * 32 + it * 8, p.M - 1);
+      const bf16_t* src = GU + (int64_t)row * p.ld_aux + colc;      // (saved pre-activations at their last use: streaming loads)
+      gq[b][it] = __builtin_nontemporal_load((const u32x4*)src);
+      uq[b][it] = __builtin_nontemporal_load((const u32x4*)(src + p.N));
     }
   };
   float sg[8], su[8];
@@ -221,8 +232,8 @@ __device__ __forceinline__ void epi8_swiglu_bwd(AccT<MT>& acc, const Problem& p,
 #pragma unroll
         for (int e = 0; e < 8; e++) { sg[e] += og[e]; su[e] += ou[e]; }
         bf16_t* dst = D + (int64_t)row * p.ldc + col;
-        st8(dst, og);
-        st8(dst + p.N, ou);
+        st8_uncounted(dst, og);
+        st8_uncounted(dst + p.N, ou);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next block overwrites the region
