@@ -70,6 +70,17 @@ __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
 __device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
   *(uint4*)p = make_uint4(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7]));
 }
+// A 16-byte global store the compiler does NOT count (inline asm).  gfx9 retires loads and stores of a wave through one in-order counter (vmcnt) and
+// the compiler keeps its model of that queue exact only along straight-line code: a store inside `if (row < M)` makes the number of requests in
+// flight unknown at the join, and every later wait for a LOAD then degrades to vmcnt(0) -- it waits for the stores just issued.  With the stores
+// of an epilogue pass hidden, the compiler counts the (unconditional) loads alone: vmcnt(n) with n = the loads issued since can only wait for MORE
+// than the load it is after (the hidden stores sit in the same queue), never for less -- safe -- and in practice it waits for stores that are at
+// least a pass old.  Store data is read from the registers when the instruction issues (no wait before they are overwritten on gfx9).
+__device__ __forceinline__ void st16_uncounted(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st8_uncounted(bf16_t* p, const float (&v)[8]) {
+  st16_uncounted(p, (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
+}
+
 __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) { float4 a = *(const float4*)p; v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; }
 __device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
   uint2 a = *(const uint2*)p;

@@ -59,17 +59,6 @@ __device__ __forceinline__ f32x4& grp(AccT<MT>& acc, int i32, int q) {
   return acc.a[f16 / FI][j16 >> 1][(f16 % FI) * 2 + (j16 & 1)];
 }
 
-// A 16-byte global store the compiler does NOT count (inline asm).  gfx9 retires loads and stores of a wave through one in-order counter (vmcnt) and
-// the compiler keeps its model of that queue exact only along straight-line code: a store inside `if (row < M)` makes the number of requests in
-// flight unknown at the join, and every later wait for a LOAD then degrades to vmcnt(0) -- it waits for the stores just issued.  With the stores
-// of an epilogue pass hidden, the compiler counts the (unconditional) loads alone: vmcnt(n) with n = the loads issued since can only wait for MORE
-// than the load it is after (the hidden stores sit in the same queue), never for less -- safe -- and in practice it waits for stores that are at
-// least a pass old.  Store data is read from the registers when the instruction issues (no wait before they are overwritten on gfx9).
-__device__ __forceinline__ void st16_uncounted(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st8_uncounted(bf16_t* p, const float (&v)[8]) {
-  st16_uncounted(p, (u32x4){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])});
-}
-
 // ---- epilogues (the arithmetic and the read-back / store side are those of gemm_tile.h; only the write side knows the fragment layout) ------
 // bf16 output (+ bias, + SiLU): the wave's 32 x 64 block is converted first, staged as 32 rows x 128 B (chunk c of row r at c ^ (r & 7)) and
 // leaves as 8 rows x 128 B per wave instruction
