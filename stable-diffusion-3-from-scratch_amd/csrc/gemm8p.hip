@@ -666,7 +666,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
   // (320-row tiles keep the static walk: the scalars this adds to what is live across the main loop cost the <320, swiglu> kernel six scratch
   //  reloads inside it.)
   int* const sq = gp.sched;
-  const bool dyn = MT == 256 && sq != nullptr;      // (kernel-uniform; 320-row tiles: never -- see launch8)
+  // (kernel-uniform; 320-row tiles: never -- see launch8.  The e4m3-operand / convolution kernels -- inference -- never: claiming exists for the data-parallel
+  //  training step, and the per-tensor fp8 SwiGLU kernel has no register to give it: there the compiler COPIES the claim register while the atomic that
+  //  fills it may be in flight (tools/check_spills.py audits that in every kernel that claims))
+  const bool dyn = MT == 256 && !MX && !CONV && sq != nullptr;
   const int xq = (int)blockIdx.x & (NXCD - 1);
   char* const s_next = smem + 16;      // (byte 0: the split tail's ticket)
   uint32_t claim_v = 0;                // wave 0, lane 0: what the last claim_issue returned (the word's value before the add)
@@ -1429,7 +1432,7 @@ int launch8(const GroupParams& gp, hipStream_t s) {
   const int work = total_work(gp);
   const int cu = mmdit_get_cu_budget();      // what the planner counted on
   const bool persistent = gp.persistent && work > cu;
-  if (MT == 256 && persistent && gp.tail_first < 0) {
+  if (MT == 256 && !MX && !CONV && persistent && gp.tail_first < 0) {
     // more positions than the budget's workgroups: claimed dynamically when the workspace is registered (mmdit_gemm_set_workspace) -- on the WHOLE device:
     // a workgroup whose compute unit is taken starts late, finds the queues empty and leaves; one whose compute unit is free does its share
     GroupParams gq = gp;

@@ -973,7 +973,9 @@ def _claiming_equals_static(ops, L, cases, dev, static):
         for a, b in zip(outs, dyn[k]):      # (the fused QKV launch changes KERNEL with the switch -- wide-slot vs 8-phase: equal to bf16 rounding, not bit for bit)
             assert (torch.equal(a, b) if k != "qkv" else rel(a.float(), b.float()) < 4e-3), k
     ws = ops._GEMM_WS[dev]
-    assert int(ws[:8192].view(torch.int32).abs().sum()) == 0, "tickets / queue heads are left zero by every launch"
+    words = ws[:8192].view(torch.int32)
+    left = [(i, int(words[i])) for i in torch.nonzero(words).flatten().tolist()]
+    assert not left, f"tickets / queue heads are left zero by every launch; nonzero (word, value): {left[:16]}"
     for _ in range(30):
         for k, f in cases.items():
             for a, b in zip(f(), dyn[k]):

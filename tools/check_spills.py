@@ -45,6 +45,34 @@ def main():
             j += 1
         body = asm[i:j]
         kernels += 1
+        # dynamic tile claiming: the returning atomic is issued from inline asm by one lane and its destination register is consumed behind an explicit
+        # s_waitcnt vmcnt(0) much later (csrc/gemm8p.hip claim_issue / claim_take) -- the compiler does not know the register is filled asynchronously,
+        # so it must never COPY, SPILL or OVERWRITE it while a claim may be in flight: after the first claim the register may only be written by claim
+        # atomics and read by ordinary instructions (found in round 6: the per-tensor fp8 SwiGLU kernel moved it through v_mov pairs -- wrong tiles)
+        claims = [k for k, l in enumerate(body) if "global_atomic_add" in l and " sc0" in l and any("s_mov_b64 exec, 1" in body[x] for x in range(max(0, k - 3), k))]
+        for reg in sorted({int(re.search(r"global_atomic_add v(\d+)", body[k]).group(1)) for k in claims}):
+            first = min(k for k in claims if re.search(rf"global_atomic_add v{reg}\b", body[k]))
+
+            def has(tok):
+                m = re.fullmatch(r"v(\d+)", tok)
+                if m:
+                    return int(m.group(1)) == reg
+                m = re.fullmatch(r"v\[(\d+):(\d+)\]", tok)
+                return bool(m) and int(m.group(1)) <= reg <= int(m.group(2))
+
+            for k in range(first + 1, len(body)):
+                t = body[k].split(";")[0].strip()
+                if not t or t.endswith(":") or k in claims:
+                    continue
+                op, _, rest = t.partition(" ")
+                toks = [x.strip() for x in rest.replace("|", "").split(",")]
+                toks = [x.split(" ")[0] for x in toks if x]
+                if not any(has(x) for x in toks):
+                    continue
+                writes = bool(toks) and has(toks[0]) and not op.startswith(("v_cmp", "global_store", "ds_write", "scratch_store", "buffer_store", "s_"))
+                if writes or op.startswith(("v_mov", "v_accvgpr", "scratch_store", "v_swap", "v_permlane")):
+                    bad.append((name, f"claim register v{reg} copied / overwritten: {t}"))
+                    break
         # <256 rows, !WGRAD, !KMAJOR-B, epilogue, ..., per-tensor scales = false>: no scratch at all
         if re.search(r"gemm8_kernelILi256ELb0ELb0ELi\d+ELb0ELb[01]ELb[01]ELb0EEE", name):
             n = sum("scratch_" in l for l in body)
@@ -68,7 +96,7 @@ def main():
                 if n and any("v_mfma" in l for l in body[k:end]):
                     bad.append((name, n))
         i = j
-    print(f"{kernels} gemm8 kernels checked; in-loop scratch instructions / scratch in the no-scratch kernels: {bad if bad else 'none'}")
+    print(f"{kernels} gemm8 kernels checked; in-loop scratch / scratch in the no-scratch kernels / copied claim registers: {bad if bad else 'none'}")
     return 1 if bad or not kernels else 0
 
 
