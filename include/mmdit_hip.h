@@ -169,7 +169,9 @@ int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit_qk_epilogu
 int mmdit_gemm_set_workspace(void* ptr, long long bytes);
 /* Dynamic tile claiming of the persistent 8-phase launches (above) on / off, per device, default OFF: it costs a launch ~3 us (the first claim, the LDS
  * hand-over of each claimed position, one look at the other queues at the end: +0.12 ms = +0.4 % on the MMDiT-B step) and pays when another kernel holds compute units
- * while the GEMMs run -- model_trainer turns it on when gradients are reduced (RCCL's channels on the reducer's stream).  Needs the workspace. */
+ * while the GEMMs run -- model_trainer turns it on when gradients are reduced (RCCL's channels on the reducer's stream).  Needs the workspace.
+ * bf16-operand launches only (the training step): e4m3-operand and convolution launches keep the static walk whatever the switch says.  With claiming
+ * on, mmdit_gemm_qkv_norm_rope runs bf16 problems on the 8-phase kernel (claimed) instead of the wide-slot kernel: the same values to bf16 rounding. */
 int mmdit_gemm_set_claiming(int on);
 int mmdit_gemm_get_claiming(void);
 /* Test / measurement aid: `wgs` (1..256) one-wave workgroups with 1 KiB of LDS each sleep-spin for `cycles` shader cycles on `stream` -- a stand-in for a
