@@ -433,7 +433,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     cfg = pick_dma_cfg(args, count, split_k, stream_k, lean_ok);
     if (swiglu && cfg != CFG_320x256) cfg = CFG_256x256;   // the activation pairs gate / up columns inside a 256-column tile
     if (swiglu_bwd) cfg = CFG_256x256;                     // (the fused backward epilogue exists at 256 rows)
-    static const char* qk8_env = getenv("MMDIT_QK_8PHASE");   // experiment: bf16 QKV launches on the 8-phase kernel too (tools/README.md)
+    static const char* qk8_env = mmdit_exp_env("MMDIT_QK_8PHASE");   // experiment (probes builds): bf16 QKV launches on the 8-phase kernel without claiming
     static const bool qk8 = qk8_env && atoi(qk8_env) > 0;
     // (MX operands + the QKV epilogue: the 8-phase kernel's 256-row tile; bf16: the same kernel when tiles are CLAIMED -- since round 6 it takes
     // the wide-slot kernel's time, 131 us at MMDiT-B, and its 927 tiles are then immune to held compute units like the other multi-round launches)
