@@ -240,6 +240,35 @@ def test_8_phase_gemm_kernels_have_no_scratch_access_in_their_k_loop():
     assert r.returncode == 0, r.stdout + r.stderr
 
 
+def test_the_isa_audit_flags_what_it_is_there_for():
+    """tools/check_spills.audit on synthetic kernels: (1) a scratch reload inside a K loop (a loop with MFMAs); (2) any scratch access in a 256-row forward
+    kernel whose epilogue works in passes; (3) the register a tile claim's returning atomic fills (issued with EXEC = 1 from inline asm, consumed behind an
+    explicit vmcnt(0) much later) copied or overwritten by the compiler -- the round-6 bug of the per-tensor fp8 SwiGLU kernel; and a clean kernel passes."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("check_spills", os.path.join(root, "tools", "check_spills.py"))
+    cs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cs)
+    wgrad = "_ZN12_GLOBAL__N_112gemm8_kernelILi256ELb1ELb1ELi3ELb0ELb0ELb0ELb0EEEvN4gemm11GroupParamsE"      # may spill outside its K loop
+    fwd = "_ZN12_GLOBAL__N_112gemm8_kernelILi256ELb0ELb0ELi1ELb0ELb0ELb0ELb0EEEvN4gemm11GroupParamsE"        # must not touch scratch at all
+
+    def kernel(name, pre=(), loop=(), post=()):
+        return [name + ":"] + list(pre) + [".LBB0_1:", "; =>  This Inner Loop Header: Depth=2", "\tv_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]"] + list(loop) + \
+               ["\ts_cbranch_scc1 .LBB0_1"] + list(post) + ["\ts_endpgm"]
+
+    claim = ["\ts_mov_b64 s[0:1], exec", "\ts_mov_b64 exec, 1", "\tglobal_atomic_add v9, v3, v2, s[14:15] sc0", "\ts_mov_b64 exec, s[0:1]"]
+    use = ["\ts_waitcnt vmcnt(0)", "\tv_lshl_or_b32 v2, v9, 3, s3", "\tv_cmp_eq_u32_e64 s[0:1], s70, v9"]
+    assert cs.audit(kernel(wgrad, pre=["\tscratch_store_dword off, v1, off"], post=["\tscratch_load_dword v1, off, off"] + claim + use)) == (1, [])
+    n, bad = cs.audit(kernel(wgrad, loop=["\tscratch_load_dword v1, off, off offset:4"]))
+    assert n == 1 and len(bad) == 1 and bad[0][1] == 1, bad
+    n, bad = cs.audit(kernel(fwd, post=["\tscratch_load_dword v1, off, off"]))
+    assert n == 1 and len(bad) == 1 and "must have none" in bad[0][1], bad
+    for stray in ("\tv_mov_b32_e32 v1, v9", "\tv_mov_b32_e32 v9, v1", "\tscratch_store_dwordx2 off, v[8:9], off offset:20", "\tv_add_u32_e32 v9, v1, v2"):
+        n, bad = cs.audit(kernel(wgrad, post=claim + [stray] + use))
+        assert n == 1 and len(bad) == 1 and "claim register v9" in bad[0][1], (stray, bad)
+    assert cs.audit(["nothing here"]) == (0, [])
+
+
 def test_product_path_fails_loudly_without_gpu():
     import sd3_amd  # noqa: F401
     from sd3_amd import ops

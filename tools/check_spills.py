@@ -33,6 +33,13 @@ def main():
                 print(r.stderr[-4000:], file=sys.stderr)
                 return 2
             asm += open(os.path.join(td, stem + "-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
+    kernels, bad = audit(asm)
+    print(f"{kernels} gemm8 kernels checked; in-loop scratch / scratch in the no-scratch kernels / copied claim registers: {bad if bad else 'none'}")
+    return 1 if bad or not kernels else 0
+
+
+def audit(asm):
+    """(number of gemm8 kernels found, list of (kernel, finding)) for the lines of a gfx950 .s file (tests/test_oracle_cpu.py feeds it synthetic kernels)."""
     bad, kernels = [], 0
     i = 0
     while i < len(asm):
@@ -96,8 +103,7 @@ def main():
                 if n and any("v_mfma" in l for l in body[k:end]):
                     bad.append((name, n))
         i = j
-    print(f"{kernels} gemm8 kernels checked; in-loop scratch / scratch in the no-scratch kernels / copied claim registers: {bad if bad else 'none'}")
-    return 1 if bad or not kernels else 0
+    return kernels, bad
 
 
 if __name__ == "__main__":

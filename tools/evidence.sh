@@ -61,6 +61,8 @@ rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_l -o run -- python3 tools/probe
 python tools/rocpd_stats.py $(find gpurun_out/prof_${R}_l -name "*.db" | head -1) 8 40 > gpurun_out/${R}_l_kernel_stats.txt; rm -rf gpurun_out/prof_${R}_l
 rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_s -o run -- python3 tools/sampler_bench.py --batch 16 > gpurun_out/${R}_sampler_prof.log 2>&1
 python tools/rocpd_stats.py $(find gpurun_out/prof_${R}_s -name "*.db" | head -1) > gpurun_out/${R}_sampler_kernel_stats.txt; rm -rf gpurun_out/prof_${R}_s
+rocprofv3 --kernel-trace -d gpurun_out/prof_${R}_s8 -o run -- python3 tools/sampler_bench.py --modes mxfp8 > gpurun_out/${R}_sampler_mxfp8_prof.log 2>&1
+python tools/rocpd_stats.py $(find gpurun_out/prof_${R}_s8 -name "*.db" | head -1) > gpurun_out/${R}_sampler_mxfp8_kernel_stats.txt; rm -rf gpurun_out/prof_${R}_s8
 python -m pytest tests -m gpu -q -s 2>&1 | grep "^\[\|passed\|failed" > gpurun_out/${R}_parity_numbers.txt
 # round 5: the reference's own stages (19 x 1216 at 256^2 / 512^2 / 1024^2), the fp8 / MX GEMM table, the 16x16x128 layout probe
 python tools/stage_bench.py --stages 1,2,3 2>/dev/null | grep "^{" > gpurun_out/${R}_trained_stages.txt
