@@ -538,36 +538,75 @@ __device__ __forceinline__ void epi8_f32(AccT<MT>& acc, const Problem& p, int m0
 template <int MT>
 __device__ __forceinline__ void epi8_f32r(AccT<MT>& acc, const Problem& p, int m0, int n0, int wm, int wn, int lane, char* stage) {
   float* C = (float*)p.C;
+  constexpr int NBLK = Geo<MT>::NB32 * 2;      // 32 x 32 blocks of the wave's 128 x 64: block k = (i = k / 2, j = k % 2)
   const int wr = lane & 15, wq = lane >> 4;
   const int rr = lane >> 3, rc = lane & 7;
+  const int rowt = m0 + wm * (MT / 2) + rr;
+  const int colj[2] = {n0 + wn * 64 + rc * 4, n0 + wn * 64 + 32 + rc * 4};
+  f32x4 b4[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  if (p.bias) {
 #pragma unroll
-  for (int i = 0; i < Geo<MT>::NB32; i++)
+    for (int j = 0; j < 2; j++) b4[j] = *(const f32x4*)(p.bias + min(colj[j], p.N - 4));      // (columns beyond N: a valid address, a value nobody stores)
+  }
+  auto stage_block = [&](int k) __attribute__((always_inline)) {
+    const int i = k >> 1, j = k & 1;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int col = n0 + wn * 64 + j * 32 + rc * 4;
-      const int row0 = m0 + wm * (MT / 2) + i * 32 + rr;
-      f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-      if (p.bias && col < p.N) b4 = *(const f32x4*)(p.bias + col);
+    for (int il = 0; il < 2; il++)
 #pragma unroll
-      for (int il = 0; il < 2; il++)
+      for (int jj = 0; jj < 2; jj++) {
+        const int row = il * 16 + wr;
+        *LDS_PTR(f32x4, stage + row * 128 + (((jj * 4 + wq) ^ (row & 7)) << 4)) = grp(acc, i, il * 4 + j * 2 + jj);
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  if (!p.residual) {      // (wave-uniform)
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
-          const int row = il * 16 + wr;
-          *LDS_PTR(f32x4, stage + row * 128 + (((jj * 4 + wq) ^ (row & 7)) << 4)) = grp(acc, i, il * 4 + j * 2 + jj);
-        }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int k = 0; k < NBLK; k++) {
+      stage_block(k);
+      const int col = colj[k & 1];
 #pragma unroll
       for (int it = 0; it < 4; it++) {
         const int r = it * 8 + rr;
         f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
-        const int row = row0 + it * 8;
+        const int row = rowt + (k >> 1) * 32 + it * 8;
         if (row >= p.M || col >= p.N) continue;
-        t += b4;
-        if (p.residual) t += *(const f32x4*)(p.residual + (int64_t)row * p.ld_res + col);
+        t += b4[k & 1];
         *(f32x4*)(C + (int64_t)row * p.ldc + col) = t;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+    return;
+  }
+  // With a residual (the second convolution of a FLUX-VAE ResNet block) every pass used to load its 16 bytes of shortcut, wait for them -- behind the
+  // stores of the pass before, through the one in-order counter -- and store: one 1 KB request in flight per wave, ~3 GB/s per compute unit for the
+  // tile's 256 KB of shortcut.  Round 6: the shortcut rows of block k + 1 are requested before block k is staged (unconditional loads, clamped
+  // addresses) and the stores are not counted by the compiler (st16_uncounted): 4-8 requests in flight per wave, waits on loads only.
+  f32x4 res[2][4];
+  auto request = [&](int k, f32x4 (&dst)[4]) __attribute__((always_inline)) {
+    const int col = min(colj[k & 1], p.N - 4);
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int row = min(rowt + (k >> 1) * 32 + it * 8, p.M - 1);
+      dst[it] = *(const f32x4*)(p.residual + (int64_t)row * p.ld_res + col);
+    }
+  };
+  request(0, res[0]);
+#pragma unroll
+  for (int k = 0; k < NBLK; k++) {
+    if (k + 1 < NBLK) request(k + 1, res[(k + 1) & 1]);
+    stage_block(k);
+    const int col = colj[k & 1];
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+      const int r = it * 8 + rr;
+      f32x4 t = *LDS_PTR(const f32x4, stage + r * 128 + ((rc ^ (r & 7)) << 4));
+      const int row = rowt + (k >> 1) * 32 + it * 8;
+      t += b4[k & 1];
+      t += res[k & 1][it];
+      if (row < p.M && col < p.N) st16_uncounted(C + (int64_t)row * p.ldc + col, __builtin_bit_cast(u32x4, t));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
 }
 
 // a partial tile of the split tail into its workspace slot (row-major [256][256] fp32, device-scope write-through stores)
