@@ -617,13 +617,18 @@ def test_gemm_stream_k_grouped_wgrad(ops):
         assert rel(o, r) < 1e-5
 
 
+@pytest.mark.parametrize("claiming", [False, True])
 @pytest.mark.parametrize("Bt,H,h2,w2,Mt,K", [(64, 12, 16, 16, 154, 768), (16, 16, 32, 32, 154, 1024), (3, 4, 4, 6, 10, 256)])
-def test_gemm_qkv_epilogue_with_qk_norm_rope_equals_gemm_plus_row_kernel(ops, Bt, H, h2, w2, Mt, K):
+def test_gemm_qkv_epilogue_with_qk_norm_rope_equals_gemm_plus_row_kernel(ops, Bt, H, h2, w2, Mt, K, claiming):
     """mmdit_gemm_qkv_norm_rope (QKV projection whose epilogue applies the per-head QK RMSNorm + axial RoPE and writes Q, K, V in the
     joint attention layout; Attention.py:118-135, 174-194, 258-261) against the two launches it replaces, mmdit_gemm_grouped +
     mmdit_qk_norm_rope_fwd_pair: the q / k columns of the raw projections bit-identical, Q / K / V equal up to the last bf16 bit on a vanishing fraction of
     the elements (the same arithmetic on the same rounded values; only instruction selection may differ), and both against an fp32
-    torch reference.  MMDiT-B and MMDiT-L block shapes and a small ragged one (rows not a multiple of the tile)."""
+    torch reference.  MMDiT-B and MMDiT-L block shapes and a small ragged one (rows not a multiple of the tile, fewer than 32 tokens per sample).
+    claiming: with mmdit_gemm_set_claiming(1) -- the data-parallel trainer's setting -- the planner gives the fused launch to the 8-phase kernel (epi8_qk:
+    factors requested a pass ahead, FULL tiles as a compile-time variant) instead of the wide-slot kernel; the conftest fixture switches it off again."""
+    from sd3_amd import _lib
+    assert _lib.lib().mmdit_gemm_set_claiming(1 if claiming else 0) == 0
     N = h2 * w2
     S, d = N + Mt, H * 64
     cos, sin = _rope_tables(h2, w2)
