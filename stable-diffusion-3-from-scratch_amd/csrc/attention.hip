@@ -165,17 +165,6 @@ __device__ __forceinline__ void lds_row8(const float* tile, int r, int c, float 
 #pragma unroll
   for (int e = 0; e < 4; e++) { v[e] = a[e]; v[4 + e] = b[e]; }
 }
-// sum over the 8 lanes of a row (lane bits 2:0) on the DPP path (quad_perm 1032, quad_perm 2301, row_half_mirror): three dependent
-// VALU moves instead of three LDS round trips (ds_bpermute) -- the epilogue is a latency chain, not a throughput problem
-template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float sum8(float x) {
-  x += dpp_f<0xB1>(x);
-  x += dpp_f<0x4E>(x);
-  return x + dpp_f<0x141>(x);
-}
-
 // tile: the wave's parked accumulators = gradient w.r.t. the normalised (and rotated) rows, to be multiplied by `mul`.  x0 / o0: raw
 // features / output slot of the wave's row 0 (this head, this part), `pitch` elements between rows; nvalid rows of the 32 exist.
 // cs0 / sn0: RoPE factors of row 0's token (image rows; rows are consecutive tokens), nullptr for text rows.  Adds this wave's

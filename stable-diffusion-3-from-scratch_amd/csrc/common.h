@@ -90,6 +90,17 @@ __device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
 __device__ __forceinline__ void st4(float* p, const float (&v)[4]) { *(float4*)p = make_float4(v[0], v[1], v[2], v[3]); }
 __device__ __forceinline__ void st4(bf16_t* p, const float (&v)[4]) { *(uint2*)p = make_uint2(pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])); }
 
+// sum over the 8 lanes of a row (lane bits 2:0) on the DPP path (quad_perm 1032, quad_perm 2301, row_half_mirror): three dependent
+// VALU moves instead of three LDS round trips (ds_bpermute) -- the epilogue is a latency chain, not a throughput problem
+template <int CTRL> __device__ __forceinline__ float dpp_f(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum8(float x) {
+  x += dpp_f<0xB1>(x);
+  x += dpp_f<0x4E>(x);
+  return x + dpp_f<0x141>(x);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -343,7 +343,7 @@ __device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const G
         float ss = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; q++) ss += x[q] * x[q];
-        ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 4, 64);
+        ss = sum8(ss);      // (the 8 lanes of a row; DPP: the same pairs as the xor-1 / 2 / 4 butterfly of the stand-alone kernel, without its three LDS round trips)
         const float rinv = rsqrtf(ss * (1.f / 64.f) + 1.1920929e-07f);
 #pragma unroll
         for (int q = 0; q < 8; q++) x[q] = x[q] * rinv * w8[q];
