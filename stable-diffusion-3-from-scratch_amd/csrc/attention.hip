@@ -7,6 +7,7 @@
 //   addressing), V^T fragments come from a row-major [key][d] LDS tile via ds_read_b64_tr_b16.
 // Forward: one wave = 32 queries, KV tiles of 64 keys double-buffered through LDS.
 // Backward: two kernels (dQ: query-stationary; dK/dV: key-stationary) so nothing is atomically reduced.
+#include <type_traits>
 #include "common.h"
 
 namespace {
@@ -169,9 +170,15 @@ __device__ __forceinline__ void lds_row8(const float* tile, int r, int c, float 
 // features / output slot of the wave's row 0 (this head, this part), `pitch` elements between rows; nvalid rows of the 32 exist.
 // cs0 / sn0: RoPE factors of row 0's token (image rows; rows are consecutive tokens), nullptr for text rows.  Adds this wave's
 // norm-weight gradient into sdw[64] (LDS atomics from 8 lanes).
+// the raw rows qk_bwd_tile needs (4 passes x 16 bytes per lane), requested ahead of it
+__device__ __forceinline__ void qk_bwd_rows(u32x4 (&xr)[4], int lane, int nvalid, const bf16_t* x0, int64_t pitch) {
+  const int c = lane & 7, rsub = lane >> 3;
+#pragma unroll
+  for (int it = 0; it < 4; it++) xr[it] = __builtin_nontemporal_load((const u32x4*)(x0 + min(it * 8 + rsub, nvalid - 1) * pitch + 8 * c));
+}
 template <int IT0 = 0, int IT1 = 4>      // passes [IT0, IT1) of 8 rows each (the one-pass backward parks 16 rows at a time: `tile` then points 16 * (IT0 / 2) rows in front of the parked ones)
 __device__ __forceinline__ void qk_bwd_tile(const float* tile, float mul, int lane, int nvalid, const bf16_t* x0, bf16_t* o0, int64_t pitch,
-                                            const float* w, const float* cs0, const float* sn0, float* sdw) {
+                                            const float* w, const float* cs0, const float* sn0, float* sdw, const u32x4* xpre = nullptr) {
   const int c = lane & 7, rsub = lane >> 3;
   float w8[8], dw[8];
   ld8(w + 8 * c, w8);
@@ -179,48 +186,70 @@ __device__ __forceinline__ void qk_bwd_tile(const float* tile, float mul, int la
   for (int e = 0; e < 8; e++) dw[e] = 0.f;
   // the four passes' raw rows are requested up front (16 registers as packed bf16): their latency overlaps the first pass
   u32x4 xr[4];
+  if (xpre) {      // (compile-time at every call site: the caller requested the rows earlier -- qk_bwd_rows -- so that their latency lies under its barriers)
 #pragma unroll
-  for (int it = IT0; it < IT1; it++) xr[it] = __builtin_nontemporal_load((const u32x4*)(x0 + min(it * 8 + rsub, nvalid - 1) * pitch + 8 * c));   // (last use of the saved projection)
+    for (int it = IT0; it < IT1; it++) xr[it] = xpre[it];
+  } else {
 #pragma unroll
-  for (int it = IT0; it < IT1; it++) {
-    const int r = it * 8 + rsub;
-    const bool valid = r < nvalid;
-    const int rc = valid ? r : nvalid - 1;
-    float dz[8], x[8];
-#pragma unroll
-    for (int e = 0; e < 4; e++) { x[2 * e] = __builtin_bit_cast(float, xr[it][e] << 16); x[2 * e + 1] = __builtin_bit_cast(float, xr[it][e] & 0xffff0000u); }
-    lds_row8(tile, r, c, dz);
-#pragma unroll
-    for (int e = 0; e < 8; e++) dz[e] *= mul;
-    if (cs0) {   // transpose of the rotation: pairs (2p, 2p+1)
-      float c8[8], s8[8];
-      ld8(cs0 + rc * 64 + 8 * c, c8);
-      ld8(sn0 + rc * 64 + 8 * c, s8);
-#pragma unroll
-      for (int p = 0; p < 4; p++) {
-        const float da = dz[2 * p], dbv = dz[2 * p + 1];
-        dz[2 * p] = da * c8[2 * p] + dbv * s8[2 * p + 1];
-        dz[2 * p + 1] = dbv * c8[2 * p + 1] - da * s8[2 * p];
-      }
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; e++) ss += x[e] * x[e];
-    const float rinv = rsqrtf(sum8(ss) * (1.f / 64.f) + QK_RMS_EPS);
-    float dot = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-      x[e] *= rinv;                                      // xhat
-      dw[e] += valid ? dz[e] * x[e] : 0.f;               // d(norm weight)
-      dz[e] *= w8[e];                                    // d(xhat)
-      dot += dz[e] * x[e];
-    }
-    dot = sum8(dot) * (1.f / 64.f);
-    float o[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) o[e] = rinv * (dz[e] - x[e] * dot);
-    if (valid) st8(o0 + r * pitch + 8 * c, o);
+    for (int it = IT0; it < IT1; it++) xr[it] = __builtin_nontemporal_load((const u32x4*)(x0 + min(it * 8 + rsub, nvalid - 1) * pitch + 8 * c));   // (last use of the saved projection)
   }
+  // Round 6 (profiles/r06_epilogue_waits.txt).  Loads and stores of a wave retire through ONE in-order counter: a pass that requests its RoPE factors
+  // behind the previous pass's store waits for that store, and the compiler's count is exact only in straight-line code.  FULL (all 32 rows exist:
+  // every wave but the last one or two of a sequence) is therefore a compile-time variant without a conditional store, in which the factors of pass
+  // p + 1 are requested into the SAME registers right after pass p's last use of them and BEFORE its store: pass p + 1 then waits with vmcnt(1).
+  // Text rows (no rotation) read the norm weights -- 64 valid floats -- and ignore them, so that the load is unconditional too.
+  const bool rope = cs0 != nullptr;
+  const float* tc = rope ? cs0 : w;
+  const float* ts = rope ? sn0 : w;
+  auto body = [&](auto full_t) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_t)::value;
+    float c8[8], s8[8];
+    auto request = [&](int it) __attribute__((always_inline)) {
+      const int rq = rope ? (FULL ? it * 8 + rsub : min(it * 8 + rsub, nvalid - 1)) : 0;
+      ld8(tc + rq * 64 + 8 * c, c8);
+      ld8(ts + rq * 64 + 8 * c, s8);
+    };
+    request(IT0);
+#pragma unroll
+    for (int it = IT0; it < IT1; it++) {
+      const int r = it * 8 + rsub;
+      const bool valid = FULL || r < nvalid;
+      float dz[8], x[8];
+#pragma unroll
+      for (int e = 0; e < 4; e++) { x[2 * e] = __builtin_bit_cast(float, xr[it][e] << 16); x[2 * e + 1] = __builtin_bit_cast(float, xr[it][e] & 0xffff0000u); }
+      lds_row8(tile, r, c, dz);
+#pragma unroll
+      for (int e = 0; e < 8; e++) dz[e] *= mul;
+      if (rope) {   // transpose of the rotation: pairs (2p, 2p+1)
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+          const float da = dz[2 * p], dbv = dz[2 * p + 1];
+          dz[2 * p] = da * c8[2 * p] + dbv * s8[2 * p + 1];
+          dz[2 * p + 1] = dbv * c8[2 * p + 1] - da * s8[2 * p];
+        }
+      }
+      if (it + 1 < IT1) request(it + 1);      // (the factors of this pass are dead: same registers; before this pass's store)
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) ss += x[e] * x[e];
+      const float rinv = rsqrtf(sum8(ss) * (1.f / 64.f) + QK_RMS_EPS);
+      float dot = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        x[e] *= rinv;                                      // xhat
+        dw[e] += valid ? dz[e] * x[e] : 0.f;               // d(norm weight)
+        dz[e] *= w8[e];                                    // d(xhat)
+        dot += dz[e] * x[e];
+      }
+      dot = sum8(dot) * (1.f / 64.f);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) o[e] = rinv * (dz[e] - x[e] * dot);
+      if (valid) st8(o0 + r * pitch + 8 * c, o);
+    }
+  };
+  if (nvalid >= 8 * IT1) body(std::integral_constant<bool, true>{});
+  else body(std::integral_constant<bool, false>{});
   // the wave's 32 rows: lanes with equal c hold partial sums for features 8c .. 8c+7 (lane bits 5:3 = row lane)
 #pragma unroll
   for (int e = 0; e < 8; e++) {
@@ -995,20 +1024,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const bf16_t* __r
   stamp();                                   // loop end
   if constexpr (FUSE) {
     // dK rows -> gradient of the raw k projection (qk_bwd_tile), dV rows into the v part of the same output rows
+    const int k0 = ktile * 32 * NW + wave * 32;
+    const bool img = k0 < n_img;                                   // wave-uniform: n_img % 32 == 0
+    const int tok0 = img ? k0 : k0 - n_img, nvalid = min(32, (img ? n_img : S) - k0);
+    const int64_t pitch = 3 * (int64_t)D, off = (img ? b * n_img + tok0 : b * n_txt + tok0) * pitch + D + h * HD;
+    u32x4 xk[4];                           // the raw k rows: requested here, used behind the two barriers and the parking of dK
+    if (active) qk_bwd_rows(xk, lane, nvalid, (img ? F.qkv_x : F.qkv_c) + off, pitch);
     __syncthreads();                       // every wave has left the last Q / dO tile
     float* sdw = (float*)(smem + NW * QK_WAVE_BYTES);             // [image | text][64]
     if (tid < 128) sdw[tid] = 0.f;
     __syncthreads();
     if (active) {
-      const int k0 = ktile * 32 * NW + wave * 32;
-      const bool img = k0 < n_img;                                   // wave-uniform: n_img % 32 == 0
-      const int tok0 = img ? k0 : k0 - n_img, nvalid = min(32, (img ? n_img : S) - k0);
-      const int64_t pitch = 3 * (int64_t)D, off = (img ? b * n_img + tok0 : b * n_txt + tok0) * pitch + D + h * HD;
       bf16_t* ob = (img ? F.dqkv_x : F.dqkv_c) + off;
       float* tile = (float*)(smem + wave * QK_WAVE_BYTES);
       acc_to_lds(dk, tile, lane);
       qk_bwd_tile(tile, scale, lane, nvalid, (img ? F.qkv_x : F.qkv_c) + off, ob, pitch, img ? F.wk_x : F.wk_c,
-                  img ? F.rcos + (int64_t)tok0 * 64 : nullptr, img ? F.rsin + (int64_t)tok0 * 64 : nullptr, sdw + (img ? 0 : 64));
+                  img ? F.rcos + (int64_t)tok0 * 64 : nullptr, img ? F.rsin + (int64_t)tok0 * 64 : nullptr, sdw + (img ? 0 : 64), xk);
       __builtin_amdgcn_wave_barrier();
       acc_to_lds(dv, tile, lane);
       rows_from_tile(tile, lane, nvalid, ob + D, pitch);
