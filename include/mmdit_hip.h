@@ -144,7 +144,8 @@ int mmdit_gemm_zero_mask(const mmdit_gemm_args* args, int count, unsigned* mask)
  * RMS-normalised over the 64 features of their head (weights wq / wk, eps = finfo(float32).eps) and, when rope_cos / rope_sin (tokens, 64)
  * are given, rotated -- the arithmetic of mmdit_qk_norm_rope_fwd on the ROUNDED raw values, i.e. the same results without its pass.
  * MMDIT_ERR_SHAPE when the planner would not give these problems to the lean wide-slot kernel (run mmdit_gemm_grouped +
- * mmdit_qk_norm_rope_fwd_pair instead). */
+ * mmdit_qk_norm_rope_fwd_pair instead).  args[i].C may be NULL (inference: nobody reads the raw projection): the q / k columns are then not written
+ * either -- by the 8-phase kernel's epilogue only (e4m3 operands with MX scales, or bf16 operands with tile claiming on), MMDIT_ERR_SHAPE otherwise. */
 typedef struct mmdit_qk_epilogue {
   const float* wq; const float* wk;
   const float* rope_cos; const float* rope_sin;

@@ -328,6 +328,7 @@ struct QkRequest {
   const mmdit_qk_epilogue* qk;
   int heads, s_total;
   void* Q; void* K; void* V;
+  unsigned no_raw;      // bit i: problem i was given C == NULL (the raw q / k columns are not wanted)
 };
 
 static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_stream_t stream, bool plan_only, unsigned* zero_mask = nullptr, const QkRequest* qkr = nullptr,
@@ -562,6 +563,7 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
     // (round 5: ... and, for MX e4m3 operands, in the 8-phase kernel at 256 rows)
     const bool mxqk = dma && fp8 && gp.mx && cfg == CFG_256x256 && !a0->a_kmajor && a0->c_dtype == MMDIT_BF16;
     if (!(lean || mxqk) || count > 2 || a0->act != MMDIT_ACT_NONE || a0->b_kmajor) return MMDIT_ERR_SHAPE;
+    if (qkr->no_raw && !(cfg == CFG_256x256 && (mxqk || g_claiming[mmdit_current_device()]))) return MMDIT_ERR_SHAPE;      // (only the 8-phase kernel's epilogue can drop the raw columns)
     for (int i = 0; i < count; i++) {
       if (order[i] != i || args[i].bias || args[i].N != 3 * qkr->heads * 64 || qkr->qk[i].tokens <= 0 || args[i].M % qkr->qk[i].tokens) return MMDIT_ERR_SHAPE;
       gp.qk[i].wq = qkr->qk[i].wq; gp.qk[i].wk = qkr->qk[i].wk;
@@ -569,6 +571,8 @@ static int gemm_grouped_impl(const mmdit_gemm_args* args, int count, mmdit_strea
       gp.qk[i].tokens = qkr->qk[i].tokens; gp.qk[i].tok0 = qkr->qk[i].tok0;
     }
     if (count == 1) gp.qk[1] = gp.qk[0];
+    for (int i = 0; i < count; i++)
+      if ((qkr->no_raw >> i) & 1) gp.p[i].C = nullptr;
     gp.qk_on = 1; gp.qk_heads = qkr->heads; gp.qk_s_total = qkr->s_total;
     gp.qkQ = (bf16_t*)qkr->Q; gp.qkK = (bf16_t*)qkr->K; gp.qkV = (bf16_t*)qkr->V;
   }
@@ -636,8 +640,15 @@ extern "C" int mmdit_gemm_qkv_norm_rope(const mmdit_gemm_args* args, const mmdit
     MMDIT_CHECK_ARG(qk[i].wq && qk[i].wk && qk[i].tokens > 0 && qk[i].tok0 >= 0 && qk[i].tok0 + qk[i].tokens <= s_total);
     MMDIT_CHECK_ARG((qk[i].rope_cos == nullptr) == (qk[i].rope_sin == nullptr));
   }
-  const QkRequest r{qk, heads, s_total, Q, K, V};
-  return gemm_grouped_impl(args, count, stream, false, nullptr, &r);
+  // C == NULL: the raw q / k columns are not wanted (inference).  The planner sees a stand-in pointer (Q: valid, aligned, never written through C).
+  mmdit_gemm_args tmp[2];
+  unsigned no_raw = 0;
+  for (int i = 0; i < count; i++) {
+    tmp[i] = args[i];
+    if (!tmp[i].C) { tmp[i].C = Q; no_raw |= 1u << i; }
+  }
+  const QkRequest r{qk, heads, s_total, Q, K, V, no_raw};
+  return gemm_grouped_impl(no_raw ? tmp : args, count, stream, false, nullptr, &r);
 }
 
 extern "C" int mmdit_gemm_set_workspace(void* ptr, long long bytes) {

@@ -247,7 +247,7 @@ __device__ __forceinline__ void epi8_swiglu_bwd(AccT<MT>& acc, const Problem& p,
 // flight at the join is then unknown and the wait degrades to "everything but the newest request" -- the stores included) nor a conditional load
 // (a merge of old and new registers = copies that wait where the load was issued): FULL tiles are a compile-time variant, the factor loads are
 // unconditional (rows beyond M read the table's last row; a stream without rotation reads the norm weights -- 64 valid floats -- and ignores
-// them), the v columns have their own loop.  MX operands, MMDiT-L QKV (75392 x 3072 x 1024): 455 -> 420 us; bf16, MMDiT-B: 153 -> 131 us, the
+// them), the v columns have their own loop; C == nullptr (inference: nobody reads the raw q / k columns) skips the raw store.  MX operands, MMDiT-L QKV (75392 x 3072 x 1024): 455 -> 420 us; bf16, MMDiT-B: 153 -> 131 us, the
 // wide-slot kernel's time (profiles/r06_epilogue_waits.txt).  What remains is the compute unit's memory path: per tile 512 KB of operands, 213 KB
 // of stores and 341 KB of factors (the four waves of a row block read the same table rows).
 template <int MT>
@@ -312,8 +312,9 @@ __device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const G
     }
     return;
   }
-  auto qk_loop = [&](auto full_t) __attribute__((always_inline)) {
+  auto qk_loop = [&](auto full_t, auto raw_t) __attribute__((always_inline)) {
     constexpr bool FULL = decltype(full_t)::value;
+    constexpr bool RAW = decltype(raw_t)::value;      // the raw q / k columns are wanted (C != nullptr: training saves them for the backward; inference passes nullptr)
     request(0, 0, lane, cb[0], sb[0]);
 #pragma unroll
     for (int i = 0; i < Geo<MT>::NB32; i++) {
@@ -356,15 +357,22 @@ __device__ __forceinline__ void epi8_qk(AccT<MT>& acc, const Problem& p, const G
           }
         }
         if (FULL || row < p.M) {
-          *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
+          if constexpr (RAW) *(u32x4*)(C + (int64_t)row * p.ldc + col) = t;
           st8(dst, x);
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   };
-  if (m0 + MT <= p.M) qk_loop(std::integral_constant<bool, true>{});
-  else qk_loop(std::integral_constant<bool, false>{});
+  using std::integral_constant;
+  const bool full = m0 + MT <= p.M;
+  if (C) {
+    if (full) qk_loop(integral_constant<bool, true>{}, integral_constant<bool, true>{});
+    else qk_loop(integral_constant<bool, false>{}, integral_constant<bool, true>{});
+  } else {
+    if (full) qk_loop(integral_constant<bool, true>{}, integral_constant<bool, false>{});
+    else qk_loop(integral_constant<bool, false>{}, integral_constant<bool, false>{});
+  }
 }
 
 // SwiGLU-fused w12 GEMM: the wave's columns 0..31 are gate rows, 32..63 up rows of the SAME 32 hidden indices 128 tn + 32 wn + c (the DMA

@@ -354,7 +354,8 @@ def block_fwd(m, w, X, C, y, dims, rope, cond=None, keep=True, lazy=False):
             qq = [_to_fp8(m, p) for p in qp]
             qp = qq if all(x is not p for x, p in zip(qq, qp)) else None
         if qp is not None:
-            fused = ops.gemm_qkv_norm_rope(qp, [(w.wq_x, w.wk_x, rope[0], rope[1], N, 0), (w.wq_c, w.wk_c, None, None, Mt, N)], H, S, sv.Q, sv.K, sv.V)
+            # (MX operands = inference: the raw q / k columns, 2/3 of the projection's bytes, are saved for a backward that never comes -- not written)
+            fused = ops.gemm_qkv_norm_rope(qp, [(w.wq_x, w.wk_x, rope[0], rope[1], N, 0), (w.wq_c, w.wk_c, None, None, Mt, N)], H, S, sv.Q, sv.K, sv.V, raw=_QKV_RAW or not mxf)
     if fused is not None:
         sv.qkv_x, sv.qkv_c = fused
     else:
@@ -436,6 +437,7 @@ _LN_PAIR = _lib.experiment("MMDIT_LN_PAIR", "1") != "0"      # image + text rows
 _MX_FUSE = _lib.experiment("MMDIT_MX_FUSE", "1") != "0"      # 0: quantise passes in front of the fp8 GEMMs (A/B measurements, tests)
 _BATCH_WMOD = _lib.experiment("MMDIT_BATCH_WMOD", "1") != "0"   # single-rank backward: the modulation-matrix weight gradients of all blocks in one grouped launch (A/B switch)
 _QKV_FUSE = _lib.experiment("MMDIT_QKV_FUSE", "1") != "0"        # QK-norm + RoPE + joint-layout store inside the QKV GEMM epilogue (A/B switch)
+_QKV_RAW = _lib.experiment("MMDIT_QKV_RAW", "0") == "1"      # experiment: the fused MX QKV launch writes the raw q / k columns even when nobody reads them
 _QK_FUSE = _lib.experiment("MMDIT_ATTN_QK_FUSE", "1") != "0"     # QK-norm + RoPE backward inside the attention backward kernels (A/B switch)
 _FUSE_SWIGLU_BWD = _lib.experiment("MMDIT_FUSE_SWIGLU_BWD", "1") != "0"   # SwiGLU backward in the epilogue of the down-projection's data gradient (A/B switch)
 _FUSE_GATE = _lib.experiment("MMDIT_FUSE_GATE", "1") != "0"   # gated-residual backward inside the adaLN backward that produces its input (A/B switch)

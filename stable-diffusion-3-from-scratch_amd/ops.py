@@ -288,15 +288,24 @@ def gemm_swiglu_bwd(problems):
     return outs
 
 
-def gemm_qkv_norm_rope(problems, streams, heads, s_total, Q, K, V):
+def gemm_qkv_norm_rope(problems, streams, heads, s_total, Q, K, V, raw=True):
     """The QKV projection with QK-RMSNorm + RoPE + joint-layout store in the GEMM epilogue (mmdit_gemm_qkv_norm_rope): one launch.
     problems: 1 or 2 dicts of gemm() arguments (A = normed stream rows, B = packed [q | k | v] weight, out_dtype bf16; image stream first);
     streams[i] = (wq, wk, rope_cos | None, rope_sin | None, tokens per sample, joint position of token 0).  Returns the raw projections
-    (kept for backward: q and k columns; the v columns are not written, V holds them) or None when the planner would not run these problems on the lean wide-slot kernel (caller: GEMM + row kernel)."""
+    (kept for backward: q and k columns; the v columns are not written, V holds them) or None when the planner would not run these problems on the lean wide-slot kernel (caller: GEMM + row kernel).
+    raw=False (inference: nobody reads the raw projection): C = NULL, the q / k columns are not written either -- 8-phase kernel only (MX operands, or bf16 with tile claiming on),
+    otherwise None as above; returns [None] * n."""
     n = len(problems)
     _ensure_gemm_workspace(problems[0]["A"].device)
     arr = (GemmArgs * n)()
-    outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
+    if raw:
+        outs = [_fill_gemm(arr[i], **problems[i]) for i in range(n)]
+    else:
+        for i in range(n):      # (a one-row stand-in gives the planner the dtype and a legal row pitch; the pointer itself is NULL)
+            N_ = problems[i]["B"].shape[0]
+            _fill_gemm(arr[i], **dict(problems[i], out=torch.empty((1, N_), dtype=problems[i].get("out_dtype") or torch.bfloat16, device=problems[i]["A"].device)))
+            arr[i].C = None
+        outs = [None] * n
     qk = (_lib.QkEpilogue * n)()
     for i, (wq, wk, rc, rs, tokens, tok0) in enumerate(streams):
         qk[i].wq, qk[i].wk, qk[i].rope_cos, qk[i].rope_sin, qk[i].tokens, qk[i].tok0 = _p(wq), _p(wk), _p(rc), _p(rs), int(tokens), int(tok0)
@@ -310,7 +319,7 @@ def gemm_qkv_norm_rope(problems, streams, heads, s_total, Q, K, V):
     check(rc, "mmdit_gemm_qkv_norm_rope")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((_variant(arr, n, outs) + "+qk", sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
+        PROFILE.append((_variant(arr, n, outs if raw else [Q] * n) + "+qk", sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
     return outs
 
 

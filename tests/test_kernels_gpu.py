@@ -665,6 +665,14 @@ def test_gemm_qkv_epilogue_with_qk_norm_rope_equals_gemm_plus_row_kernel(ops, Bt
     qx, kx, vx = ref(X, Wx, N, wqx, wkx, True)
     qc, kc, vc = ref(C, Wc, Mt, wqc, wkc, False)
     assert rel(Q1, torch.cat([qx, qc], 2)) < 6e-3 and rel(K1, torch.cat([kx, kc], 2)) < 6e-3 and rel(V1, torch.cat([vx, vc], 2)) < 6e-3
+    # raw=False (C = NULL): only the 8-phase kernel's epilogue can drop the raw columns -- refused (None) on the wide-slot kernel, the same Q / K / V to the bit otherwise
+    Q3 = torch.full((Bt, H, S, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    K3, V3 = Q3.clone(), Q3.clone()
+    r3 = ops.gemm_qkv_norm_rope(probs(), [(wqx, wkx, cos, sin, N, 0), (wqc, wkc, None, None, Mt, N)], H, S, Q3, K3, V3, raw=False)
+    if claiming:
+        assert r3 == [None, None] and torch.equal(Q3, Q1) and torch.equal(K3, K1) and torch.equal(V3, V1)
+    else:
+        assert r3 is None
 
 
 @pytest.mark.parametrize("Bt,H,h2,w2,Mt,K", [(16, 16, 32, 32, 154, 1024), (8, 12, 16, 16, 154, 768)])
@@ -693,6 +701,11 @@ def test_gemm_qkv_epilogue_on_mx_operands_equals_gemm_plus_row_kernel(ops, Bt, H
         frac = float((a.view(torch.int16) != b_.view(torch.int16)).float().mean())
         assert frac < 1e-4 and rel(a, b_) < 1e-4, (name, frac, rel(a, b_))
     assert torch.equal(V1, V2)
+    # raw=False (inference): C = NULL, the raw q / k columns are not written -- the same Q, K, V to the bit
+    Q3 = torch.full((Bt, H, S, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    K3, V3 = Q3.clone(), Q3.clone()
+    assert ops.gemm_qkv_norm_rope(probs(), [(wqx, wkx, cos, sin, N, 0), (wqc, wkc, None, None, Mt, N)], H, S, Q3, K3, V3, raw=False) == [None, None]
+    assert torch.equal(Q3, Q1) and torch.equal(K3, K1) and torch.equal(V3, V1)
 
 
 def test_gemm_lean_weight_gradient_kernel(ops):
