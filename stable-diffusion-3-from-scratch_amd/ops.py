@@ -319,7 +319,9 @@ def gemm_qkv_norm_rope(problems, streams, heads, s_total, Q, K, V, raw=True):
     check(rc, "mmdit_gemm_qkv_norm_rope")
     if PROFILE is not None:
         e1.record()
-        PROFILE.append((_variant(arr, n, outs if raw else [Q] * n) + "+qk", sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
+        # (mmdit_gemm_plan knows nothing of the epilogue request: the fused launch runs on the wide-slot kernel -- bf16 -- or, MX operands / tile claiming on, on the 8-phase kernel)
+        on8 = arr[0].a_dtype == _lib.FP8 or bool(L.mmdit_gemm_get_claiming())
+        PROFILE.append((("gemm8_kernel<256,0,0,bf16>+qk" if on8 else "gemm_wide_kernel<2,4,5,2,0>+qk"), sum(2.0 * arr[i].M * arr[i].N * arr[i].K for i in range(n)), e0, e1))
     return outs
 
 
