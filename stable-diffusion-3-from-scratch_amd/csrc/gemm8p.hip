@@ -620,12 +620,16 @@ __device__ __forceinline__ void epi8_f32r(AccT<MT>& acc, const Problem& p, int m
 // a partial tile of the split tail into its workspace slot (row-major [256][256] fp32, device-scope write-through stores)
 template <int MT>
 __device__ __forceinline__ void epi8_f32_slot(AccT<MT>& acc, float* slot, int wm, int wn, int lane, char* stage) {
-  const int wr = lane & 15, wq = lane >> 4;
-  const int rr = lane >> 3, rc = lane & 7;
 #pragma unroll
   for (int i = 0; i < Geo<MT>::NB32; i++)
 #pragma unroll
     for (int j = 0; j < 2; j++) {
+      // (the lane id laundered per block: hoisted, the staging offsets of the 32 passes were spilled, and each reload -- scratch_load + vmcnt(0) -- waited for
+      //  the write-through store before it: profiles/r06_epilogue_waits.txt)
+      int ln = lane;
+      asm volatile("" : "+v"(ln));
+      const int wr = ln & 15, wq = ln >> 4;
+      const int rr = ln >> 3, rc = ln & 7;
 #pragma unroll
       for (int il = 0; il < 2; il++)
 #pragma unroll
