@@ -62,7 +62,7 @@ __device__ __forceinline__ f32x4& grp(AccT<MT>& acc, int i32, int q) {
 // ---- epilogues (the arithmetic and the read-back / store side are those of gemm_tile.h; only the write side knows the fragment layout) ------
 // bf16 output (+ bias, + SiLU): the wave's 32 x 64 block is converted first, staged as 32 rows x 128 B (chunk c of row r at c ^ (r & 7)) and
 // leaves as 8 rows x 128 B per wave instruction
-template <int MT, bool SC = false>      // SC (e4m3 operands with per-tensor scales): the accumulators are multiplied by alpha = scale_a * scale_b first
+template <int MT, bool SC = false, bool LAUNDER = SC>      // SC (e4m3 operands with per-tensor scales): the accumulators are multiplied by alpha = scale_a * scale_b first
 __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const GroupParams& gp, int m0, int n0, int wm, int wn, int lane, char* stage, float alpha = 1.f) {
   bf16_t* C = (bf16_t*)p.C;
   const float* bias = p.bias;
@@ -115,7 +115,9 @@ __device__ __forceinline__ void epi8_bf16(AccT<MT>& acc, const Problem& p, const
 #pragma unroll
   for (int i = 0; i < Geo<MT>::NB32; i++) {
     int ln = lane;
-    if constexpr (SC) asm volatile("" : "+v"(ln));      // (per-block address VALU instead of spilled offsets: see epi8_swiglu)
+    // (per-block address VALU instead of spilled offsets: see epi8_swiglu.  LAUNDER also for the 320-row data-gradient kernel -- 14 reloads -> 1, its launches
+    //  2-3 % faster --, NOT for the 320-row forward kernel: there it moves the remaining reloads into the K loop, tools/check_spills.py)
+    if constexpr (LAUNDER) asm volatile("" : "+v"(ln));
     const int wr = ln & 15, wq = ln >> 4, rr = ln >> 3, rc = ln & 7;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
@@ -1226,7 +1228,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(GroupParams gp) {
 #endif
   float alpha = 1.f;
   if constexpr (PT) alpha = q.scale_a[0] * q.scale_b[0];      // e4m3 operands with per-tensor scales (device scalars)
-  if constexpr (EPI == EPI_BF16) epi8_bf16<MT, MX>(acc, q, gp, m0, n0, wr, wc, lane, stage, alpha);
+  if constexpr (EPI == EPI_BF16) epi8_bf16<MT, MX, MX || (MT == 320 && B_KM)>(acc, q, gp, m0, n0, wr, wc, lane, stage, alpha);
   else if constexpr (EPI == EPI_SWIGLU) epi8_swiglu<MT, MX>(acc, q, m0, it.tn, wr, wc, lane, stage, alpha);
   else if constexpr (EPI == EPI_QK) epi8_qk<MT>(acc, q, gp, gp.qk[it.pi & 1], m0, n0, wr, wc, lane, stage);
   else if constexpr (EPI == EPI_SWIGLU_BWD) epi8_swiglu_bwd<MT>(acc, q, m0, n0, wr, wc, lane, stage);
