@@ -388,7 +388,11 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
   const int h = p.N >> 1;
   const int wr = lane & 15, wq = lane >> 4;
   const int hc = tn * 128 + wn * 32;
-  float bgv[2][4], buv[2][4];
+  float bgv[2][4], buv[2][4];      // (zeros without a bias: the add below is unconditional -- inside the unrolled loops `if (bias)` became a select per accumulator value)
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) bgv[j][e] = buv[j][e] = 0.f;
   if (bias) {
 #pragma unroll
     for (int j = 0; j < 2; j++) {
@@ -416,10 +420,8 @@ __device__ __forceinline__ void epi8_swiglu(AccT<MT>& acc, const Problem& p, int
 #pragma unroll
           for (int e = 0; e < 4; e++) { vg[e] *= alpha; vu[e] *= alpha; }
         }
-        if (bias) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) { vg[e] += bgv[j][e]; vu[e] += buv[j][e]; }
-        }
+        for (int e = 0; e < 4; e++) { vg[e] += bgv[j][e]; vu[e] += buv[j][e]; }
         const u32x2 pg = {pack_bf2(vg[0], vg[1]), pack_bf2(vg[2], vg[3])}, pu = {pack_bf2(vu[0], vu[1]), pack_bf2(vu[2], vu[3])};
         const int row = il * 16 + wr;
         if (GU) {   // staged as 32 rows x 128 B: chunks 0..3 = gate columns, 4..7 = up columns
